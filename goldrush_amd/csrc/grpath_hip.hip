@@ -1,0 +1,1678 @@
+// libgrpath_hip.so — hand-written gfx950 (CDNA4) kernels + the C ABI of
+// include/grpath.h.  Integer / bit-vector work, HBM-transaction bound: no MFMA.
+//
+// Kernels
+//   k_fill        spaced-seed ntHash of every read position + test-and-set of
+//                 bit (hash % m)           (goldrush_path.cpp:304-305,
+//                 MIBFConstructSupport.hpp:134-147)
+//   k_rank_*      popcount prefix scan -> per-block relative rank + superblock
+//                 table                    (MIBFConstructSupport.hpp:165-170)
+//   k_query       fused hash -> probe (bit+rank, then ID) -> per-frame ID
+//                 dedup -> per-tile LDS count table -> top ID + count>2 list
+//                 (read_hashing.cpp:29-54, goldrush_path.cpp:544-626)
+//   k_insert      hash -> rank -> exact per-call rank dedup -> reservoir rule
+//                 (MIBFConstructSupport.hpp:247-283)
+#include "grp_device.h"
+
+#include "../../include/grpath.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// host-side context
+// ---------------------------------------------------------------------------
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair
+{
+  hipEvent_t a, b;
+  int kind;
+};
+
+} // namespace
+
+struct grp_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  grp_params params{};
+  std::vector<std::string> seeds;
+  DevSeeds h_seeds{};
+  DevSeeds* d_seeds = nullptr;
+  DevFilter f{};
+  uint64_t nsb = 0;      // superblocks
+  uint64_t n_chunks = 0; // rank-build chunks
+  uint64_t* d_super = nullptr;
+  bool finalized = false;
+  // query scratch
+  grp_tile_summary* d_tiles = nullptr;
+  uint64_t d_tiles_cap = 0;
+  grp_id_count* d_lists = nullptr;
+  uint64_t d_lists_cap = 0;
+  uint64_t* d_qctr = nullptr; // [0..2] stats, [3] list arena cursor
+  uint64_t* h_qctr = nullptr; // pinned
+  // insert scratch
+  unsigned long long* d_dedup = nullptr;
+  uint64_t dedup_cap = 0;
+  uint32_t epoch = 0;
+  // timing
+  bool timing = true;
+  std::vector<EventPair> pending;
+  std::vector<EventPair> free_events;
+  grp_kernel_stat kstat[GRP_K_COUNT]{};
+  mutable std::string err;
+  // LDS geometry of the query kernel
+  uint32_t hist_cap = 0; // power of two
+  uint32_t list_cap_lds = 0;
+};
+
+struct grp_reads
+{
+  grp_ctx* ctx = nullptr;
+  uint32_t n_reads = 0;
+  uint64_t n_words = 0;
+  bool owns_packed = false;
+  uint32_t* d_packed = nullptr;
+  uint64_t* d_word_off = nullptr;
+  uint32_t* d_len = nullptr;
+  uint64_t* d_tile0 = nullptr;
+  uint32_t* d_tile_read = nullptr;
+  uint64_t* d_chunk0 = nullptr;
+  uint32_t* d_chunk_read = nullptr;
+  std::vector<uint64_t> tile0;  // host copy
+  std::vector<uint64_t> chunk0; // host copy
+  std::vector<uint32_t> len;    // host copy
+  DevReads dev{};
+};
+
+namespace {
+
+int
+set_err(const grp_ctx* ctx, int code, const char* fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) {
+    ctx->err = buf;
+  } else {
+    g_create_error = buf;
+  }
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                             \
+  do {                                                                                                                 \
+    hipError_t e_ = (expr);                                                                                            \
+    if (e_ != hipSuccess) {                                                                                            \
+      return set_err(ctx, GRP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);     \
+    }                                                                                                                  \
+  } while (0)
+
+constexpr uint32_t FILL_CHUNK = 2048; // read positions per fill workgroup
+constexpr int THREADS = 256;
+
+// ---- ntHash (btllib::SeedNtHash, restated; see DESIGN.md "Hash") -----------
+
+uint64_t
+srol_n(uint64_t x, unsigned d)
+{
+  const uint64_t M33 = 0x1FFFFFFFFULL, M31 = 0x7FFFFFFFULL;
+  uint64_t lo = x & M33, hi = (x >> 33) & M31;
+  unsigned rl = d % 33, rh = d % 31;
+  if (rl) {
+    lo = ((lo << rl) | (lo >> (33 - rl))) & M33;
+  }
+  if (rh) {
+    hi = ((hi << rh) | (hi >> (31 - rh))) & M31;
+  }
+  return (hi << 33) | lo;
+}
+
+const uint64_t BASE_SEED[4] = { 0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x20323ed082572324ULL, 0x295549f54be24456ULL };
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// device code
+// ---------------------------------------------------------------------------
+
+// 64-bit window of 2-bit bases starting at base index `b` of the staged words
+__device__ inline uint64_t
+window_at(const uint32_t* sBases, uint32_t b)
+{
+  uint32_t bit = b * 2u;
+  uint32_t wi = bit >> 5;
+  uint32_t sh = bit & 31u;
+  uint64_t lo = (uint64_t)sBases[wi] | ((uint64_t)sBases[wi + 1] << 32);
+  uint64_t w = lo >> sh;
+  if (sh) {
+    w |= (uint64_t)sBases[wi + 2] << (64u - sh);
+  }
+  return w;
+}
+
+// hash of seed s on window w (closed form: XOR of per-position table entries,
+// fwd + rev); tab is the LDS copy [s][i][b]
+__device__ inline uint64_t
+seed_hash(const ulonglong2* sTab, const DevSeeds* __restrict__ sd, uint32_t s, uint64_t w)
+{
+  uint64_t fwd = 0, rev = 0;
+  const uint32_t wt = sd->weight[s];
+  const ulonglong2* t = sTab + (size_t)s * sd->wmax * 4u;
+  for (uint32_t i = 0; i < wt; ++i) {
+    uint32_t b = (uint32_t)(w >> sd->shift[s][i]) & 3u;
+    ulonglong2 e = t[i * 4u + b];
+    fwd ^= e.x;
+    rev ^= e.y;
+  }
+  return fwd + rev;
+}
+
+__device__ inline void
+load_tab(ulonglong2* sTab, const DevSeeds* __restrict__ sd)
+{
+  const uint32_t n = sd->h * sd->wmax * 4u;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    uint32_t s = i / (sd->wmax * 4u);
+    uint32_t r = i - s * sd->wmax * 4u;
+    sTab[i] = sd->tab[s][r >> 2][r & 3u];
+  }
+}
+
+// stage bases [b0, b0+nb) of a read into LDS words (plus 2 zero pad words);
+// returns the base offset of b0 inside the staged words
+__device__ inline uint32_t
+stage_bases(uint32_t* sBases, const uint32_t* __restrict__ packed, uint64_t word_off, uint32_t len, uint32_t b0, uint32_t nb)
+{
+  const uint32_t w0 = b0 >> 4;
+  const uint32_t w_last = (b0 + nb + 15u) >> 4; // exclusive
+  const uint32_t w_read = (len + 15u) >> 4;     // words the read owns
+  const uint32_t nw = w_last - w0 + 2u;
+  for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) {
+    uint32_t w = w0 + i;
+    sBases[i] = (w < w_read) ? packed[word_off + w] : 0u;
+  }
+  return b0 & 15u;
+}
+
+// ---- wave / block reductions -------------------------------------------------
+
+__device__ inline uint32_t
+wave_sum(uint32_t v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_xor(v, o, 64);
+  }
+  return v;
+}
+
+// ---- fill ------------------------------------------------------------------------
+
+template<int H>
+__global__ void __launch_bounds__(THREADS)
+k_fill(DevFilter f, DevReads rd, const DevSeeds* __restrict__ sd, uint64_t chunk_begin)
+{
+  extern __shared__ uint4 smem4[];
+  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
+  uint32_t* sBases = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
+
+  const uint64_t chunk = chunk_begin + blockIdx.x;
+  const uint32_t r = rd.chunk_read[chunk];
+  const uint32_t ci = (uint32_t)(chunk - rd.chunk0[r]);
+  const uint32_t len = rd.len[r];
+  const uint32_t k = sd->k;
+  const uint32_t npos = len - k + 1u; // chunk exists => len >= k + H - 1
+  const uint32_t p0 = ci * FILL_CHUNK;
+  const uint32_t np = min(FILL_CHUNK, npos - p0);
+
+  load_tab(sTab, sd);
+  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[r], len, p0, np + k + H - 2u);
+  __syncthreads();
+
+  uint32_t* words = reinterpret_cast<uint32_t*>(f.blocks);
+  constexpr int FR = 4;
+  for (uint32_t i0 = threadIdx.x; i0 < np; i0 += THREADS * FR) {
+    uint64_t widx[FR][H];
+    uint32_t mask[FR][H];
+    uint32_t val[FR][H];
+#pragma unroll
+    for (int j = 0; j < FR; ++j) {
+      const uint32_t i = i0 + j * THREADS;
+      const uint32_t p = p0 + i;
+#pragma unroll
+      for (int s = 0; s < H; ++s) {
+        // seed s is valid at read position p iff p + span_s <= len
+        // (stale re-inserts of the iterator set the same bit again)
+        const bool ok = (i < np) && (p + sd->span[s] <= len);
+        mask[j][s] = 0;
+        widx[j][s] = 0;
+        if (ok) {
+          uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + i));
+          uint64_t pos = grp_mod_m(hv, f.m, f.m_inv);
+          uint64_t blk = pos / GRP_BLOCK_BITS;
+          uint32_t off = (uint32_t)(pos - blk * GRP_BLOCK_BITS);
+          widx[j][s] = blk * 4u + 1u + (off >> 5);
+          mask[j][s] = 1u << (off & 31u);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FR; ++j) {
+#pragma unroll
+      for (int s = 0; s < H; ++s) {
+        val[j][s] = mask[j][s] ? words[widx[j][s]] : 0xFFFFFFFFu;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FR; ++j) {
+#pragma unroll
+      for (int s = 0; s < H; ++s) {
+        if (mask[j][s] & ~val[j][s]) {
+          atomicOr(&words[widx[j][s]], mask[j][s]);
+        }
+      }
+    }
+  }
+}
+
+// ---- rank build ------------------------------------------------------------------
+
+__device__ inline uint32_t
+block_pop(const uint4& b)
+{
+  return __popc(b.y) + __popc(b.z) + __popc(b.w);
+}
+
+// per-chunk popcount
+__global__ void __launch_bounds__(THREADS)
+k_rank_chunk_sums(const uint4* __restrict__ blocks, uint64_t nblk, uint32_t* __restrict__ chunk_sum)
+{
+  __shared__ uint32_t sW[THREADS / 64];
+  const uint64_t b0 = (uint64_t)blockIdx.x * GRP_CHUNK_BLOCKS;
+  uint32_t acc = 0;
+  for (uint32_t i = threadIdx.x; i < GRP_CHUNK_BLOCKS; i += THREADS) {
+    uint64_t b = b0 + i;
+    if (b < nblk) {
+      acc += block_pop(blocks[b]);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) {
+    sW[threadIdx.x >> 6] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < THREADS / 64; ++w) {
+      t += sW[w];
+    }
+    chunk_sum[blockIdx.x] = t;
+  }
+}
+
+// single workgroup: exclusive scan of the chunk sums (uint64), superblock table, pop
+__global__ void __launch_bounds__(1024)
+k_rank_scan_chunks(const uint32_t* __restrict__ chunk_sum, uint64_t n_chunks, uint64_t* __restrict__ chunk_base, uint64_t* __restrict__ super, uint64_t* __restrict__ pop_out)
+{
+  __shared__ uint64_t sScan[1024];
+  __shared__ uint64_t sCarry;
+  if (threadIdx.x == 0) {
+    sCarry = 0;
+  }
+  __syncthreads();
+  const uint32_t chunks_per_super = (1u << GRP_SUPER_SHIFT) / GRP_CHUNK_BLOCKS;
+  for (uint64_t c0 = 0; c0 < n_chunks; c0 += 1024) {
+    uint64_t c = c0 + threadIdx.x;
+    uint64_t v = (c < n_chunks) ? chunk_sum[c] : 0;
+    sScan[threadIdx.x] = v;
+    __syncthreads();
+    // Hillis-Steele inclusive scan
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+      uint64_t t = (threadIdx.x >= o) ? sScan[threadIdx.x - o] : 0;
+      __syncthreads();
+      sScan[threadIdx.x] += t;
+      __syncthreads();
+    }
+    uint64_t excl = sCarry + sScan[threadIdx.x] - v;
+    if (c < n_chunks) {
+      chunk_base[c] = excl;
+      if (c % chunks_per_super == 0) {
+        super[c / chunks_per_super] = excl;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) {
+      sCarry += sScan[1023];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *pop_out = sCarry;
+  }
+}
+
+// write the relative rank into every block of a chunk
+__global__ void __launch_bounds__(THREADS)
+k_rank_write(uint4* __restrict__ blocks, uint64_t nblk, const uint64_t* __restrict__ chunk_base, const uint64_t* __restrict__ super)
+{
+  constexpr uint32_t PER = GRP_CHUNK_BLOCKS / THREADS; // consecutive blocks per thread
+  __shared__ uint32_t sScan[THREADS];
+  const uint64_t chunk = blockIdx.x;
+  const uint64_t b0 = chunk * GRP_CHUNK_BLOCKS + (uint64_t)threadIdx.x * PER;
+  uint32_t pc[PER];
+  uint32_t tot = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < PER; ++i) {
+    uint64_t b = b0 + i;
+    pc[i] = (b < nblk) ? block_pop(blocks[b]) : 0u;
+    tot += pc[i];
+  }
+  sScan[threadIdx.x] = tot;
+  __syncthreads();
+  for (uint32_t o = 1; o < THREADS; o <<= 1) {
+    uint32_t t = (threadIdx.x >= o) ? sScan[threadIdx.x - o] : 0;
+    __syncthreads();
+    sScan[threadIdx.x] += t;
+    __syncthreads();
+  }
+  const uint64_t sb = (chunk * GRP_CHUNK_BLOCKS) >> GRP_SUPER_SHIFT;
+  uint32_t rel = (uint32_t)(chunk_base[chunk] - super[sb]) + sScan[threadIdx.x] - tot;
+#pragma unroll
+  for (uint32_t i = 0; i < PER; ++i) {
+    uint64_t b = b0 + i;
+    if (b < nblk) {
+      reinterpret_cast<uint32_t*>(&blocks[b])[0] = rel;
+    }
+    rel += pc[i];
+  }
+}
+
+// ---- query -------------------------------------------------------------------------
+
+__device__ inline void
+hist_add(uint32_t* keys, uint32_t* cnts, uint32_t mask, uint32_t id)
+{
+  uint32_t slot = (id * 2654435761u) & mask;
+  for (;;) {
+    uint32_t old = atomicCAS(&keys[slot], 0u, id);
+    if (old == 0u || old == id) {
+      atomicAdd(&cnts[slot], 1u);
+      return;
+    }
+    slot = (slot + 1u) & mask;
+  }
+}
+
+// (count, id) ordering of calc_num_assigned_tiles :607-615: larger count wins,
+// equal counts -> smaller id (std::map ascending + strict '>')
+__device__ inline bool
+better(uint32_t c, uint32_t id, uint32_t bc, uint32_t bid)
+{
+  return (c > bc) || (c == bc && c != 0u && id < bid);
+}
+
+template<int H, int FR>
+__global__ void __launch_bounds__(THREADS)
+k_query(DevFilter f,
+        DevReads rd,
+        const DevSeeds* __restrict__ sd,
+        uint32_t tile_len,
+        uint64_t tile_begin,
+        uint32_t hist_cap,
+        uint32_t list_cap_lds,
+        grp_tile_summary* __restrict__ tiles_out,
+        grp_id_count* __restrict__ lists_out,
+        uint64_t lists_cap,
+        unsigned long long* __restrict__ ctr)
+{
+  extern __shared__ uint4 smem4[];
+  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
+  uint32_t* sKeys = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
+  uint32_t* sCnts = sKeys + hist_cap;
+  grp_id_count* sList = reinterpret_cast<grp_id_count*>(sCnts + hist_cap);
+  uint32_t* sBases = reinterpret_cast<uint32_t*>(sList + list_cap_lds);
+  __shared__ uint32_t sListN;
+  __shared__ uint32_t sRed[3 * (THREADS / 64)];
+  __shared__ uint32_t sBest[2 * (THREADS / 64)];
+  __shared__ uint32_t sListOff;
+
+  const uint64_t t = tile_begin + blockIdx.x;
+  const uint32_t r = rd.tile_read[t];
+  const uint32_t ti = (uint32_t)(t - rd.tile0[r]);
+  const uint32_t len = rd.len[r];
+  const uint32_t k = sd->k;
+  // tile string = seq.substr(ti*tile, tile + k - 1)   (read_hashing.cpp:44-45)
+  const uint32_t start = ti * tile_len;
+  const uint32_t Lp = min(tile_len + k - 1u, len - start);
+  const uint32_t frames = (Lp >= k) ? (Lp - k + 1u) : 0u;
+
+  load_tab(sTab, sd);
+  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[r], len, start, Lp);
+  for (uint32_t i = threadIdx.x; i < hist_cap; i += THREADS) {
+    sKeys[i] = 0u;
+    sCnts[i] = 0u;
+  }
+  if (threadIdx.x == 0) {
+    sListN = 0;
+  }
+  __syncthreads();
+
+  const uint32_t hmask = hist_cap - 1u;
+  uint32_t n_hit = 0, n_miss = 0;
+
+  for (uint32_t f0 = threadIdx.x; f0 < frames; f0 += THREADS * FR) {
+    uint64_t blk[FR][H];
+    uint32_t off[FR][H];
+    uint4 bv[FR][H];
+    // 1) hashes -> positions -> block loads
+#pragma unroll
+    for (int j = 0; j < FR; ++j) {
+      const uint32_t fr = f0 + j * THREADS;
+      const bool live = fr < frames;
+#pragma unroll
+      for (int s = 0; s < H; ++s) {
+        // a seed that can no longer roll keeps its last value
+        // (multiLensfrHashIterator.hpp:49-68): clamp its frame index
+        const uint32_t last = Lp - sd->span[s];
+        const uint32_t fs = min(fr, last);
+        uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + (live ? fs : 0u)));
+        uint64_t pos = grp_mod_m(hv, f.m, f.m_inv);
+        uint64_t b = pos / GRP_BLOCK_BITS;
+        blk[j][s] = b;
+        off[j][s] = (uint32_t)(pos - b * GRP_BLOCK_BITS);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FR; ++j) {
+      const bool live = (f0 + j * THREADS) < frames;
+#pragma unroll
+      for (int s = 0; s < H; ++s) {
+        bv[j][s] = live ? f.blocks[blk[j][s]] : make_uint4(0, 0, 0, 0);
+      }
+    }
+    // 2) bit + rank -> ID loads
+    uint32_t idv[FR][H];
+    bool all_set[FR];
+#pragma unroll
+    for (int j = 0; j < FR; ++j) {
+      const bool live = (f0 + j * THREADS) < frames;
+      bool all = live;
+      uint64_t rk[H];
+#pragma unroll
+      for (int s = 0; s < H; ++s) {
+        all = all && grp_block_bit(bv[j][s], off[j][s]);
+        rk[s] = f.super[blk[j][s] >> GRP_SUPER_SHIFT] + bv[j][s].x + grp_block_rank(bv[j][s], off[j][s]);
+      }
+      all_set[j] = all; // atRank (MIBloomFilter.hpp:465-476)
+#pragma unroll
+      for (int s = 0; s < H; ++s) {
+        idv[j][s] = all ? f.idc[rk[s]].x : 0u; // getData (:614-621)
+      }
+    }
+    // 3) per-frame ID set -> tile count table
+#pragma unroll
+    for (int j = 0; j < FR; ++j) {
+      if (!all_set[j]) {
+        continue;
+      }
+      uint32_t ids[H];
+#pragma unroll
+      for (int s = 0; s < H; ++s) {
+        uint32_t d = idv[j][s];
+        // saturation bit stripped exactly as goldrush_path.cpp:573-594
+        uint32_t id = (d > 0x80000000u) ? (d & 0x7FFFFFFFu) : d;
+        if (id == 0u) {
+          ++n_miss;
+        } else {
+          ++n_hit;
+        }
+        bool dup = false;
+#pragma unroll
+        for (int u = 0; u < s; ++u) {
+          dup = dup || (ids[u] == id);
+        }
+        ids[s] = id;
+        if (id != 0u && !dup) {
+          hist_add(sKeys, sCnts, hmask, id);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // top ID + count>2 list
+  uint32_t bc = 0, bid = 0;
+  for (uint32_t i = threadIdx.x; i < hist_cap; i += THREADS) {
+    uint32_t key = sKeys[i];
+    if (key != 0u) {
+      uint32_t c = sCnts[i];
+      if (better(c, key, bc, bid)) {
+        bc = c;
+        bid = key;
+      }
+      if (c > 2u) {
+        uint32_t li = atomicAdd(&sListN, 1u);
+        if (li < list_cap_lds) {
+          sList[li].id = key;
+          sList[li].count = c;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t oc = __shfl_xor(bc, o, 64);
+    uint32_t oid = __shfl_xor(bid, o, 64);
+    if (better(oc, oid, bc, bid)) {
+      bc = oc;
+      bid = oid;
+    }
+  }
+  n_hit = wave_sum(n_hit);
+  n_miss = wave_sum(n_miss);
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sBest[2 * wave] = bc;
+    sBest[2 * wave + 1] = bid;
+    sRed[3 * wave] = n_hit;
+    sRed[3 * wave + 1] = n_miss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t hsum = 0, msum = 0;
+    for (int w = 0; w < THREADS / 64; ++w) {
+      if (better(sBest[2 * w], sBest[2 * w + 1], bc, bid)) {
+        bc = sBest[2 * w];
+        bid = sBest[2 * w + 1];
+      }
+      hsum += sRed[3 * w];
+      msum += sRed[3 * w + 1];
+    }
+    const uint32_t n = sListN;
+    uint64_t lo = 0;
+    if (n) {
+      lo = atomicAdd(&ctr[3], (unsigned long long)n);
+    }
+    sListOff = (uint32_t)lo;
+    grp_tile_summary ts;
+    ts.top_id = bid;
+    ts.top_count = bc;
+    ts.list_off = (uint32_t)lo;
+    ts.list_n = n;
+    tiles_out[blockIdx.x] = ts;
+    atomicAdd(&ctr[0], (unsigned long long)frames);
+    if (hsum) {
+      atomicAdd(&ctr[1], (unsigned long long)hsum);
+    }
+    if (msum) {
+      atomicAdd(&ctr[2], (unsigned long long)msum);
+    }
+  }
+  __syncthreads();
+  const uint32_t n = min(sListN, list_cap_lds);
+  const uint64_t lo = sListOff;
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
+    if (lo + i < lists_cap) {
+      lists_out[lo + i] = sList[i];
+    }
+  }
+}
+
+// ---- insert ------------------------------------------------------------------------
+
+// claim `key` in the per-call dedup set; true for exactly one caller per key.
+// Entries tagged with an older epoch count as empty (no clearing between calls).
+__device__ inline bool
+dedup_claim(unsigned long long* table, uint64_t cap_mask, unsigned long long key, unsigned long long epoch_tag)
+{
+  uint64_t slot = (key * 0x9E3779B97F4A7C15ULL) >> 20 & cap_mask;
+  for (;;) {
+    unsigned long long cur = table[slot];
+    for (;;) {
+      if (cur == key) {
+        return false;
+      }
+      if ((cur & 0xFFFFFF0000000000ULL) == epoch_tag) {
+        break; // occupied by another rank of this call -> next slot
+      }
+      unsigned long long prev = atomicCAS(&table[slot], cur, key);
+      if (prev == cur) {
+        return true;
+      }
+      cur = prev;
+    }
+    slot = (slot + 1) & cap_mask;
+  }
+}
+
+template<int H>
+__global__ void __launch_bounds__(THREADS)
+k_insert(DevFilter f,
+         DevReads rd,
+         const DevSeeds* __restrict__ sd,
+         uint32_t tile_len,
+         uint32_t read_idx,
+         uint32_t tile_start,
+         uint32_t id,
+         unsigned long long* __restrict__ dedup,
+         uint64_t dedup_mask,
+         unsigned long long epoch_tag)
+{
+  extern __shared__ uint4 smem4[];
+  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
+  uint32_t* sBases = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
+
+  const uint32_t r = read_idx;
+  const uint32_t ti = tile_start + blockIdx.x;
+  const uint32_t len = rd.len[r];
+  const uint32_t k = sd->k;
+  const uint32_t start = ti * tile_len;
+  const uint32_t Lp = min(tile_len + k - 1u, len - start);
+  const uint32_t frames = (Lp >= k) ? (Lp - k + 1u) : 0u;
+
+  load_tab(sTab, sd);
+  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[r], len, start, Lp);
+  __syncthreads();
+
+  for (uint32_t fr = threadIdx.x; fr < frames; fr += THREADS) {
+    uint64_t blk[H];
+    uint32_t off[H];
+    uint4 bv[H];
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+      const uint32_t fs = min(fr, Lp - sd->span[s]);
+      uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + fs));
+      uint64_t pos = grp_mod_m(hv, f.m, f.m_inv);
+      blk[s] = pos / GRP_BLOCK_BITS;
+      off[s] = (uint32_t)(pos - blk[s] * GRP_BLOCK_BITS);
+    }
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+      bv[s] = f.blocks[blk[s]];
+    }
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+      // getRankPos (MIBloomFilter.hpp:488-491): rank only, the bit is not tested
+      uint64_t rank = f.super[blk[s] >> GRP_SUPER_SHIFT] + bv[s].x + grp_block_rank(bv[s], off[s]);
+      if (rank >= f.pop) {
+        continue; // out of range in the reference too (position past the last set bit)
+      }
+      if (dedup_claim(dedup, dedup_mask, epoch_tag | rank, epoch_tag)) {
+        // MIBFConstructSupport.hpp:274-282 ; the only writer of this rank in this call
+        uint2 e = f.idc[rank];
+        uint32_t count = e.y + 1u;
+        uint32_t random_num = (uint32_t)(rank ^ (uint64_t)id) % count;
+        if (random_num == count - 1u) {
+          // setData (MIBloomFilter.hpp:593-602): keep a set saturation bit
+          e.x = (e.x > 0x80000000u) ? (id | 0x80000000u) : id;
+        }
+        e.y = count;
+        f.idc[rank] = e;
+      }
+    }
+  }
+}
+
+// ---- inspection kernels ----------------------------------------------------------
+
+__global__ void
+k_export_bits(const uint4* __restrict__ blocks, uint64_t m, uint64_t n_words, unsigned long long* __restrict__ out)
+{
+  uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) {
+    return;
+  }
+  unsigned long long v = 0;
+  for (uint32_t i = 0; i < 64; ++i) {
+    uint64_t pos = w * 64 + i;
+    if (pos >= m) {
+      break;
+    }
+    uint64_t b = pos / GRP_BLOCK_BITS;
+    uint32_t off = (uint32_t)(pos - b * GRP_BLOCK_BITS);
+    uint4 bl = blocks[b];
+    v |= (unsigned long long)grp_block_bit(bl, off) << i;
+  }
+  out[w] = v;
+}
+
+__global__ void
+k_rank_positions(DevFilter f, const uint64_t* __restrict__ pos, uint64_t n, uint8_t* __restrict__ bit, uint64_t* __restrict__ rank)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) {
+    return;
+  }
+  uint64_t p = pos[i];
+  uint64_t b = p / GRP_BLOCK_BITS;
+  uint32_t off = (uint32_t)(p - b * GRP_BLOCK_BITS);
+  uint4 bl = f.blocks[b];
+  bit[i] = (uint8_t)grp_block_bit(bl, off);
+  rank[i] = f.super[b >> GRP_SUPER_SHIFT] + bl.x + grp_block_rank(bl, off);
+}
+
+template<int H>
+__global__ void __launch_bounds__(THREADS)
+k_debug_tile_hashes(DevReads rd, const DevSeeds* __restrict__ sd, uint32_t tile_len, uint32_t read_idx, uint32_t tile_idx, uint64_t* __restrict__ out, uint64_t cap)
+{
+  extern __shared__ uint4 smem4[];
+  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
+  uint32_t* sBases = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
+  const uint32_t len = rd.len[read_idx];
+  const uint32_t k = sd->k;
+  const uint32_t start = tile_idx * tile_len;
+  const uint32_t Lp = min(tile_len + k - 1u, len - start);
+  const uint32_t frames = (Lp >= k) ? (Lp - k + 1u) : 0u;
+  load_tab(sTab, sd);
+  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[read_idx], len, start, Lp);
+  __syncthreads();
+  for (uint32_t fr = threadIdx.x; fr < frames; fr += THREADS) {
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+      const uint32_t fs = min(fr, Lp - sd->span[s]);
+      uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + fs));
+      uint64_t o = (uint64_t)fr * H + s;
+      if (o < cap) {
+        out[o] = hv;
+      }
+    }
+  }
+}
+
+__global__ void
+k_split_idc(const uint2* __restrict__ idc, uint64_t first, uint64_t n, uint32_t* __restrict__ ids, uint32_t* __restrict__ counts)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    uint2 e = idc[first + i];
+    ids[i] = e.x;
+    counts[i] = e.y;
+  }
+}
+
+__global__ void
+k_merge_idc(uint2* __restrict__ idc, uint64_t first, uint64_t n, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ counts)
+{
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    uint2 e = idc[first + i];
+    if (ids) {
+      e.x = ids[i];
+    }
+    if (counts) {
+      e.y = counts[i];
+    }
+    idc[first + i] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+namespace {
+
+struct Timer
+{
+  grp_ctx* c;
+  EventPair ep{};
+  bool on = false;
+  Timer(grp_ctx* ctx, int kind, uint64_t units)
+    : c(ctx)
+  {
+    c->kstat[kind].launches += 1;
+    c->kstat[kind].units += units;
+    if (!c->timing) {
+      return;
+    }
+    if (!c->free_events.empty()) {
+      ep = c->free_events.back();
+      c->free_events.pop_back();
+    } else {
+      if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) {
+        return;
+      }
+    }
+    ep.kind = kind;
+    on = true;
+    (void)hipEventRecord(ep.a, c->stream);
+  }
+  ~Timer()
+  {
+    if (on) {
+      (void)hipEventRecord(ep.b, c->stream);
+      c->pending.push_back(ep);
+    }
+  }
+};
+
+void
+drain_events(grp_ctx* c)
+{
+  for (auto& ep : c->pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+      c->kstat[ep.kind].ms += (double)ms;
+    }
+    c->free_events.push_back(ep);
+  }
+  c->pending.clear();
+}
+
+uint32_t
+next_pow2(uint64_t v)
+{
+  uint32_t p = 1;
+  while (p < v) {
+    p <<= 1;
+  }
+  return p;
+}
+
+size_t
+tab_bytes(const grp_ctx* c)
+{
+  return (size_t)c->h_seeds.h * c->h_seeds.wmax * 4u * sizeof(ulonglong2);
+}
+
+size_t
+bases_bytes(uint32_t nbases)
+{
+  // words covering nbases at any 16-base phase + 2 pad words, rounded to 16 B
+  size_t words = (nbases + 15u) / 16u + 1u + 2u;
+  return ((words * 4u + 15u) / 16u) * 16u;
+}
+
+template<typename K>
+int
+ensure_lds(grp_ctx* c, K kernel, size_t bytes)
+{
+  if (bytes > 64 * 1024) {
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  }
+  return GRP_OK;
+}
+
+#define DISPATCH_H(hval, CALL)                                                                                         \
+  switch (hval) {                                                                                                      \
+    case 1: { constexpr int HH = 1; CALL; } break;                                                                     \
+    case 2: { constexpr int HH = 2; CALL; } break;                                                                     \
+    case 3: { constexpr int HH = 3; CALL; } break;                                                                     \
+    case 4: { constexpr int HH = 4; CALL; } break;                                                                     \
+    case 5: { constexpr int HH = 5; CALL; } break;                                                                     \
+    case 6: { constexpr int HH = 6; CALL; } break;                                                                     \
+    case 7: { constexpr int HH = 7; CALL; } break;                                                                     \
+    default: { constexpr int HH = 8; CALL; } break;                                                                    \
+  }
+
+template<int HH>
+int
+launch_query(grp_ctx* c, const grp_reads* r, uint64_t nt, uint64_t t0, uint64_t list_cap, size_t lds)
+{
+  auto kern = k_query<HH, 2>;
+  int rc = ensure_lds(c, kern, lds);
+  if (rc != GRP_OK) {
+    return rc;
+  }
+  kern<<<dim3((uint32_t)nt), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, c->hist_cap, c->list_cap_lds, c->d_tiles, c->d_lists, list_cap, reinterpret_cast<unsigned long long*>(c->d_qctr));
+  return GRP_OK;
+}
+
+int
+build_seed_tables(grp_ctx* c)
+{
+  DevSeeds& sd = c->h_seeds;
+  memset(&sd, 0, sizeof(sd));
+  sd.h = c->params.h;
+  sd.k = c->params.k;
+  sd.wmax = 0;
+  for (uint32_t s = 0; s < sd.h; ++s) {
+    const std::string& p = c->seeds[s];
+    if (p.size() != (size_t)c->params.k + s) {
+      return set_err(c, GRP_ERR_INVALID, "seed %u has span %zu, expected k+%u = %u", s, p.size(), s, c->params.k + s);
+    }
+    sd.span[s] = (uint32_t)p.size();
+    uint32_t w = 0;
+    for (uint32_t q = 0; q < p.size(); ++q) {
+      if (p[q] == '1') {
+        if (w >= GRP_DEV_MAX_W) {
+          return set_err(c, GRP_ERR_INVALID, "seed weight > %d unsupported", GRP_DEV_MAX_W);
+        }
+        sd.shift[s][w] = 2u * q;
+        for (uint32_t b = 0; b < 4; ++b) {
+          sd.tab[s][w][b].x = srol_n(BASE_SEED[b], sd.span[s] - 1u - q);
+          sd.tab[s][w][b].y = srol_n(BASE_SEED[3u - b], q);
+        }
+        ++w;
+      } else if (p[q] != '0') {
+        return set_err(c, GRP_ERR_INVALID, "seed %u contains '%c'", s, p[q]);
+      }
+    }
+    sd.weight[s] = w;
+    sd.wmax = std::max(sd.wmax, w);
+  }
+  if (sd.wmax == 0) {
+    return set_err(c, GRP_ERR_INVALID, "seeds have weight 0");
+  }
+  return GRP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char*
+grp_last_error(const grp_ctx* ctx)
+{
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int
+grp_create(const grp_params* p, grp_ctx** out)
+{
+  if (!p || !out || p->struct_size != sizeof(grp_params)) {
+    return set_err(nullptr, GRP_ERR_INVALID, "grp_create: bad params / struct_size");
+  }
+  *out = nullptr;
+  if (p->h < 1 || p->h > GRP_MAX_SEEDS) {
+    return set_err(nullptr, GRP_ERR_INVALID, "h=%u outside [1,%d]", p->h, GRP_MAX_SEEDS);
+  }
+  if (p->k < 1 || p->k + p->h - 1 > GRP_MAX_SPAN) {
+    return set_err(nullptr, GRP_ERR_INVALID, "k+h-1=%u exceeds the %d-base window of this implementation", p->k + p->h - 1, GRP_MAX_SPAN);
+  }
+  if (p->tile < p->k + p->h - 1) {
+    return set_err(nullptr, GRP_ERR_INVALID, "tile length %u shorter than the longest seed span %u", p->tile, p->k + p->h - 1);
+  }
+  if (p->m < 64 || p->m >= (1ULL << 40) * GRP_BLOCK_BITS) {
+    return set_err(nullptr, GRP_ERR_INVALID, "filter size m=%llu unsupported", (unsigned long long)p->m);
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    return set_err(nullptr, GRP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+  }
+  grp_ctx* c = new grp_ctx();
+  c->params = *p;
+  for (uint32_t s = 0; s < p->h; ++s) {
+    c->seeds.emplace_back(p->seeds[s] ? p->seeds[s] : "");
+  }
+  c->params.seeds = nullptr;
+  auto fail = [&](int code) {
+    g_create_error = c->err;
+    grp_destroy(c);
+    return code;
+  };
+  if (p->device >= 0) {
+    if (hipSetDevice(p->device) != hipSuccess) {
+      set_err(c, GRP_ERR_NO_DEVICE, "hipSetDevice(%d) failed", p->device);
+      return fail(GRP_ERR_NO_DEVICE);
+    }
+    c->device = p->device;
+  } else if (hipGetDevice(&c->device) != hipSuccess) {
+    set_err(c, GRP_ERR_NO_DEVICE, "hipGetDevice failed");
+    return fail(GRP_ERR_NO_DEVICE);
+  }
+  int rc = build_seed_tables(c);
+  if (rc != GRP_OK) {
+    return fail(rc);
+  }
+  // LDS geometry of the query kernel: count table sized so that even
+  // tile*h distinct IDs fit at load <= 0.75; list bound = floor(tile*h/3)
+  uint64_t max_ids = (uint64_t)p->tile * p->h;
+  c->hist_cap = next_pow2((max_ids * 4 + 2) / 3);
+  c->list_cap_lds = (uint32_t)(max_ids / 3 + 1);
+  size_t lds = tab_bytes(c) + (size_t)c->hist_cap * 8 + (size_t)c->list_cap_lds * 8 + bases_bytes(p->tile + p->k + p->h);
+  if (lds > 160 * 1024 - 256) {
+    set_err(c, GRP_ERR_INVALID, "tile*h=%llu needs %zu B of LDS per workgroup (limit 160 KiB)", (unsigned long long)max_ids, lds);
+    return fail(GRP_ERR_INVALID);
+  }
+#define CREATE_TRY(expr)                                                                                               \
+  do {                                                                                                                 \
+    hipError_t e_ = (expr);                                                                                            \
+    if (e_ != hipSuccess) {                                                                                            \
+      set_err(c, GRP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                                          \
+      return fail(e_ == hipErrorOutOfMemory ? GRP_ERR_NOMEM : GRP_ERR_HIP);                                            \
+    }                                                                                                                  \
+  } while (0)
+  CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipMalloc(&c->d_seeds, sizeof(DevSeeds)));
+  CREATE_TRY(hipMemcpyAsync(c->d_seeds, &c->h_seeds, sizeof(DevSeeds), hipMemcpyHostToDevice, c->stream));
+  c->f.m = p->m;
+  c->f.m_inv = ~0ULL / p->m;
+  c->f.nblk = (p->m + GRP_BLOCK_BITS - 1) / GRP_BLOCK_BITS;
+  c->n_chunks = (c->f.nblk + GRP_CHUNK_BLOCKS - 1) / GRP_CHUNK_BLOCKS;
+  c->nsb = ((c->f.nblk - 1) >> GRP_SUPER_SHIFT) + 1;
+  CREATE_TRY(hipMalloc(&c->f.blocks, c->f.nblk * sizeof(uint4)));
+  CREATE_TRY(hipMemsetAsync(c->f.blocks, 0, c->f.nblk * sizeof(uint4), c->stream));
+  CREATE_TRY(hipMalloc(&c->d_super, c->nsb * sizeof(uint64_t)));
+  CREATE_TRY(hipMemsetAsync(c->d_super, 0, c->nsb * sizeof(uint64_t), c->stream));
+  c->f.super = c->d_super;
+  CREATE_TRY(hipMalloc(&c->d_qctr, 8 * sizeof(uint64_t)));
+  CREATE_TRY(hipHostMalloc(&c->h_qctr, 8 * sizeof(uint64_t), hipHostMallocDefault));
+  CREATE_TRY(hipStreamSynchronize(c->stream));
+#undef CREATE_TRY
+  *out = c;
+  return GRP_OK;
+}
+
+void
+grp_destroy(grp_ctx* c)
+{
+  if (!c) {
+    return;
+  }
+  if (c->stream) {
+    (void)hipStreamSynchronize(c->stream);
+  }
+  drain_events(c);
+  for (auto& ep : c->free_events) {
+    (void)hipEventDestroy(ep.a);
+    (void)hipEventDestroy(ep.b);
+  }
+  (void)hipFree(c->d_seeds);
+  (void)hipFree(c->f.blocks);
+  (void)hipFree(c->d_super);
+  (void)hipFree(c->f.idc);
+  (void)hipFree(c->d_tiles);
+  (void)hipFree(c->d_lists);
+  (void)hipFree(c->d_qctr);
+  if (c->h_qctr) {
+    (void)hipHostFree(c->h_qctr);
+  }
+  (void)hipFree(c->d_dedup);
+  if (c->stream) {
+    (void)hipStreamDestroy(c->stream);
+  }
+  delete c;
+}
+
+// ---- reads -------------------------------------------------------------------------
+
+static int
+reads_build(grp_ctx* c, grp_reads* r, const uint64_t* word_off, const uint32_t* len, uint32_t n)
+{
+  const uint32_t tile = c->params.tile;
+  const uint32_t k = c->params.k;
+  const uint32_t min_len = c->params.k + c->params.h - 1;
+  r->ctx = c;
+  r->n_reads = n;
+  r->n_words = word_off[n];
+  r->len.assign(len, len + n);
+  r->tile0.resize((size_t)n + 1);
+  r->chunk0.resize((size_t)n + 1);
+  uint64_t t = 0, ch = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    r->tile0[i] = t;
+    r->chunk0[i] = ch;
+    t += len[i] / tile;
+    // reads shorter than the longest span are outside the reference's defined
+    // behaviour (SeedNtHash on a too-short string); they contribute nothing
+    if (len[i] >= min_len) {
+      uint64_t npos = (uint64_t)len[i] - k + 1;
+      ch += (npos + FILL_CHUNK - 1) / FILL_CHUNK;
+    }
+    if ((uint64_t)(len[i] + 15u) / 16u > word_off[i + 1] - word_off[i]) {
+      return set_err(c, GRP_ERR_INVALID, "read %u: %u bases do not fit its %llu words", i, len[i], (unsigned long long)(word_off[i + 1] - word_off[i]));
+    }
+  }
+  r->tile0[n] = t;
+  r->chunk0[n] = ch;
+  std::vector<uint32_t> tile_read(t), chunk_read(ch);
+  for (uint32_t i = 0; i < n; ++i) {
+    for (uint64_t j = r->tile0[i]; j < r->tile0[i + 1]; ++j) {
+      tile_read[j] = i;
+    }
+    for (uint64_t j = r->chunk0[i]; j < r->chunk0[i + 1]; ++j) {
+      chunk_read[j] = i;
+    }
+  }
+  HIP_TRY(c, hipMalloc(&r->d_word_off, ((size_t)n + 1) * 8));
+  HIP_TRY(c, hipMalloc(&r->d_len, std::max<size_t>(n, 1) * 4));
+  HIP_TRY(c, hipMalloc(&r->d_tile0, ((size_t)n + 1) * 8));
+  HIP_TRY(c, hipMalloc(&r->d_chunk0, ((size_t)n + 1) * 8));
+  HIP_TRY(c, hipMalloc(&r->d_tile_read, std::max<size_t>(t, 1) * 4));
+  HIP_TRY(c, hipMalloc(&r->d_chunk_read, std::max<size_t>(ch, 1) * 4));
+  HIP_TRY(c, hipMemcpy(r->d_word_off, word_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(r->d_len, len, (size_t)n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(r->d_tile0, r->tile0.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(r->d_chunk0, r->chunk0.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(r->d_tile_read, tile_read.data(), t * 4, hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(r->d_chunk_read, chunk_read.data(), ch * 4, hipMemcpyHostToDevice));
+  r->dev.packed = r->d_packed;
+  r->dev.word_off = r->d_word_off;
+  r->dev.len = r->d_len;
+  r->dev.tile0 = r->d_tile0;
+  r->dev.tile_read = r->d_tile_read;
+  r->dev.chunk0 = r->d_chunk0;
+  r->dev.chunk_read = r->d_chunk_read;
+  return GRP_OK;
+}
+
+int
+grp_reads_upload(grp_ctx* c, const uint32_t* packed, const uint64_t* word_off, const uint32_t* len, uint32_t n, grp_reads** out)
+{
+  if (!c || !out || !word_off || (!len && n) || (!packed && n && word_off[n])) {
+    return set_err(c, GRP_ERR_INVALID, "grp_reads_upload: null argument");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  grp_reads* r = new grp_reads();
+  r->owns_packed = true;
+  hipError_t e = hipMalloc(&r->d_packed, std::max<uint64_t>(word_off[n], 1) * 4 + 16);
+  if (e != hipSuccess) {
+    delete r;
+    return set_err(c, GRP_ERR_NOMEM, "hipMalloc(%llu words) failed: %s", (unsigned long long)word_off[n], hipGetErrorString(e));
+  }
+  e = hipMemcpy(r->d_packed, packed, word_off[n] * 4, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    grp_reads_free(r);
+    return set_err(c, GRP_ERR_HIP, "hipMemcpy(packed) failed: %s", hipGetErrorString(e));
+  }
+  int rc = reads_build(c, r, word_off, len, n);
+  if (rc != GRP_OK) {
+    grp_reads_free(r);
+    return rc;
+  }
+  *out = r;
+  return GRP_OK;
+}
+
+int
+grp_reads_wrap_device(grp_ctx* c, const void* d_packed, const uint64_t* word_off, const uint32_t* len, uint32_t n, grp_reads** out)
+{
+  if (!c || !out || !word_off || (!len && n) || !d_packed) {
+    return set_err(c, GRP_ERR_INVALID, "grp_reads_wrap_device: null argument");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  grp_reads* r = new grp_reads();
+  r->owns_packed = false;
+  r->d_packed = const_cast<uint32_t*>(static_cast<const uint32_t*>(d_packed));
+  int rc = reads_build(c, r, word_off, len, n);
+  if (rc != GRP_OK) {
+    grp_reads_free(r);
+    return rc;
+  }
+  *out = r;
+  return GRP_OK;
+}
+
+void
+grp_reads_free(grp_reads* r)
+{
+  if (!r) {
+    return;
+  }
+  if (r->ctx && r->ctx->stream) {
+    (void)hipStreamSynchronize(r->ctx->stream);
+  }
+  if (r->owns_packed) {
+    (void)hipFree(r->d_packed);
+  }
+  (void)hipFree(r->d_word_off);
+  (void)hipFree(r->d_len);
+  (void)hipFree(r->d_tile0);
+  (void)hipFree(r->d_tile_read);
+  (void)hipFree(r->d_chunk0);
+  (void)hipFree(r->d_chunk_read);
+  delete r;
+}
+
+const uint64_t*
+grp_reads_tile0(const grp_reads* r)
+{
+  return r ? r->tile0.data() : nullptr;
+}
+
+// ---- fill ---------------------------------------------------------------------------
+
+int
+grp_bv_insert(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count)
+{
+  if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads) {
+    return set_err(c, GRP_ERR_INVALID, "grp_bv_insert: bad range");
+  }
+  if (c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_bv_insert after grp_finalize: the bit vector is immutable");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t ch0 = r->chunk0[first], ch1 = r->chunk0[first + count];
+  if (ch1 == ch0) {
+    return GRP_OK;
+  }
+  const size_t lds = tab_bytes(c) + bases_bytes(FILL_CHUNK + c->params.k + c->params.h);
+  uint64_t probes = 0;
+  for (uint32_t i = first; i < first + count; ++i) {
+    for (uint32_t s = 0; s < c->params.h; ++s) {
+      uint32_t span = c->params.k + s;
+      if (r->len[i] >= c->params.k + c->params.h - 1) {
+        probes += r->len[i] - span + 1;
+      }
+    }
+  }
+  // launch in slices of at most 2^30 workgroups
+  for (uint64_t b = ch0; b < ch1;) {
+    uint32_t nb = (uint32_t)std::min<uint64_t>(ch1 - b, 1u << 30);
+    Timer t(c, GRP_K_FILL, b == ch0 ? probes : 0);
+    DISPATCH_H(c->params.h, (k_fill<HH><<<dim3(nb), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, b)));
+    HIP_TRY(c, hipGetLastError());
+    b += nb;
+  }
+  return GRP_OK;
+}
+
+int
+grp_finalize(grp_ctx* c, uint64_t* pop)
+{
+  if (!c) {
+    return GRP_ERR_INVALID;
+  }
+  if (c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_finalize called twice");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t* d_chunk_sum = nullptr;
+  uint64_t* d_chunk_base = nullptr;
+  uint64_t* d_pop = nullptr;
+  HIP_TRY(c, hipMalloc(&d_chunk_sum, c->n_chunks * 4));
+  HIP_TRY(c, hipMalloc(&d_chunk_base, c->n_chunks * 8));
+  HIP_TRY(c, hipMalloc(&d_pop, 8));
+  {
+    Timer t(c, GRP_K_RANK, c->f.nblk);
+    hipLaunchKernelGGL(k_rank_chunk_sums, dim3((uint32_t)c->n_chunks), dim3(THREADS), 0, c->stream, c->f.blocks, c->f.nblk, d_chunk_sum);
+    hipLaunchKernelGGL(k_rank_scan_chunks, dim3(1), dim3(1024), 0, c->stream, d_chunk_sum, c->n_chunks, d_chunk_base, c->d_super, d_pop);
+    hipLaunchKernelGGL(k_rank_write, dim3((uint32_t)c->n_chunks), dim3(THREADS), 0, c->stream, c->f.blocks, c->f.nblk, d_chunk_base, c->d_super);
+  }
+  HIP_TRY(c, hipGetLastError());
+  uint64_t h_pop = 0;
+  HIP_TRY(c, hipMemcpyAsync(&h_pop, d_pop, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_chunk_sum);
+  (void)hipFree(d_chunk_base);
+  (void)hipFree(d_pop);
+  c->f.pop = h_pop;
+  hipError_t e = hipMalloc(&c->f.idc, std::max<uint64_t>(h_pop, 1) * sizeof(uint2));
+  if (e != hipSuccess) {
+    return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu ID/count pairs failed: %s", (unsigned long long)h_pop, hipGetErrorString(e));
+  }
+  HIP_TRY(c, hipMemsetAsync(c->f.idc, 0, std::max<uint64_t>(h_pop, 1) * sizeof(uint2), c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->finalized = true;
+  if (pop) {
+    *pop = h_pop;
+  }
+  return GRP_OK;
+}
+
+// ---- query --------------------------------------------------------------------------
+
+int
+grp_query_tiles(grp_ctx* c,
+                const grp_reads* r,
+                uint32_t first,
+                uint32_t count,
+                grp_tile_summary* tiles_out,
+                grp_id_count* lists_out,
+                uint64_t list_cap,
+                uint64_t* list_used,
+                grp_query_stats* stats)
+{
+  if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads) {
+    return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: bad range");
+  }
+  if (!c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_query_tiles before grp_finalize");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t t0 = r->tile0[first], t1 = r->tile0[first + count];
+  const uint64_t nt = t1 - t0;
+  if (list_used) {
+    *list_used = 0;
+  }
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+  }
+  if (nt == 0) {
+    return GRP_OK;
+  }
+  if (nt > (1u << 30)) {
+    return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: %llu tiles in one call (limit 2^30)", (unsigned long long)nt);
+  }
+  if (!tiles_out) {
+    return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: tiles_out is NULL");
+  }
+  if (nt > c->d_tiles_cap) {
+    (void)hipFree(c->d_tiles);
+    c->d_tiles = nullptr;
+    c->d_tiles_cap = 0;
+    HIP_TRY(c, hipMalloc(&c->d_tiles, nt * sizeof(grp_tile_summary)));
+    c->d_tiles_cap = nt;
+  }
+  const uint64_t want_lists = std::max<uint64_t>(list_cap, 1);
+  if (want_lists > c->d_lists_cap) {
+    (void)hipFree(c->d_lists);
+    c->d_lists = nullptr;
+    c->d_lists_cap = 0;
+    HIP_TRY(c, hipMalloc(&c->d_lists, want_lists * sizeof(grp_id_count)));
+    c->d_lists_cap = want_lists;
+  }
+  HIP_TRY(c, hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
+  const size_t lds = tab_bytes(c) + (size_t)c->hist_cap * 8 + (size_t)c->list_cap_lds * 8 + bases_bytes(c->params.tile + c->params.k + c->params.h);
+  uint64_t probes = 0;
+  {
+    const uint32_t tile = c->params.tile, k = c->params.k;
+    for (uint32_t i = first; i < first + count; ++i) {
+      uint32_t ntile = r->len[i] / tile;
+      if (ntile == 0) {
+        continue;
+      }
+      // all tiles but the last have `tile` frames; the last may be clipped
+      uint32_t start = (ntile - 1) * tile;
+      uint32_t Lp = std::min(tile + k - 1, r->len[i] - start);
+      probes += ((uint64_t)(ntile - 1) * tile + (Lp - k + 1)) * c->params.h;
+    }
+  }
+  {
+    Timer t(c, GRP_K_QUERY, probes);
+    int lrc = GRP_OK;
+    DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, nt, t0, list_cap, lds));
+    if (lrc != GRP_OK) {
+      return lrc;
+    }
+  }
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(c->h_qctr, c->d_qctr, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(tiles_out, c->d_tiles, nt * sizeof(grp_tile_summary), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const uint64_t used = c->h_qctr[3];
+  if (list_used) {
+    *list_used = used;
+  }
+  if (stats) {
+    stats->queries = c->h_qctr[0];
+    stats->hits = c->h_qctr[1];
+    stats->misses = c->h_qctr[2];
+  }
+  if (used > list_cap) {
+    return set_err(c, GRP_ERR_NOMEM, "grp_query_tiles: %llu list entries needed, capacity %llu", (unsigned long long)used, (unsigned long long)list_cap);
+  }
+  if (used) {
+    if (!lists_out) {
+      return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: lists_out is NULL");
+    }
+    HIP_TRY(c, hipMemcpy(lists_out, c->d_lists, used * sizeof(grp_id_count), hipMemcpyDeviceToHost));
+    // canonical order inside each tile's list: count descending, id ascending
+    for (uint64_t i = 0; i < nt; ++i) {
+      grp_tile_summary& ts = tiles_out[i];
+      if (ts.list_n > 1) {
+        std::sort(lists_out + ts.list_off, lists_out + ts.list_off + ts.list_n, [](const grp_id_count& a, const grp_id_count& b) {
+          return a.count != b.count ? a.count > b.count : a.id < b.id;
+        });
+      }
+    }
+  }
+  return GRP_OK;
+}
+
+// ---- insert -------------------------------------------------------------------------
+
+int
+grp_insert_tiles(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t id)
+{
+  if (!c || !r || r->ctx != c || read_idx >= r->n_reads) {
+    return set_err(c, GRP_ERR_INVALID, "grp_insert_tiles: bad read index");
+  }
+  if (!c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_insert_tiles before grp_finalize");
+  }
+  const uint64_t ntile = r->tile0[read_idx + 1] - r->tile0[read_idx];
+  if (tile_start > tile_end || tile_end > ntile) {
+    return set_err(c, GRP_ERR_INVALID, "grp_insert_tiles: tiles [%u,%u) outside the read's %llu tiles", tile_start, tile_end, (unsigned long long)ntile);
+  }
+  if (tile_start == tile_end) {
+    return GRP_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t nt = tile_end - tile_start;
+  const uint64_t max_ranks = (uint64_t)nt * c->params.tile * c->params.h;
+  const uint64_t want = next_pow2(max_ranks * 2);
+  if (want > c->dedup_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_dedup);
+    c->d_dedup = nullptr;
+    c->dedup_cap = 0;
+    HIP_TRY(c, hipMalloc(&c->d_dedup, want * 8));
+    HIP_TRY(c, hipMemsetAsync(c->d_dedup, 0, want * 8, c->stream));
+    c->dedup_cap = want;
+    c->epoch = 0;
+  }
+  c->epoch += 1;
+  if (c->epoch >= (1u << 24)) {
+    HIP_TRY(c, hipMemsetAsync(c->d_dedup, 0, c->dedup_cap * 8, c->stream));
+    c->epoch = 1;
+  }
+  const unsigned long long epoch_tag = (unsigned long long)c->epoch << 40;
+  const size_t lds = tab_bytes(c) + bases_bytes(c->params.tile + c->params.k + c->params.h);
+  {
+    Timer t(c, GRP_K_INSERT, max_ranks);
+    DISPATCH_H(c->params.h, (k_insert<HH><<<dim3(nt), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, read_idx, tile_start, id, c->d_dedup, c->dedup_cap - 1, epoch_tag)));
+  }
+  HIP_TRY(c, hipGetLastError());
+  return GRP_OK;
+}
+
+int
+grp_reset_ids(grp_ctx* c)
+{
+  if (!c || !c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_reset_ids before grp_finalize");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemsetAsync(c->f.idc, 0, std::max<uint64_t>(c->f.pop, 1) * sizeof(uint2), c->stream));
+  return GRP_OK;
+}
+
+int
+grp_sync(grp_ctx* c)
+{
+  if (!c) {
+    return GRP_ERR_INVALID;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return GRP_OK;
+}
+
+// ---- inspection -------------------------------------------------------------------
+
+uint64_t
+grp_filter_bits(const grp_ctx* c)
+{
+  return c ? c->f.m : 0;
+}
+
+uint64_t
+grp_pop(const grp_ctx* c)
+{
+  return c ? c->f.pop : 0;
+}
+
+int
+grp_export_bits(grp_ctx* c, uint64_t* words, uint64_t n_words)
+{
+  if (!c || !words || n_words != (c->f.m + 63) / 64) {
+    return set_err(c, GRP_ERR_INVALID, "grp_export_bits: n_words must be ceil(m/64)");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  unsigned long long* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, n_words * 8));
+  hipLaunchKernelGGL(k_export_bits, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, c->stream, c->f.blocks, c->f.m, n_words, d);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(words, d, n_words * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  return GRP_OK;
+}
+
+int
+grp_rank(grp_ctx* c, const uint64_t* pos, uint64_t n, uint8_t* bit, uint64_t* rank)
+{
+  if (!c || !c->finalized || !pos || !bit || !rank) {
+    return set_err(c, GRP_ERR_STATE, "grp_rank: needs a finalized filter and non-null arrays");
+  }
+  for (uint64_t i = 0; i < n; ++i) {
+    if (pos[i] >= c->f.m) {
+      return set_err(c, GRP_ERR_INVALID, "grp_rank: position %llu >= m", (unsigned long long)pos[i]);
+    }
+  }
+  if (n == 0) {
+    return GRP_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint64_t *d_pos = nullptr, *d_rank = nullptr;
+  uint8_t* d_bit = nullptr;
+  HIP_TRY(c, hipMalloc(&d_pos, n * 8));
+  HIP_TRY(c, hipMalloc(&d_rank, n * 8));
+  HIP_TRY(c, hipMalloc(&d_bit, n));
+  HIP_TRY(c, hipMemcpyAsync(d_pos, pos, n * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_rank_positions, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->f, d_pos, n, d_bit, d_rank);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(bit, d_bit, n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(rank, d_rank, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_pos);
+  (void)hipFree(d_rank);
+  (void)hipFree(d_bit);
+  return GRP_OK;
+}
+
+int
+grp_export_ids(grp_ctx* c, uint64_t first, uint64_t n, uint32_t* ids, uint32_t* counts)
+{
+  if (!c || !c->finalized || first + n > c->f.pop || !ids || !counts) {
+    return set_err(c, GRP_ERR_INVALID, "grp_export_ids: bad range");
+  }
+  if (n == 0) {
+    return GRP_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t *d_ids = nullptr, *d_cnt = nullptr;
+  HIP_TRY(c, hipMalloc(&d_ids, n * 4));
+  HIP_TRY(c, hipMalloc(&d_cnt, n * 4));
+  hipLaunchKernelGGL(k_split_idc, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->f.idc, first, n, d_ids, d_cnt);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(counts, d_cnt, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_ids);
+  (void)hipFree(d_cnt);
+  return GRP_OK;
+}
+
+int
+grp_import_ids(grp_ctx* c, uint64_t first, uint64_t n, const uint32_t* ids, const uint32_t* counts)
+{
+  if (!c || !c->finalized || first + n > c->f.pop) {
+    return set_err(c, GRP_ERR_INVALID, "grp_import_ids: bad range");
+  }
+  if (n == 0 || (!ids && !counts)) {
+    return GRP_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint32_t *d_ids = nullptr, *d_cnt = nullptr;
+  if (ids) {
+    HIP_TRY(c, hipMalloc(&d_ids, n * 4));
+    HIP_TRY(c, hipMemcpyAsync(d_ids, ids, n * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  if (counts) {
+    HIP_TRY(c, hipMalloc(&d_cnt, n * 4));
+    HIP_TRY(c, hipMemcpyAsync(d_cnt, counts, n * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  hipLaunchKernelGGL(k_merge_idc, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->f.idc, first, n, d_ids, d_cnt);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_ids);
+  (void)hipFree(d_cnt);
+  return GRP_OK;
+}
+
+int
+grp_debug_tile_hashes(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t tile_idx, uint64_t* out, uint64_t cap, uint64_t* n_values)
+{
+  if (!c || !r || r->ctx != c || read_idx >= r->n_reads || !out || !n_values) {
+    return set_err(c, GRP_ERR_INVALID, "grp_debug_tile_hashes: bad argument");
+  }
+  const uint32_t tile = c->params.tile, k = c->params.k;
+  if (tile_idx >= r->len[read_idx] / tile) {
+    return set_err(c, GRP_ERR_INVALID, "grp_debug_tile_hashes: tile index out of range");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t start = tile_idx * tile;
+  const uint32_t Lp = std::min(tile + k - 1, r->len[read_idx] - start);
+  const uint64_t nv = (uint64_t)(Lp - k + 1) * c->params.h;
+  *n_values = nv;
+  if (nv > cap) {
+    return set_err(c, GRP_ERR_NOMEM, "grp_debug_tile_hashes: %llu values, capacity %llu", (unsigned long long)nv, (unsigned long long)cap);
+  }
+  uint64_t* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, nv * 8));
+  const size_t lds = tab_bytes(c) + bases_bytes(tile + k + c->params.h);
+  DISPATCH_H(c->params.h, (k_debug_tile_hashes<HH><<<dim3(1), dim3(THREADS), lds, c->stream>>>(r->dev, c->d_seeds, tile, read_idx, tile_idx, d, nv)));
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(out, d, nv * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d);
+  return GRP_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------
+
+int
+grp_set_timing(grp_ctx* c, int enabled)
+{
+  if (!c) {
+    return GRP_ERR_INVALID;
+  }
+  c->timing = enabled != 0;
+  return GRP_OK;
+}
+
+int
+grp_get_kernel_stats(grp_ctx* c, grp_kernel_stat out[GRP_K_COUNT])
+{
+  if (!c || !out) {
+    return GRP_ERR_INVALID;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  memcpy(out, c->kstat, sizeof(c->kstat));
+  return GRP_OK;
+}
+
+int
+grp_reset_kernel_stats(grp_ctx* c)
+{
+  if (!c) {
+    return GRP_ERR_INVALID;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  memset(c->kstat, 0, sizeof(c->kstat));
+  return GRP_OK;
+}
+
+void*
+grp_stream(grp_ctx* c)
+{
+  return c ? (void*)c->stream : nullptr;
+}
+
+} // extern "C"

@@ -1,0 +1,313 @@
+"""ctypes binding of the C ABI in include/grpath.h (libgrpath_hip.so).
+
+The binding is plumbing only: every compute call goes to the hand-written HIP
+kernels.  There is no Python / CPU fallback — if the library is missing or no
+HIP device is usable the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(LIB_DIR, "libgrpath_hip.so")
+
+GRP_OK = 0
+GRP_ERR_INVALID, GRP_ERR_NO_DEVICE, GRP_ERR_HIP, GRP_ERR_STATE, GRP_ERR_NOMEM = -1, -2, -3, -4, -5
+GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_COUNT = 0, 1, 2, 3, 4
+KERNEL_NAMES = ("fill", "rank", "query", "insert")
+
+
+class GrpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"grpath error {code}: {msg}")
+        self.code = code
+
+
+class grp_params(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("k", C.c_uint32),
+        ("h", C.c_uint32),
+        ("tile", C.c_uint32),
+        ("m", C.c_uint64),
+        ("seeds", C.POINTER(C.c_char_p)),
+        ("device", C.c_int32),
+        ("flags", C.c_uint32),
+    ]
+
+
+tile_summary_dtype = np.dtype([("top_id", "<u4"), ("top_count", "<u4"), ("list_off", "<u4"), ("list_n", "<u4")])
+id_count_dtype = np.dtype([("id", "<u4"), ("count", "<u4")])
+
+
+class grp_query_stats(C.Structure):
+    _fields_ = [("queries", C.c_uint64), ("hits", C.c_uint64), ("misses", C.c_uint64)]
+
+
+class grp_kernel_stat(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("units", C.c_uint64), ("ms", C.c_double)]
+
+
+# name -> (restype, argtypes); every symbol include/grpath.h declares
+_vp = C.c_void_p
+SIGNATURES = {
+    "grp_create": (C.c_int, [C.POINTER(grp_params), C.POINTER(_vp)]),
+    "grp_destroy": (None, [_vp]),
+    "grp_last_error": (C.c_char_p, [_vp]),
+    "grp_reads_upload": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(_vp)]),
+    "grp_reads_wrap_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(_vp)]),
+    "grp_reads_free": (None, [_vp]),
+    "grp_reads_tile0": (C.POINTER(C.c_uint64), [_vp]),
+    "grp_bv_insert": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32]),
+    "grp_finalize": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "grp_query_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(grp_query_stats)]),
+    "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "grp_reset_ids": (C.c_int, [_vp]),
+    "grp_sync": (C.c_int, [_vp]),
+    "grp_filter_bits": (C.c_uint64, [_vp]),
+    "grp_pop": (C.c_uint64, [_vp]),
+    "grp_export_bits": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "grp_rank": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "grp_export_ids": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp]),
+    "grp_import_ids": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp]),
+    "grp_debug_tile_hashes": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "grp_set_timing": (C.c_int, [_vp, C.c_int]),
+    "grp_get_kernel_stats": (C.c_int, [_vp, C.POINTER(grp_kernel_stat)]),
+    "grp_reset_kernel_stats": (C.c_int, [_vp]),
+    "grp_stream": (_vp, [_vp]),
+}
+
+_lib = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the gfx950 library in-tree (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(["make", "-C", CSRC_DIR], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libgrpath_hip.so failed:\n" + res.stdout + res.stderr)
+    if verbose:
+        sys.stderr.write(res.stdout)
+    return LIB_PATH
+
+
+def load():
+    """dlopen libgrpath_hip.so and type every exported symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GrpError(GRP_ERR_NO_DEVICE, f"{LIB_PATH} is missing: run goldrush_amd.native.build() (no CPU fallback exists)")
+    # torch bundles its own libamdhip64.so.7; load it first when torch is around
+    # so that one HIP runtime serves both (torch is used for torch.distributed only)
+    if "torch" in sys.modules or os.environ.get("GRP_PRELOAD_TORCH", "1") == "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch absent: plain ROCm runtime
+            pass
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------------------
+# 2-bit packing (host side; the CLI has its own C++ packer)
+# ---------------------------------------------------------------------------
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _i, _ch in enumerate(b"ACGT"):
+    _CODE[_ch] = _i
+    _CODE[_ch + 32] = _i  # lower case
+
+
+def pack_reads(seqs):
+    """seqs: list of bytes (pure ACGT). Returns (packed u32, word_off u64[n+1], len u32[n])."""
+    n = len(seqs)
+    lens = np.array([len(s) for s in seqs], dtype=np.uint32)
+    words = (lens.astype(np.uint64) + 15) // 16
+    word_off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(words, out=word_off[1:])
+    packed = np.zeros(int(word_off[-1]) + 1, dtype=np.uint32)
+    for i, s in enumerate(seqs):
+        codes = _CODE[np.frombuffer(s, dtype=np.uint8)]
+        if codes.size and codes.max() > 3:
+            raise ValueError(f"read {i} contains a non-ACGT base")
+        nw = int(words[i])
+        buf = np.zeros(nw * 16, dtype=np.uint32)
+        buf[: codes.size] = codes
+        buf = buf.reshape(nw, 16)
+        shifts = (np.arange(16, dtype=np.uint32) * 2)[None, :]
+        packed[int(word_off[i]): int(word_off[i]) + nw] = np.bitwise_or.reduce(buf << shifts, axis=1)
+    return packed[:-1].copy() if packed.size > 1 else packed[:0].copy(), word_off, lens
+
+
+class ReadBatch:
+    """A batch of packed reads resident in HBM (grp_reads)."""
+
+    def __init__(self, engine: "Engine", handle, n_reads: int, lens: np.ndarray, keep=None):
+        self.engine = engine
+        self._h = handle
+        self.n_reads = n_reads
+        self.lens = lens
+        self._keep = keep
+        p = engine.lib.grp_reads_tile0(handle)
+        self.tile0 = np.ctypeslib.as_array(p, shape=(n_reads + 1,)).copy()
+
+    def free(self):
+        if self._h:
+            self.engine.lib.grp_reads_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One miBF on one MI355X (grp_ctx)."""
+
+    def __init__(self, k: int, h: int, tile: int, m: int, seeds, device: int = -1):
+        self.lib = load()
+        self.k, self.h, self.tile, self.m = k, h, tile, m
+        arr = (C.c_char_p * h)(*[s.encode() if isinstance(s, str) else s for s in seeds])
+        p = grp_params(C.sizeof(grp_params), k, h, tile, m, arr, device, 0)
+        out = C.c_void_p()
+        rc = self.lib.grp_create(C.byref(p), C.byref(out))
+        if rc != GRP_OK:
+            raise GrpError(rc, (self.lib.grp_last_error(None) or b"").decode())
+        self._h = out
+        self.pop = 0
+
+    def _check(self, rc):
+        if rc != GRP_OK:
+            raise GrpError(rc, (self.lib.grp_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h:
+            self.lib.grp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reads
+    def upload(self, seqs) -> ReadBatch:
+        packed, word_off, lens = pack_reads(seqs)
+        return self.upload_packed(packed, word_off, lens)
+
+    def upload_packed(self, packed, word_off, lens) -> ReadBatch:
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        out = C.c_void_p()
+        self._check(self.lib.grp_reads_upload(self._h, _ptr(packed), _ptr(word_off), _ptr(lens), len(lens), C.byref(out)))
+        return ReadBatch(self, out, len(lens), lens)
+
+    def wrap_device(self, d_ptr: int, word_off, lens, keep=None) -> ReadBatch:
+        word_off = np.ascontiguousarray(word_off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        out = C.c_void_p()
+        self._check(self.lib.grp_reads_wrap_device(self._h, C.c_void_p(d_ptr), _ptr(word_off), _ptr(lens), len(lens), C.byref(out)))
+        return ReadBatch(self, out, len(lens), lens, keep=keep)
+
+    # -- phase 1
+    def bv_insert(self, batch: ReadBatch, first: int = 0, count: int | None = None):
+        count = batch.n_reads - first if count is None else count
+        self._check(self.lib.grp_bv_insert(self._h, batch._h, first, count))
+
+    def finalize(self) -> int:
+        pop = C.c_uint64()
+        self._check(self.lib.grp_finalize(self._h, C.byref(pop)))
+        self.pop = pop.value
+        return self.pop
+
+    # -- phase 2
+    def query_tiles(self, batch: ReadBatch, first: int = 0, count: int | None = None, list_cap: int | None = None):
+        """Returns (tiles[structured], lists[structured], stats dict)."""
+        count = batch.n_reads - first if count is None else count
+        nt = int(batch.tile0[first + count] - batch.tile0[first])
+        tiles = np.zeros(nt, dtype=tile_summary_dtype)
+        cap = list_cap if list_cap is not None else max(4 * nt, 1024)
+        while True:
+            lists = np.zeros(cap, dtype=id_count_dtype)
+            used = C.c_uint64()
+            st = grp_query_stats()
+            rc = self.lib.grp_query_tiles(self._h, batch._h, first, count, _ptr(tiles), _ptr(lists), cap, C.byref(used), C.byref(st))
+            if rc == GRP_ERR_NOMEM and used.value > cap:
+                cap = int(used.value)
+                continue
+            self._check(rc)
+            return tiles, lists[: used.value], {"queries": st.queries, "hits": st.hits, "misses": st.misses}
+
+    def insert_tiles(self, batch: ReadBatch, read_idx: int, tile_start: int, tile_end: int, id_: int):
+        self._check(self.lib.grp_insert_tiles(self._h, batch._h, read_idx, tile_start, tile_end, id_))
+
+    def reset_ids(self):
+        self._check(self.lib.grp_reset_ids(self._h))
+
+    def sync(self):
+        self._check(self.lib.grp_sync(self._h))
+
+    # -- inspection
+    def export_bits(self) -> np.ndarray:
+        n = (self.m + 63) // 64
+        out = np.zeros(n, dtype=np.uint64)
+        self._check(self.lib.grp_export_bits(self._h, _ptr(out), n))
+        return out
+
+    def rank(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.uint64)
+        bit = np.zeros(pos.size, dtype=np.uint8)
+        rank = np.zeros(pos.size, dtype=np.uint64)
+        self._check(self.lib.grp_rank(self._h, _ptr(pos), pos.size, _ptr(bit), _ptr(rank)))
+        return bit, rank
+
+    def export_ids(self, first: int = 0, n: int | None = None):
+        n = self.pop - first if n is None else n
+        ids = np.zeros(n, dtype=np.uint32)
+        counts = np.zeros(n, dtype=np.uint32)
+        self._check(self.lib.grp_export_ids(self._h, first, n, _ptr(ids), _ptr(counts)))
+        return ids, counts
+
+    def import_ids(self, first: int, ids=None, counts=None):
+        n = len(ids) if ids is not None else len(counts)
+        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+        counts = None if counts is None else np.ascontiguousarray(counts, dtype=np.uint32)
+        self._check(self.lib.grp_import_ids(self._h, first, n, _ptr(ids), _ptr(counts)))
+
+    def tile_hashes(self, batch: ReadBatch, read_idx: int, tile_idx: int) -> np.ndarray:
+        cap = (self.tile + 1) * self.h
+        out = np.zeros(cap, dtype=np.uint64)
+        nv = C.c_uint64()
+        self._check(self.lib.grp_debug_tile_hashes(self._h, batch._h, read_idx, tile_idx, _ptr(out), cap, C.byref(nv)))
+        return out[: nv.value]
+
+    # -- measurement
+    def kernel_stats(self) -> dict:
+        arr = (grp_kernel_stat * GRP_K_COUNT)()
+        self._check(self.lib.grp_get_kernel_stats(self._h, arr))
+        return {KERNEL_NAMES[i]: {"launches": arr[i].launches, "units": arr[i].units, "ms": arr[i].ms} for i in range(GRP_K_COUNT)}
+
+    def reset_kernel_stats(self):
+        self._check(self.lib.grp_reset_kernel_stats(self._h))
+
+    def set_timing(self, on: bool):
+        self._check(self.lib.grp_set_timing(self._h, 1 if on else 0))

@@ -1,0 +1,267 @@
+/*
+ * grpath.h — C ABI of the MI355X (gfx950) GoldRush-Path engine, libgrpath_hip.so
+ *
+ * This is the drop-in boundary for the hot path of bcgsc/goldrush's
+ * goldrush-path (spaced-seed ntHash -> multi-index Bloom filter insert/query
+ * -> per-tile ID hit counts).  The reference has no plugin / FFI layer; each
+ * entry point below replaces a set of C++ call sites in the reference host
+ * (file:line relative to /root/reference/goldrush_path/), so that a host
+ * program keeps its control flow and swaps the data-structure calls for
+ * these.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every function returns GRP_OK (0) or a negative grp_status;
+ *     grp_last_error() gives the message.  The reference never throws on this
+ *     path, it prints to std::cerr and exit(1)s (goldrush_path.cpp:247-250,
+ *     327-334); a host built on this ABI prints grp_last_error() and exits
+ *     with the same code.
+ *   - there is NO CPU fallback: if no HIP device is usable, grp_create fails
+ *     with GRP_ERR_NO_DEVICE.
+ *   - threading: one host thread per grp_ctx (the reference's consumer side is
+ *     single-threaded too, goldrush_path.cpp:1229-1256).  grp_bv_insert may
+ *     be called repeatedly, in any order of reads (idempotent, order-free,
+ *     like MIBFConstructSupport::insertBV under `omp parallel`).
+ *   - ownership: the library owns all device memory; caller-provided host
+ *     buffers are only read/written during the call.
+ *
+ * Sequence encoding handed to the library: 2 bits per base, A=0 C=1 G=2 T=3
+ * (case-folded), 16 bases per little-endian uint32 word, base i of a read in
+ * bits [2*(i%16), 2*(i%16)+2) of word i/16; every read starts on a word
+ * boundary.  Only reads that are pure ACGT reach the hot path in the
+ * reference (goldrush_path.cpp:293-301), so the encoding is lossless there.
+ */
+#ifndef GRPATH_H
+#define GRPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRP_ABI_VERSION 1
+
+typedef enum
+{
+  GRP_OK = 0,
+  GRP_ERR_INVALID = -1,   /* bad argument / unsupported parameter */
+  GRP_ERR_NO_DEVICE = -2, /* no usable HIP device (no CPU fallback exists) */
+  GRP_ERR_HIP = -3,       /* a HIP runtime call failed */
+  GRP_ERR_STATE = -4,     /* call not valid in the current phase */
+  GRP_ERR_NOMEM = -5
+} grp_status;
+
+typedef struct grp_ctx grp_ctx;     /* one miBF + its device, stream, scratch */
+typedef struct grp_reads grp_reads; /* a batch of packed reads resident in HBM */
+
+/* limits of this implementation (checked by grp_create) */
+#define GRP_MAX_SEEDS 8  /* -h */
+#define GRP_MAX_SPAN 32  /* k + h - 1 <= 32 bases (one 64-bit window) */
+
+typedef struct
+{
+  uint32_t struct_size; /* = sizeof(grp_params) */
+  uint32_t k;           /* span of the base seed (-k) */
+  uint32_t h;           /* number of seed patterns (-h) */
+  uint32_t tile;        /* tile length (-t) */
+  uint64_t m;           /* filter size in bits, computed by the host with
+                           MIBloomFilter::calcOptimalSize
+                           (MIBloomFilter.hpp:94-101, goldrush_path.cpp:1183) */
+  const char* const* seeds; /* h strings of '0'/'1'; seed i has span k+i
+                               (make_seed_pattern, spaced_seeds.cpp:63-66) */
+  int32_t device;       /* HIP device ordinal; -1 = current device */
+  uint32_t flags;       /* reserved, 0 */
+} grp_params;
+
+/*
+ * Replaces: MIBFConstructSupport ctor (MIBFConstructSupport.hpp:66-84,
+ * called at goldrush_path.cpp:1185-1191).  Allocates the zeroed bit vector
+ * (in its rank-interleaved HBM layout) on the device.
+ */
+int grp_create(const grp_params* params, grp_ctx** out);
+void grp_destroy(grp_ctx* ctx);
+/* message of the last failure on ctx (ctx may be NULL: last grp_create failure) */
+const char* grp_last_error(const grp_ctx* ctx);
+
+/* ---- read batches --------------------------------------------------------- */
+/*
+ * Upload n_reads packed reads.  word_off has n_reads+1 entries (offset of each
+ * read in `packed`, in 32-bit words; word_off[n_reads] = total words);
+ * len[i] = bases in read i.  Replaces the per-read std::string the reference
+ * hands to multiLensfrHashIterator (goldrush_path.cpp:304, read_hashing.cpp:44-46).
+ */
+int grp_reads_upload(grp_ctx* ctx,
+                     const uint32_t* packed,
+                     const uint64_t* word_off,
+                     const uint32_t* len,
+                     uint32_t n_reads,
+                     grp_reads** out);
+/*
+ * Same, but `d_packed` already lives in device memory of ctx's device (e.g.
+ * synthetic reads generated on the GPU); it is borrowed, not copied, and must
+ * outlive the grp_reads.  word_off / len are host arrays.
+ */
+int grp_reads_wrap_device(grp_ctx* ctx,
+                          const void* d_packed,
+                          const uint64_t* word_off,
+                          const uint32_t* len,
+                          uint32_t n_reads,
+                          grp_reads** out);
+void grp_reads_free(grp_reads* reads);
+/* number of tiles of read i = len[i] / tile (read_hashing.cpp:29-30);
+ * tile0[i] = index of its first tile in the batch-wide tile numbering;
+ * tile0 has n_reads+1 entries. Pointer valid until grp_reads_free. */
+const uint64_t* grp_reads_tile0(const grp_reads* reads);
+
+/* ---- phase 1: bit-vector fill -------------------------------------------- */
+/*
+ * Replaces: multiLensfrHashIterator itr(record.seq, seeds); miBFCS.insertBV(itr)
+ * (goldrush_path.cpp:304-305 -> MIBFConstructSupport.hpp:134-147) for reads
+ * [first, first+count) of the batch: every position of the WHOLE read, every
+ * seed, bit (hash % m) is set.  Asynchronous on the context's stream.
+ */
+int grp_bv_insert(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count);
+
+/*
+ * Replaces: miBFCS.setup(); miBFCS.getEmptyMIBF()
+ * (goldrush_path.cpp:1203-1205 -> MIBFConstructSupport.hpp:165-181,
+ * MIBloomFilter.hpp:165-184, getPop :538-546).  Builds the rank structure,
+ * returns pop (number of set bits) and allocates the zeroed ID and count
+ * arrays (pop entries each).  After this call the bit vector is immutable.
+ */
+int grp_finalize(grp_ctx* ctx, uint64_t* pop);
+
+/* ---- phase 2: tile query -------------------------------------------------- */
+typedef struct
+{
+  uint32_t top_id;    /* arg-max ID of the tile's count table; ties -> smallest
+                         ID; 0 if the table is empty (goldrush_path.cpp:607-615) */
+  uint32_t top_count; /* its count (frames whose ID set contains it) */
+  uint32_t list_off;  /* first entry of this tile in the list array */
+  uint32_t list_n;    /* entries with count > 2 (goldrush_path.cpp:616-619),
+                         sorted by count descending, then ID ascending */
+} grp_tile_summary;
+
+typedef struct
+{
+  uint32_t id;
+  uint32_t count;
+} grp_id_count;
+
+typedef struct
+{
+  uint64_t queries; /* frames probed          (goldrush_path.cpp:567-568) */
+  uint64_t hits;    /* probes with non-zero ID (:577-591) */
+  uint64_t misses;  /* probes with ID 0        (:577-591) */
+} grp_query_stats;
+
+/*
+ * Replaces, for reads [first, first+count) of the batch: the hashing producer
+ * (start_read_hashing / read_hashing, read_hashing.cpp:29-54) and loop 1 of
+ * calc_num_assigned_tiles (goldrush_path.cpp:544-626: atRank
+ * MIBloomFilter.hpp:465-476, getData :614-621, per-frame ID dedup, per-tile
+ * count table, top ID, count>2 list).  The hashes are never materialised.
+ *
+ * tiles_out receives one summary per tile, reads in order, tiles in order
+ * (tile0[first+count]-tile0[first] entries; caller sizes it from
+ * grp_reads_tile0).  lists_out receives the count>2 lists, capacity
+ * list_cap entries; *list_used returns the number needed — if it exceeds
+ * list_cap the call returns GRP_ERR_NOMEM, nothing else is lost, and the call
+ * can be repeated with a larger array.  stats may be NULL.
+ * Synchronous: returns when the results are in the caller's arrays.
+ * Read-only on the miBF.
+ */
+int grp_query_tiles(grp_ctx* ctx,
+                    const grp_reads* reads,
+                    uint32_t first,
+                    uint32_t count,
+                    grp_tile_summary* tiles_out,
+                    grp_id_count* lists_out,
+                    uint64_t list_cap,
+                    uint64_t* list_used,
+                    grp_query_stats* stats);
+
+/* ---- phase 2: ID insert ---------------------------------------------------- */
+/*
+ * Replaces: miBFCS.insertMIBF(*miBF, hashed_values, tile_start, tile_end, id)
+ * (goldrush_path.cpp:988-989, 1048-1049 -> MIBFConstructSupport.hpp:247-283,
+ * getRankPos MIBloomFilter.hpp:488-491, setData :593-602) for one read of the
+ * batch: the set of distinct ranks over all hashes of tiles
+ * [tile_start, tile_end) ; for each distinct rank  c = ++counts[rank];
+ * if (uint32(rank ^ id) % c == c-1) ids[rank] = id (bit 31 preserved).
+ * One call = one dedup scope.  Asynchronous, ordered on the context's stream
+ * before any later grp_query_tiles / grp_insert_tiles.
+ */
+int grp_insert_tiles(grp_ctx* ctx,
+                     const grp_reads* reads,
+                     uint32_t read_idx,
+                     uint32_t tile_start,
+                     uint32_t tile_end,
+                     uint32_t id);
+
+/*
+ * Replaces: miBFCS.reset_counts(); mibf->reset_ID_vector()
+ * (goldrush_path.cpp:180-181 -> MIBFConstructSupport.hpp:183-186,
+ * MIBloomFilter.hpp:679-682).  Bit vector and rank structure untouched.
+ */
+int grp_reset_ids(grp_ctx* ctx);
+
+/* wait for all queued work of ctx */
+int grp_sync(grp_ctx* ctx);
+
+/* ---- inspection (used by the parity tests; not on the hot path) ----------- */
+/* m, number of set bits (0 before finalize) */
+uint64_t grp_filter_bits(const grp_ctx* ctx);
+uint64_t grp_pop(const grp_ctx* ctx);
+/* plain bit vector, bit i = word i>>6 bit i&63 (sdsl::bit_vector layout,
+ * MIBFConstructSupport.hpp:140-142); n_words = ceil(m/64) */
+int grp_export_bits(grp_ctx* ctx, uint64_t* words, uint64_t n_words);
+/* bit[i] / rank[i] (= ones in [0,pos[i])) for n positions; needs finalize */
+int grp_rank(grp_ctx* ctx, const uint64_t* pos, uint64_t n, uint8_t* bit, uint64_t* rank);
+/* ids / counts of ranks [first, first+n) */
+int grp_export_ids(grp_ctx* ctx, uint64_t first, uint64_t n, uint32_t* ids, uint32_t* counts);
+/* overwrite ids / counts of ranks [first, first+n) (either may be NULL) */
+int grp_import_ids(grp_ctx* ctx, uint64_t first, uint64_t n, const uint32_t* ids, const uint32_t* counts);
+/* the hash values of one tile exactly as read_hashing.cpp:47-53 lays them out
+ * (frame-major [f*h+s], stale values included); returns values written via
+ * *n_values, capacity cap */
+int grp_debug_tile_hashes(grp_ctx* ctx,
+                          const grp_reads* reads,
+                          uint32_t read_idx,
+                          uint32_t tile_idx,
+                          uint64_t* out,
+                          uint64_t cap,
+                          uint64_t* n_values);
+
+/* ---- measurement ------------------------------------------------------------ */
+enum
+{
+  GRP_K_FILL = 0,     /* bit-vector fill kernel */
+  GRP_K_RANK = 1,     /* rank build kernels (finalize) */
+  GRP_K_QUERY = 2,    /* fused hash + probe + tile histogram kernel */
+  GRP_K_INSERT = 3,   /* ID insert kernel */
+  GRP_K_COUNT = 4
+};
+
+typedef struct
+{
+  uint64_t launches;
+  uint64_t units;     /* probes (fill, query, insert) or blocks (rank) */
+  double ms;          /* sum of per-launch durations from HIP events recorded
+                         on the context's stream around each launch */
+} grp_kernel_stat;
+
+/* enable / disable per-launch HIP-event timing (default on) */
+int grp_set_timing(grp_ctx* ctx, int enabled);
+/* drains outstanding events (synchronises) and returns cumulative stats */
+int grp_get_kernel_stats(grp_ctx* ctx, grp_kernel_stat out[GRP_K_COUNT]);
+int grp_reset_kernel_stats(grp_ctx* ctx);
+
+/* HIP stream the context launches on (hipStream_t as void*) */
+void* grp_stream(grp_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRPATH_H */

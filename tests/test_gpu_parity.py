@@ -1,0 +1,181 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Integer / bit / index work: the bar is bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import SEED22, canon_list, default_seeds, random_reads
+
+pytestmark = pytest.mark.gpu
+
+K, TILE = 22, 1000
+
+
+def _mk(oracle, native, h=3, m=None, tile=TILE, k=K, preset=SEED22):
+    seeds = default_seeds(h, preset)
+    m = m or oracle.load().orc_calc_optimal_size(3_000_000, 1, 0.1)
+    eng = native.Engine(k, h, tile, m, seeds)
+    oseeds = oracle.Seeds(seeds)
+    omf = oracle.MiBF(m, oseeds, tile, k)
+    return eng, oseeds, omf, m
+
+
+@pytest.mark.parametrize("h", [1, 3, 5])
+def test_tile_hashes_match_oracle(oracle, native, h):
+    eng, oseeds, omf, m = _mk(oracle, native, h=h)
+    # lengths chosen to hit: exact multiple of tile, last tile clipped to
+    # fewer than `tile` frames (len % tile < k-1), stale frames of longer seeds
+    reads = random_reads(3, 2000, 6000, seed=11)
+    reads += [random_reads(1, 3000, 3000, 12)[0], random_reads(1, 3005, 3005, 13)[0], random_reads(1, 3021, 3021, 14)[0],
+              random_reads(1, 3020, 3020, 15)[0], random_reads(1, 1000, 1000, 16)[0]]
+    b = eng.upload(reads)
+    for ri, seq in enumerate(reads):
+        for t in range(len(seq) // TILE):
+            got = eng.tile_hashes(b, ri, t)
+            exp = oseeds.tile_hashes(seq, TILE, K, t)
+            assert got.shape == exp.shape, (ri, t)
+            assert np.array_equal(got, exp), (ri, t)
+
+
+def test_fill_bits_pop_rank(oracle, native):
+    eng, oseeds, omf, m = _mk(oracle, native)
+    reads = random_reads(12, 1500, 9000, seed=21) + [b"ACGT" * 6, b"A" * 25, b"ACGTTGCA" * 40]
+    b = eng.upload(reads)
+    eng.bv_insert(b, 0, 5)
+    eng.bv_insert(b, 5)        # second call; fill is order-free and idempotent
+    eng.bv_insert(b, 2, 3)     # repeat some reads
+    for s in reads:
+        if len(s) >= K + 3 - 1:  # shorter reads are reference-undefined
+            omf.bv_insert_read(s)
+    pop = eng.finalize()
+    assert pop == omf.finalize()
+    assert np.array_equal(eng.export_bits(), omf.bits())
+    rng = np.random.default_rng(5)
+    pos = rng.integers(0, m, size=20000, dtype=np.uint64)
+    pos[:4] = [0, 1, m - 1, m - 2]
+    bit, rank = eng.rank(pos)
+    for i in range(0, pos.size, 7):
+        assert bit[i] == omf.bit(int(pos[i]))
+        assert rank[i] == omf.rank(int(pos[i]))
+
+
+def _compare_queries(eng, omf, batch, reads):
+    tiles, lists, stats = eng.query_tiles(batch)
+    ti = 0
+    q = h = ms = 0
+    for seq in reads:
+        for res in omf.query_read(seq):
+            top_id, top_count, lst, ctr = res
+            t = tiles[ti]
+            assert (int(t["top_id"]), int(t["top_count"])) == (top_id, top_count), ti
+            got = [(int(a), int(c)) for a, c in lists[t["list_off"]: t["list_off"] + t["list_n"]]]
+            assert got == canon_list(lst), ti
+            q += ctr[0]; h += ctr[1]; ms += ctr[2]
+            ti += 1
+    assert ti == len(tiles)
+    assert (stats["queries"], stats["hits"], stats["misses"]) == (q, h, ms)
+
+
+def test_insert_and_query_match_oracle(oracle, native):
+    eng, oseeds, omf, m = _mk(oracle, native)
+    genome = random_reads(1, 60000, 60000, seed=31)[0]
+    reads = random_reads(10, 3000, 12000, seed=32, genome=genome) + random_reads(2, 4000, 5000, seed=33)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    for s in reads:
+        omf.bv_insert_read(s)
+    assert eng.finalize() == omf.finalize()
+    _compare_queries(eng, omf, b, reads)  # empty ID array: all misses
+    # inserts: whole reads in blocks of 10 tiles (goldrush_path.cpp:982-994),
+    # overlapping reads so that counts > 1 and the reservoir rule is exercised
+    next_id = 0
+    for ri in (0, 3, 5, 1, 7):
+        seq = reads[ri]
+        nt = len(seq) // TILE
+        next_id += 1
+        for bs in range(0, nt, 10):
+            be = min(bs + 10, nt)
+            eng.insert_tiles(b, ri, bs, be, next_id + bs // 10)
+            omf.insert_read_tiles(seq, bs, be, next_id + bs // 10)
+        next_id += len(seq) // (TILE * 10)
+        ids, counts = eng.export_ids()
+        assert np.array_equal(ids, omf.ids())
+        assert np.array_equal(counts, omf.counts())
+    _compare_queries(eng, omf, b, reads)
+    # partial (trimmed) insert with a dedup scope that is not tile-0 based
+    eng.insert_tiles(b, 8, 1, 3, 77)
+    omf.insert_read_tiles(reads[8], 1, 3, 77)
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts())
+    _compare_queries(eng, omf, b, reads)
+    # reset (silver path rollover, goldrush_path.cpp:180-181)
+    eng.reset_ids(); omf.reset_ids()
+    ids, counts = eng.export_ids()
+    assert not ids.any() and not counts.any()
+    _compare_queries(eng, omf, b, reads)
+
+
+def test_query_dense_random_ids_and_saturation_bit(oracle, native):
+    """Many distinct IDs per tile, ties, saturated (bit 31) values."""
+    eng, oseeds, omf, m = _mk(oracle, native, m=oracle.load().orc_calc_optimal_size(200_000, 1, 0.1))
+    reads = random_reads(6, 2500, 5200, seed=41)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    for s in reads:
+        omf.bv_insert_read(s)
+    pop = eng.finalize()
+    assert pop == omf.finalize()
+    rng = np.random.default_rng(7)
+    for n_ids in (3, 40, 100000):
+        ids = rng.integers(0, n_ids, size=pop, dtype=np.uint32)  # 0 = empty
+        sat = rng.random(pop) < 0.05
+        ids[sat] |= np.uint32(0x80000000)  # includes bare 0x80000000 ("saturated empty")
+        eng.import_ids(0, ids=ids, counts=np.zeros(pop, dtype=np.uint32))
+        omf.ids()[:] = ids
+        _compare_queries(eng, omf, b, reads)
+
+
+@pytest.mark.parametrize("h,tile", [(1, 1000), (5, 1000), (3, 500), (2, 64)])
+def test_other_geometries(oracle, native, h, tile):
+    k = 22
+    seeds = default_seeds(h)
+    m = oracle.load().orc_calc_optimal_size(400_000, 1, 0.1)
+    eng = native.Engine(k, h, tile, m, seeds)
+    oseeds = oracle.Seeds(seeds)
+    omf = oracle.MiBF(m, oseeds, tile, k)
+    reads = random_reads(5, 2 * tile, 6 * tile + 40, seed=51 + h)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    for s in reads:
+        omf.bv_insert_read(s)
+    assert eng.finalize() == omf.finalize()
+    assert np.array_equal(eng.export_bits(), omf.bits())
+    for ri in (0, 2):
+        nt = len(reads[ri]) // tile
+        eng.insert_tiles(b, ri, 0, nt, ri + 1)
+        omf.insert_read_tiles(reads[ri], 0, nt, ri + 1)
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts())
+    tiles, lists, stats = eng.query_tiles(b)
+    ti = 0
+    for seq in reads:
+        for res in omf.query_read(seq):
+            t = tiles[ti]
+            assert (int(t["top_id"]), int(t["top_count"])) == (res[0], res[1])
+            got = [(int(a), int(c)) for a, c in lists[t["list_off"]: t["list_off"] + t["list_n"]]]
+            assert got == canon_list(res[2])
+            ti += 1
+
+
+def test_errors_are_loud(native):
+    with pytest.raises(native.GrpError):
+        native.Engine(22, 3, 10, 1 << 20, default_seeds(3))  # tile shorter than the seeds
+    with pytest.raises(native.GrpError):
+        native.Engine(40, 3, 1000, 1 << 20, ["1" * 40, "1" * 41, "1" * 42])  # span > 32
+    eng = native.Engine(22, 3, 1000, 1 << 20, default_seeds(3))
+    b = eng.upload([b"ACGT" * 600])
+    with pytest.raises(native.GrpError):
+        eng.query_tiles(b)  # before finalize
+    eng.bv_insert(b)
+    eng.finalize()
+    with pytest.raises(native.GrpError):
+        eng.bv_insert(b)  # bit vector immutable after finalize
