@@ -84,6 +84,21 @@ SIGNATURES = {
     "grp_stream": (_vp, [_vp]),
 }
 
+
+class grp_synth_params(C.Structure):
+    _fields_ = [("genome_len", C.c_uint64), ("genome_seed", C.c_uint64), ("error_seed", C.c_uint64),
+                ("p_sub", C.c_float), ("p_ins", C.c_float), ("p_del", C.c_float)]
+
+
+# include/grpath_synth.h (measurement support)
+SIGNATURES.update({
+    "grp_synth_reads": (C.c_int, [C.POINTER(grp_synth_params), _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp]),
+    "grp_synth_alloc": (_vp, [C.c_uint64]),
+    "grp_synth_free": (None, [_vp]),
+    "grp_synth_download": (C.c_int, [_vp, C.c_uint64, _vp]),
+    "grp_synth_last_error": (C.c_char_p, []),
+})
+
 _lib = None
 
 
@@ -311,3 +326,66 @@ class Engine:
 
     def set_timing(self, on: bool):
         self._check(self.lib.grp_set_timing(self._h, 1 if on else 0))
+
+
+# ---------------------------------------------------------------------------
+# synthetic reads generated on the GPU (include/grpath_synth.h)
+# ---------------------------------------------------------------------------
+class DeviceReads:
+    """Packed synthetic reads living in a hipMalloc'ed buffer."""
+
+    def __init__(self, d_ptr: int, word_off: np.ndarray, lens: np.ndarray):
+        self.d_ptr, self.word_off, self.lens = d_ptr, word_off, lens
+
+    def download(self, first: int, count: int):
+        """ASCII sequences of reads [first, first+count) (for the CPU baseline / checks)."""
+        lib = load()
+        w0, w1 = int(self.word_off[first]), int(self.word_off[first + count])
+        buf = np.zeros(max(w1 - w0, 1), dtype=np.uint32)
+        rc = lib.grp_synth_download(C.c_void_p(self.d_ptr + 4 * w0), 4 * (w1 - w0), _ptr(buf))
+        if rc != 0:
+            raise GrpError(rc, lib.grp_synth_last_error().decode())
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        out = []
+        for i in range(first, first + count):
+            a = int(self.word_off[i]) - w0
+            nw = (int(self.lens[i]) + 15) // 16
+            words = buf[a:a + nw]
+            codes = ((words[:, None] >> (np.arange(16, dtype=np.uint32) * 2)[None, :]) & 3).reshape(-1)[: int(self.lens[i])]
+            out.append(acgt[codes].tobytes())
+        return out
+
+    def free(self):
+        if self.d_ptr:
+            load().grp_synth_free(C.c_void_p(self.d_ptr))
+            self.d_ptr = 0
+
+
+def synth_read_plan(n_reads: int, genome_len: int, mean_len: int = 25000, min_len: int = 20000, sigma: float = 0.25, seed: int = 2,
+                    max_len: int | None = None):
+    """Host-side plan (start, len, strand, word_off) of a synthetic read set."""
+    rng = np.random.default_rng(seed)
+    mu = np.log(mean_len) - 0.5 * sigma * sigma
+    lens = np.maximum(rng.lognormal(mu, sigma, size=n_reads).astype(np.int64), min_len)
+    if max_len is not None:
+        lens = np.minimum(lens, max_len)
+    lens = lens.astype(np.uint32)
+    start = rng.integers(0, genome_len, size=n_reads, dtype=np.uint64)
+    strand = (rng.random(n_reads) < 0.5).astype(np.uint8)
+    word_off = np.zeros(n_reads + 1, dtype=np.uint64)
+    np.cumsum((lens.astype(np.uint64) + 15) // 16, out=word_off[1:])
+    return start, lens, strand, word_off
+
+
+def synth_reads(n_reads: int, genome_len: int, genome_seed: int = 1, error_seed: int = 3, p_sub=0.03, p_ins=0.01, p_del=0.01,
+                stream: int = 0, **plan_kw) -> DeviceReads:
+    lib = load()
+    start, lens, strand, word_off = synth_read_plan(n_reads, genome_len, **plan_kw)
+    d = lib.grp_synth_alloc(int(word_off[-1]) * 4 + 64)
+    if not d:
+        raise GrpError(GRP_ERR_NOMEM, lib.grp_synth_last_error().decode())
+    p = grp_synth_params(genome_len, genome_seed, error_seed, p_sub, p_ins, p_del)
+    rc = lib.grp_synth_reads(C.byref(p), _ptr(start), _ptr(lens), _ptr(strand), _ptr(word_off), n_reads, C.c_void_p(d), C.c_void_p(stream))
+    if rc != 0:
+        raise GrpError(rc, lib.grp_synth_last_error().decode())
+    return DeviceReads(d, word_off, lens)
