@@ -611,14 +611,9 @@ k_query(DevFilter f,
     ts.top_count = bc;
     ts.list_off = (uint32_t)lo;
     ts.list_n = n;
+    ts.hits = hsum;
+    ts.misses = msum;
     tiles_out[blockIdx.x] = ts;
-    atomicAdd(&ctr[0], (unsigned long long)frames);
-    if (hsum) {
-      atomicAdd(&ctr[1], (unsigned long long)hsum);
-    }
-    if (msum) {
-      atomicAdd(&ctr[2], (unsigned long long)msum);
-    }
   }
   __syncthreads();
   const uint32_t n = min(sListN, list_cap_lds);
@@ -1398,9 +1393,11 @@ grp_query_tiles(grp_ctx* c,
     *list_used = used;
   }
   if (stats) {
-    stats->queries = c->h_qctr[0];
-    stats->hits = c->h_qctr[1];
-    stats->misses = c->h_qctr[2];
+    stats->queries = probes / c->params.h; /* one query per frame (goldrush_path.cpp:567-568) */
+    for (uint64_t i = 0; i < nt; ++i) {
+      stats->hits += tiles_out[i].hits;
+      stats->misses += tiles_out[i].misses;
+    }
   }
   if (used > list_cap) {
     return set_err(c, GRP_ERR_NOMEM, "grp_query_tiles: %llu list entries needed, capacity %llu", (unsigned long long)used, (unsigned long long)list_cap);

@@ -43,7 +43,7 @@ class grp_params(C.Structure):
     ]
 
 
-tile_summary_dtype = np.dtype([("top_id", "<u4"), ("top_count", "<u4"), ("list_off", "<u4"), ("list_n", "<u4")])
+tile_summary_dtype = np.dtype([("top_id", "<u4"), ("top_count", "<u4"), ("list_off", "<u4"), ("list_n", "<u4"), ("hits", "<u4"), ("misses", "<u4")])
 id_count_dtype = np.dtype([("id", "<u4"), ("count", "<u4")])
 
 

@@ -141,6 +141,9 @@ typedef struct
   uint32_t list_off;  /* first entry of this tile in the list array */
   uint32_t list_n;    /* entries with count > 2 (goldrush_path.cpp:616-619),
                          sorted by count descending, then ID ascending */
+  uint32_t hits;      /* probes of this tile that returned a non-zero ID
+                         (total_hits_per_path, goldrush_path.cpp:577-591) */
+  uint32_t misses;    /* probes that returned ID 0 (total_misses_per_path) */
 } grp_tile_summary;
 
 typedef struct
