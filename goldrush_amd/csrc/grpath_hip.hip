@@ -670,7 +670,10 @@ k_insert(DevFilter f,
   uint32_t* sBases = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
 
   const uint32_t r = read_idx;
-  const uint32_t ti = tile_start + blockIdx.x;
+  // one frame per thread: `parts` workgroups share a tile
+  const uint32_t parts = (tile_len + THREADS - 1) / THREADS;
+  const uint32_t ti = tile_start + blockIdx.x / parts;
+  const uint32_t part = blockIdx.x % parts;
   const uint32_t len = rd.len[r];
   const uint32_t k = sd->k;
   const uint32_t start = ti * tile_len;
@@ -681,7 +684,7 @@ k_insert(DevFilter f,
   const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[r], len, start, Lp);
   __syncthreads();
 
-  for (uint32_t fr = threadIdx.x; fr < frames; fr += THREADS) {
+  for (uint32_t fr = part * THREADS + threadIdx.x; fr < frames; fr += THREADS * parts) {
     uint64_t blk[H];
     uint32_t off[H];
     uint4 bv[H];
@@ -1461,7 +1464,7 @@ grp_insert_tiles(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t til
   const size_t lds = tab_bytes(c) + bases_bytes(c->params.tile + c->params.k + c->params.h);
   {
     Timer t(c, GRP_K_INSERT, max_ranks);
-    DISPATCH_H(c->params.h, (k_insert<HH><<<dim3(nt), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, read_idx, tile_start, id, c->d_dedup, c->dedup_cap - 1, epoch_tag)));
+    DISPATCH_H(c->params.h, (k_insert<HH><<<dim3(nt * ((c->params.tile + THREADS - 1) / THREADS)), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, read_idx, tile_start, id, c->d_dedup, c->dedup_cap - 1, epoch_tag)));
   }
   HIP_TRY(c, hipGetLastError());
   return GRP_OK;

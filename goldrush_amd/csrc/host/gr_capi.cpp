@@ -1,0 +1,145 @@
+// extern "C" surface of libgrpath_host.so (include/grpath_host.h).
+#include "../../../include/grpath_host.h"
+#include "gr_classifier.hpp"
+#include "gr_params.hpp"
+#include "gr_tiles.hpp"
+
+#include <cstring>
+#include <new>
+
+extern "C" {
+
+int
+gr_make_seed_pattern(const char* preset, unsigned k, unsigned weight, unsigned h, char* out, size_t stride, int log_to_stderr)
+{
+  if (!out || k / 2 == 0) {
+    return -1;
+  }
+  auto seeds = gr::make_seed_pattern(preset ? preset : "", k, weight, h, log_to_stderr != 0);
+  for (unsigned i = 0; i < h; ++i) {
+    if (seeds[i].size() + 1 > stride) {
+      return -1;
+    }
+    std::memcpy(out + (size_t)i * stride, seeds[i].c_str(), seeds[i].size() + 1);
+  }
+  return 0;
+}
+
+uint64_t
+gr_hash_universe(uint64_t weight, uint64_t genome_size, uint64_t hash_num)
+{
+  return gr::hash_universe(weight, genome_size, hash_num);
+}
+
+uint64_t
+gr_calc_optimal_size(uint64_t entries, unsigned hash_num, double occupancy)
+{
+  return gr::calc_optimal_size(entries, hash_num, occupancy);
+}
+
+void
+gr_calc_phred_average(const char* qual, size_t n, uint32_t* avg, uint32_t* delta)
+{
+  gr::calc_phred_average(qual, n, *avg, *delta);
+}
+
+double
+gr_sum_phred(const char* qual, size_t n)
+{
+  return gr::sum_phred(qual, n);
+}
+
+int
+gr_pack_2bit(const char* seq, size_t n, uint32_t* out_words)
+{
+  return gr::pack_2bit(seq, n, out_words) ? 0 : -1;
+}
+
+void
+gr_decide_read(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t num_tiles, const grp_tile_summary* tiles, const grp_id_count* lists, gr_read_decision* out)
+{
+  gr::TileWorkspace ws;
+  gr::ReadDecision d;
+  gr::decide_read(gr::DecideParams{ threshold, unassigned_min, assigned_max }, num_tiles, tiles, lists, ws, d);
+  std::memcpy(out, &d, sizeof(d));
+}
+
+size_t
+gr_smooth_tiles(size_t num_tiles, const grp_tile_summary* tiles, const grp_id_count* lists, size_t threshold, uint32_t* ids_out, uint8_t* bools_out)
+{
+  gr::TileWorkspace ws;
+  size_t n = gr::smooth_tiles(num_tiles, tiles, lists, threshold, ws);
+  for (size_t i = 0; i < num_tiles; ++i) {
+    ids_out[i] = ws.ids[i];
+    bools_out[i] = ws.asg[i];
+  }
+  return n;
+}
+
+void
+gr_find_longest_stretch(const uint8_t* bools, size_t num_tiles, long* start, long* end)
+{
+  std::vector<uint8_t> b(bools, bools + num_tiles);
+  gr::find_longest_stretch(b, num_tiles, *start, *end);
+}
+
+int
+gr_eval_flanks(long ls, long le, const uint32_t* ids, size_t num_tiles, size_t* trim_start, size_t* trim_end)
+{
+  return gr::eval_flanks(ls, le, ids, num_tiles, *trim_start, *trim_end) ? 1 : 0;
+}
+
+struct gr_classifier
+{
+  gr::Classifier impl;
+  gr_classifier(const gr_classifier_params& p, const grp_engine_vt& vt, void* ctx)
+    : impl(p, vt, ctx)
+  {}
+};
+
+int
+gr_classifier_create(const gr_classifier_params* p, const grp_engine_vt* vt, void* engine_ctx, gr_classifier** out)
+{
+  if (!p || !vt || !out || p->struct_size != sizeof(gr_classifier_params) || p->tile_length == 0 || p->block_size == 0) {
+    return GRP_ERR_INVALID;
+  }
+  *out = new (std::nothrow) gr_classifier(*p, *vt, engine_ctx);
+  return *out ? GRP_OK : GRP_ERR_NOMEM;
+}
+
+void
+gr_classifier_destroy(gr_classifier* c)
+{
+  delete c;
+}
+
+void
+gr_classifier_set_callbacks(gr_classifier* c, gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user)
+{
+  c->impl.set_callbacks(commit, rollover, allgather, user);
+}
+
+int
+gr_classifier_run(gr_classifier* c, void* reads, const uint32_t* lens, uint32_t n_reads, const uint32_t* skipped_before, uint32_t skipped_after, int* finished)
+{
+  bool fin = false;
+  int rc = c->impl.run(reads, lens, n_reads, skipped_before, skipped_after, fin);
+  if (finished) {
+    *finished = fin ? 1 : 0;
+  }
+  return rc;
+}
+
+const char*
+gr_classifier_error(const gr_classifier* c)
+{
+  return c->impl.error().c_str();
+}
+
+void
+gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out)
+{
+  c->impl.get_state(*out);
+}
+
+} // extern "C"

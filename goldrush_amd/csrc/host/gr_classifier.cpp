@@ -1,0 +1,366 @@
+// See gr_classifier.hpp.  commit() is process_read() after the tile query
+// (goldrush_path.cpp:960-1094); silver_path_check() is :156-187.
+#include "gr_classifier.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+namespace gr {
+
+Classifier::Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, void* ctx)
+  : p_(p)
+  , vt_(vt)
+  , ctx_(ctx)
+{
+  if (p_.world == 0) {
+    p_.world = 1;
+  }
+  if (p_.max_window == 0) {
+    p_.max_window = 4096;
+  }
+  if (p_.max_window < p_.world) {
+    p_.max_window = p_.world;
+  }
+}
+
+void
+Classifier::set_callbacks(gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user)
+{
+  commit_cb_ = commit;
+  rollover_cb_ = rollover;
+  allgather_cb_ = allgather;
+  user_ = user;
+}
+
+void
+Classifier::get_state(gr_classifier_state& s) const
+{
+  s = gr_classifier_state{};
+  s.valid_reads = valid_reads_;
+  s.total_tiles = total_tiles_;
+  s.assigned_tiles = assigned_tiles_;
+  s.unassigned_tiles = unassigned_tiles_;
+  s.queries = queries_;
+  s.hits = hits_;
+  s.misses = misses_;
+  s.num_reads_in_path = num_reads_in_path_;
+  s.phred_sum_in_path = phred_sum_in_path_;
+  s.inserted_bases = inserted_bases_;
+  s.curr_path = curr_path_;
+  s.id = id_;
+  s.ids_inserted = ids_inserted_;
+  s.windows = n_windows_;
+  s.reads_queried = n_queried_;
+  s.reads_committed = n_committed_;
+  s.inserts = n_inserts_;
+}
+
+void
+Classifier::log_path_stat() const
+{
+  // goldrush_path.cpp:126-154
+  const uint64_t cp = curr_path_;
+  std::cerr << "Visited " << valid_reads_ << " reads to generate " << cp << " silver paths" << std::endl;
+  std::cerr << "Saw: " << total_tiles_ << " tiles to generate " << cp << " silver paths" << std::endl;
+  std::cerr << "Assigned: " << assigned_tiles_ << " tiles to generate " << cp << " silver paths" << std::endl;
+  std::cerr << "Unassigned: " << unassigned_tiles_ << " tiles to generate " << cp << " silver paths" << std::endl;
+  std::cerr << "Total queries: " << queries_ << " to generate " << cp << " silver paths" << std::endl;
+  std::cerr << "Total hits: " << hits_ << " to generate " << cp << " silver paths" << std::endl;
+  std::cerr << "Total misses: " << misses_ << " to generate " << cp << " silver paths" << std::endl;
+  std::cerr << "Num reads: " << num_reads_in_path_ << " in silver path " << cp << std::endl;
+  const uint32_t avg_phred = (uint32_t)(-10 * std::log10(phred_sum_in_path_ / inserted_bases_));
+  std::cerr << "Average Phred: " << avg_phred << " in silver path " << cp << std::endl;
+}
+
+void
+Classifier::bump_id()
+{
+  ++id_;
+  if (id_ % 10000 == 0 && p_.rank == 0) {
+    std::cerr << "processed " << id_ << " reads" << std::endl;
+  }
+}
+
+void
+Classifier::skip_reads(uint32_t n)
+{
+  // too short / filtered reads only advance the counter (goldrush_path.cpp:907-932)
+  for (uint32_t i = 0; i < n; ++i) {
+    bump_id();
+  }
+}
+
+uint32_t
+Classifier::window_size() const
+{
+  // P(no insert within the window) ~ exp(-0.7) ~ 0.5
+  double s = 0.7 / std::max(p_insert_, 1e-6);
+  uint32_t w = (uint32_t)std::min<double>(std::max(s, 1.0), (double)p_.max_window);
+  if (p_.world > 1) {
+    w = ((w + p_.world - 1) / p_.world) * p_.world;
+  }
+  return w;
+}
+
+int
+Classifier::query_window(void* reads, const uint32_t* lens, uint32_t first, uint32_t count)
+{
+  (void)lens;
+  const uint32_t world = p_.world;
+  const uint32_t q = (count + world - 1) / world; // reads per rank
+  const uint32_t my_first = std::min<uint64_t>((uint64_t)first + (uint64_t)p_.rank * q, (uint64_t)first + count);
+  const uint32_t my_count = std::min<uint32_t>(q, first + count - my_first);
+  dec_.assign(q, gr_read_decision{});
+  if (my_count) {
+    const uint64_t nt = tile0_[my_first + my_count] - tile0_[my_first];
+    tiles_.resize(nt ? nt : 1);
+    if (lists_.size() < 4 * nt + 1024) {
+      lists_.resize(4 * nt + 1024);
+    }
+    for (;;) {
+      uint64_t used = 0;
+      int rc = vt_.query_tiles(ctx_, reads, my_first, my_count, tiles_.data(), lists_.data(), lists_.size(), &used, nullptr);
+      if (rc == GRP_ERR_NOMEM && used > lists_.size()) {
+        lists_.resize(used + used / 4);
+        continue;
+      }
+      if (rc != GRP_OK) {
+        err_ = std::string("query_tiles: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+        return rc;
+      }
+      break;
+    }
+    n_queried_ += my_count;
+    const DecideParams dp{ p_.threshold, p_.unassigned_min, p_.assigned_max };
+    const uint64_t t_base = tile0_[my_first];
+#if defined(_OPENMP)
+    const int nthreads = (my_count >= 64) ? omp_get_max_threads() : 1;
+#else
+    const int nthreads = 1;
+#endif
+    if ((int)ws_.size() < nthreads) {
+      ws_.resize(nthreads);
+    }
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+    for (uint32_t j = 0; j < my_count; ++j) {
+#if defined(_OPENMP)
+      TileWorkspace& ws = ws_[omp_get_thread_num()];
+#else
+      TileWorkspace& ws = ws_[0];
+#endif
+      const uint64_t a = tile0_[my_first + j] - t_base;
+      const uint64_t b = tile0_[my_first + j + 1] - t_base;
+      ReadDecision rd;
+      decide_read(dp, (size_t)(b - a), tiles_.data() + a, lists_.data(), ws, rd);
+      static_assert(sizeof(ReadDecision) == sizeof(gr_read_decision), "decision layout");
+      std::memcpy(&dec_[j], &rd, sizeof(rd));
+    }
+  }
+  if (world > 1) {
+    dec_all_.resize((size_t)q * world);
+    if (!allgather_cb_) {
+      err_ = "world > 1 but no allgather callback";
+      return GRP_ERR_INVALID;
+    }
+    int rc = allgather_cb_(user_, dec_.data(), (uint64_t)q * sizeof(gr_read_decision), dec_all_.data());
+    if (rc != 0) {
+      err_ = "allgather callback failed";
+      return GRP_ERR_INVALID;
+    }
+  } else {
+    dec_all_.swap(dec_);
+  }
+  ++n_windows_;
+  return GRP_OK;
+}
+
+void
+Classifier::silver_path_check(int& rc)
+{
+  // goldrush_path.cpp:156-187
+  if (p_.target_bases < inserted_bases_) {
+    if (p_.verbose && p_.rank == 0) {
+      log_path_stat();
+    }
+    ++curr_path_;
+    if (p_.max_paths < curr_path_) {
+      finished_ = true; // exit(0) in the reference
+      return;
+    }
+    inserted_bases_ = 0;
+    num_reads_in_path_ = 0;
+    phred_sum_in_path_ = 0;
+    int e = vt_.reset_ids(ctx_);
+    if (e != GRP_OK) {
+      rc = e;
+      err_ = std::string("reset_ids: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+      return;
+    }
+    if (rollover_cb_) {
+      rollover_cb_(user_, curr_path_);
+    }
+    ids_inserted_ = 0;
+  }
+}
+
+// returns true when the read changed the miBF (everything queried after it is stale)
+bool
+Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_decision& d, int& rc)
+{
+  const uint32_t len = lens[r];
+  const uint32_t tile = p_.tile_length, block = p_.block_size, k = p_.kmer_size;
+  const uint32_t nt = d.num_tiles;
+  total_tiles_ += nt;
+  if (nt) {
+    // one query per frame (:567-568); only the last tile can be clipped
+    const uint32_t start = (nt - 1) * tile;
+    const uint32_t Lp = std::min(tile + k - 1, len - start);
+    queries_ += (uint64_t)(nt - 1) * tile + (Lp >= k ? Lp - k + 1 : 0);
+  }
+  hits_ += d.hits;
+  misses_ += d.misses;
+  assigned_tiles_ += d.num_assigned;
+  unassigned_tiles_ += nt - d.num_assigned;
+
+  gr_commit ev{};
+  ev.read = r;
+  ev.dec = d;
+  ev.path = curr_path_;
+  bool inserted = false;
+
+  auto insert_block = [&](uint32_t ts, uint32_t te, uint32_t id) {
+    if (rc != GRP_OK) {
+      return;
+    }
+    int e = vt_.insert_tiles(ctx_, reads, r, ts, te, id);
+    if (e != GRP_OK) {
+      rc = e;
+      err_ = std::string("insert_tiles: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+    }
+  };
+
+  switch (d.kind) {
+    case DEC_INSERT_WHOLE: {
+      // :978-1011
+      ++ids_inserted_;
+      ev.first_id = ids_inserted_;
+      for (uint32_t bs = 0; bs < nt; bs += block) {
+        insert_block(bs, std::min(bs + block, nt), ids_inserted_ + (uint32_t)(bs / block));
+      }
+      ids_inserted_ = ids_inserted_ + (uint32_t)(len / ((size_t)tile * block));
+      const double ph = commit_cb_ ? commit_cb_(user_, &ev) : 0.0;
+      inserted_bases_ += len;
+      ++num_reads_in_path_;
+      phred_sum_in_path_ += ph;
+      if (p_.silver_path) {
+        silver_path_check(rc);
+      }
+      inserted = true;
+      break;
+    }
+    case DEC_ASSIGNED_ALL: {
+      // :1013-1023
+      if (commit_cb_) {
+        commit_cb_(user_, &ev);
+      }
+      ++valid_reads_;
+      bump_id();
+      return false;
+    }
+    case DEC_INSERT_TRIMMED: {
+      // :1038-1080
+      const uint32_t ts = d.trim_start, te = d.trim_end;
+      ++ids_inserted_;
+      ev.first_id = ids_inserted_;
+      for (uint64_t bs = ts; bs <= te; bs += block) {
+        const uint64_t be = std::min<uint64_t>(bs + block - 1, te);
+        insert_block((uint32_t)bs, (uint32_t)be + 1, ids_inserted_ + (uint32_t)((bs - ts + 1) / block));
+      }
+      ids_inserted_ = ids_inserted_ + (uint32_t)((te - ts) / block);
+      // new_seq = seq.substr(ts*tile, te == nt-1 ? npos : (te-ts+1)*tile)
+      const uint64_t off = (uint64_t)ts * tile;
+      uint64_t n_out = len - off;
+      if (te != nt - 1) {
+        n_out = std::min<uint64_t>(n_out, (uint64_t)(te - ts + 1) * tile);
+      }
+      inserted_bases_ += n_out;
+      const double ph = commit_cb_ ? commit_cb_(user_, &ev) : 0.0;
+      ++num_reads_in_path_;
+      phred_sum_in_path_ += ph;
+      if (p_.silver_path) {
+        silver_path_check(rc);
+      }
+      inserted = true;
+      break;
+    }
+    default: // DEC_ASSIGNED (:1083-1088)
+      if (commit_cb_) {
+        commit_cb_(user_, &ev);
+      }
+      break;
+  }
+  if (finished_) {
+    return inserted; // exit(0) inside silver_path_check: no ++id
+  }
+  ++valid_reads_;
+  bump_id();
+  return inserted;
+}
+
+int
+Classifier::run(void* reads, const uint32_t* lens, uint32_t n, const uint32_t* skipped_before, uint32_t skipped_after, bool& finished)
+{
+  finished = finished_;
+  if (finished_) {
+    return GRP_OK;
+  }
+  tile0_.resize((size_t)n + 1);
+  tile0_[0] = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    tile0_[i + 1] = tile0_[i] + lens[i] / p_.tile_length;
+  }
+  uint32_t pos = 0;
+  int rc = GRP_OK;
+  while (pos < n && !finished_) {
+    const uint32_t S = std::min<uint32_t>(window_size(), n - pos);
+    rc = query_window(reads, lens, pos, S);
+    if (rc != GRP_OK) {
+      return rc;
+    }
+    uint32_t j = 0;
+    while (j < S) {
+      if (skipped_before) {
+        skip_reads(skipped_before[pos + j]);
+      }
+      const bool ins = commit(reads, lens, pos + j, dec_all_[j], rc);
+      if (rc != GRP_OK) {
+        return rc;
+      }
+      ++n_committed_;
+      p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
+      ++j;
+      if (ins) {
+        ++n_inserts_;
+        break; // the miBF changed: later speculative results are stale
+      }
+      if (finished_) {
+        break;
+      }
+    }
+    pos += j;
+  }
+  if (!finished_) {
+    skip_reads(skipped_after);
+  }
+  finished = finished_;
+  return GRP_OK;
+}
+
+} // namespace gr

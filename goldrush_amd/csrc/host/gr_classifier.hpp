@@ -1,0 +1,72 @@
+// Order-exact read classification on top of the engine ABI.
+//
+// The reference classifies reads strictly one after the other
+// (goldrush_path.cpp:1229-1256): read N is queried after the inserts of every
+// accepted read < N.  Here a *window* of consecutive reads is queried
+// speculatively in one kernel launch, the decisions are committed in file
+// order, and as soon as one read inserts (which changes the miBF) the rest of
+// the window is discarded and queried again.  The window size adapts to the
+// observed insert rate, so the result is identical to the serial loop while
+// the insert-free stretches run as large GPU batches.
+#pragma once
+#include "../../../include/grpath_host.h"
+#include "gr_tiles.hpp"
+
+#include <string>
+#include <vector>
+
+namespace gr {
+
+class Classifier
+{
+public:
+  Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, void* ctx);
+  void set_callbacks(gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user);
+  int run(void* reads, const uint32_t* lens, uint32_t n, const uint32_t* skipped_before, uint32_t skipped_after, bool& finished);
+  void get_state(gr_classifier_state& s) const;
+  // tail of main(): verbose per-path statistics (goldrush_path.cpp:1266-1270)
+  void log_path_stat() const;
+  const std::string& error() const { return err_; }
+  uint64_t curr_path() const { return curr_path_; }
+  bool finished() const { return finished_; }
+
+private:
+  int query_window(void* reads, const uint32_t* lens, uint32_t first, uint32_t count);
+  bool commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_decision& d, int& rc);
+  void silver_path_check(int& rc);
+  void skip_reads(uint32_t n);
+  void bump_id();
+  uint32_t window_size() const;
+
+  gr_classifier_params p_;
+  grp_engine_vt vt_;
+  void* ctx_;
+  gr_commit_fn commit_cb_ = nullptr;
+  gr_rollover_fn rollover_cb_ = nullptr;
+  gr_allgather_fn allgather_cb_ = nullptr;
+  void* user_ = nullptr;
+
+  // main()'s loop state (goldrush_path.cpp:1222-1227) + log_info_struct (:41-51)
+  uint64_t inserted_bases_ = 0;
+  uint64_t curr_path_ = 1;
+  uint32_t id_ = 1;
+  uint32_t ids_inserted_ = 0;
+  uint64_t valid_reads_ = 0, total_tiles_ = 0, assigned_tiles_ = 0, unassigned_tiles_ = 0;
+  uint64_t queries_ = 0, hits_ = 0, misses_ = 0, num_reads_in_path_ = 0;
+  double phred_sum_in_path_ = 0;
+  bool finished_ = false;
+
+  // speculation control / statistics
+  double p_insert_ = 1.0;
+  uint64_t n_windows_ = 0, n_queried_ = 0, n_committed_ = 0, n_inserts_ = 0;
+
+  // scratch
+  std::vector<uint64_t> tile0_;
+  std::vector<grp_tile_summary> tiles_;
+  std::vector<grp_id_count> lists_;
+  std::vector<gr_read_decision> dec_, dec_all_;
+  std::vector<TileWorkspace> ws_;
+  std::string err_;
+};
+
+} // namespace gr

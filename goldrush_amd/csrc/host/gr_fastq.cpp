@@ -1,0 +1,134 @@
+#include "gr_fastq.hpp"
+
+#include <cctype>
+#include <cstring>
+
+namespace gr {
+
+FastqStream::FastqStream(const std::string& path)
+{
+  fp_ = fopen(path.c_str(), "rb");
+  buf_.resize(size_t(8) << 20);
+}
+
+FastqStream::~FastqStream()
+{
+  if (fp_) {
+    fclose(fp_);
+  }
+}
+
+bool
+FastqStream::fill()
+{
+  if (eof_ || !fp_) {
+    return false;
+  }
+  // keep the unread tail, refill the rest
+  const size_t tail = end_ - pos_;
+  if (tail && pos_) {
+    memmove(buf_.data(), buf_.data() + pos_, tail);
+  }
+  pos_ = 0;
+  end_ = tail;
+  if (end_ == buf_.size()) {
+    buf_.resize(buf_.size() * 2); // a single line longer than the buffer
+  }
+  const size_t got = fread(buf_.data() + end_, 1, buf_.size() - end_, fp_);
+  if (got == 0) {
+    eof_ = true;
+    return false;
+  }
+  end_ += got;
+  return true;
+}
+
+bool
+FastqStream::is_fastq()
+{
+  if (pos_ == end_ && !fill()) {
+    return false;
+  }
+  return buf_[pos_] == '@';
+}
+
+bool
+FastqStream::get_line(const char*& p, size_t& n)
+{
+  for (;;) {
+    const char* start = buf_.data() + pos_;
+    const char* nl = (const char*)memchr(start, '\n', end_ - pos_);
+    if (nl) {
+      p = start;
+      n = (size_t)(nl - start);
+      pos_ += n + 1;
+      break;
+    }
+    if (!fill()) {
+      if (pos_ == end_) {
+        return false;
+      }
+      p = buf_.data() + pos_; // last line without newline
+      n = end_ - pos_;
+      pos_ = end_;
+      break;
+    }
+  }
+  while (n > 0 && (p[n - 1] == '\r' || p[n - 1] == ' ' || p[n - 1] == '\t')) {
+    --n;
+  }
+  return true;
+}
+
+bool
+FastqStream::next_batch(RecordBatch& out, size_t max_records, size_t max_bases)
+{
+  out.clear();
+  while (out.rec.size() < max_records && out.bases < max_bases) {
+    const char* p;
+    size_t n;
+    // get_line pointers die at the next refill, so each line is copied at once
+    if (!get_line(p, n)) {
+      break;
+    }
+    if (n == 0 || p[0] != '@') {
+      break; // not a FASTQ header: stop like a reader at end of input
+    }
+    RecordRef r{};
+    size_t idn = 0;
+    while (1 + idn < n && !isspace((unsigned char)p[1 + idn])) {
+      ++idn;
+    }
+    r.id_off = out.text.size();
+    r.id_len = idn;
+    out.text.insert(out.text.end(), p + 1, p + 1 + idn);
+    out.text.push_back('\0');
+    if (!get_line(p, n)) {
+      out.text.resize(r.id_off);
+      break;
+    }
+    r.seq_off = out.text.size();
+    r.seq_len = n;
+    out.text.insert(out.text.end(), p, p + n);
+    out.text.push_back('\0');
+    for (size_t i = 0; i < n; ++i) {
+      char& c = out.text[r.seq_off + i];
+      if (c >= 'a' && c <= 'z') {
+        c = (char)(c - 32);
+      }
+    }
+    if (!get_line(p, n) || !get_line(p, n)) { // '+' line, then qualities
+      out.text.resize(r.id_off);
+      break;
+    }
+    r.qual_off = out.text.size();
+    r.qual_len = n;
+    out.text.insert(out.text.end(), p, p + n);
+    out.text.push_back('\0');
+    out.rec.push_back(r);
+    out.bases += r.seq_len;
+  }
+  return !out.rec.empty();
+}
+
+} // namespace gr

@@ -1,0 +1,60 @@
+// Streaming FASTQ reader with the record semantics the reference gets from
+// btllib::SeqReader (LONG_MODE, default flags): id = header up to the first
+// whitespace, sequence case-folded to upper case, 4-line records, records in
+// file order.  Plain-text input only.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace gr {
+
+struct RecordRef
+{
+  size_t id_off, id_len;
+  size_t seq_off, seq_len;
+  size_t qual_off, qual_len;
+};
+
+// a run of consecutive records; all text lives in one buffer
+struct RecordBatch
+{
+  std::vector<char> text;
+  std::vector<RecordRef> rec;
+  size_t bases = 0;
+  void clear()
+  {
+    text.clear();
+    rec.clear();
+    bases = 0;
+  }
+  const char* id(size_t i) const { return text.data() + rec[i].id_off; }
+  const char* seq(size_t i) const { return text.data() + rec[i].seq_off; }
+  const char* qual(size_t i) const { return text.data() + rec[i].qual_off; }
+  std::string id_str(size_t i) const { return std::string(id(i), rec[i].id_len); }
+};
+
+class FastqStream
+{
+public:
+  explicit FastqStream(const std::string& path);
+  ~FastqStream();
+  bool ok() const { return fp_ != nullptr; }
+  // SeqReader::get_format() == FASTQ  <=>  first byte of the file is '@'
+  bool is_fastq();
+  // appends up to max_records / ~max_bases to `out` (cleared first); false at EOF
+  bool next_batch(RecordBatch& out, size_t max_records, size_t max_bases);
+
+private:
+  bool fill();
+  bool get_line(const char*& p, size_t& n); // without the trailing newline / CR / blanks
+  FILE* fp_ = nullptr;
+  std::vector<char> buf_;
+  size_t pos_ = 0, end_ = 0;
+  bool eof_ = false;
+  std::vector<char> carry_;
+};
+
+} // namespace gr

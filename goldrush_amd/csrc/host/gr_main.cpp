@@ -1,0 +1,34 @@
+// goldrush-path — drop-in for the reference binary of the same name
+// (goldrush_path/meson.build:6): same flags, same outputs; the miBF work runs
+// on an MI355X through libgrpath_hip.so.  There is no CPU path.
+#include "../../../include/grpath.h"
+#include "../../../include/grpath_host.h"
+
+static grp_engine_vt
+hip_engine()
+{
+  grp_engine_vt vt{};
+  vt.create = [](const grp_params* p, void** out) { return grp_create(p, reinterpret_cast<grp_ctx**>(out)); };
+  vt.destroy = [](void* c) { grp_destroy(static_cast<grp_ctx*>(c)); };
+  vt.last_error = [](const void* c) { return grp_last_error(static_cast<const grp_ctx*>(c)); };
+  vt.reads_upload = [](void* c, const uint32_t* packed, const uint64_t* off, const uint32_t* len, uint32_t n, void** out) {
+    return grp_reads_upload(static_cast<grp_ctx*>(c), packed, off, len, n, reinterpret_cast<grp_reads**>(out));
+  };
+  vt.reads_free = [](void* r) { grp_reads_free(static_cast<grp_reads*>(r)); };
+  vt.bv_insert = [](void* c, const void* r, uint32_t first, uint32_t count) { return grp_bv_insert(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count); };
+  vt.finalize = [](void* c, uint64_t* pop) { return grp_finalize(static_cast<grp_ctx*>(c), pop); };
+  vt.query_tiles = [](void* c, const void* r, uint32_t first, uint32_t count, grp_tile_summary* t, grp_id_count* l, uint64_t cap, uint64_t* used, grp_query_stats* st) {
+    return grp_query_tiles(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, t, l, cap, used, st);
+  };
+  vt.insert_tiles = [](void* c, const void* r, uint32_t ri, uint32_t ts, uint32_t te, uint32_t id) { return grp_insert_tiles(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), ri, ts, te, id); };
+  vt.reset_ids = [](void* c) { return grp_reset_ids(static_cast<grp_ctx*>(c)); };
+  vt.sync = [](void* c) { return grp_sync(static_cast<grp_ctx*>(c)); };
+  return vt;
+}
+
+int
+main(int argc, char** argv)
+{
+  const grp_engine_vt vt = hip_engine();
+  return gr_path_main(argc, argv, &vt);
+}

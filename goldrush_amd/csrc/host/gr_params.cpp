@@ -1,0 +1,143 @@
+#include "gr_params.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+
+namespace gr {
+
+std::vector<std::string>
+make_seed_pattern(const std::string& preset, unsigned k, unsigned weight, unsigned h, bool log)
+{
+  // spaced_seeds.cpp:7-69.  Without a preset the left half is drawn with glibc
+  // srand(123)/rand()%2 until it has weight/2 ones (first position forced to 1);
+  // the right half is its mirror image.  Seed i = left + i zeros + right.
+  std::string left, right;
+  if (preset.empty()) {
+    srand(123);
+    if (log) {
+      std::cerr << "Designing base symmetrical spaced seed\nUsing:\nspan: " << k << "\nweight: " << weight << std::endl;
+    }
+    std::vector<unsigned> v(k / 2, 0);
+    if (!v.empty()) {
+      v[0] = 1;
+    }
+    size_t ones = 0;
+    while (ones != weight / 2) {
+      for (size_t i = 1; i < v.size(); ++i) {
+        v[i] = (unsigned)(rand() % 2);
+      }
+      ones = (size_t)std::count(v.begin(), v.end(), 1u);
+    }
+    for (unsigned b : v) {
+      left.push_back(b ? '1' : '0');
+    }
+    right.assign(left.rbegin(), left.rend());
+  } else {
+    if (log) {
+      std::cerr << "Using preset spaced seed\nwith:\n\tspan: " << preset.size() << "\n\tweight: " << std::count(preset.begin(), preset.end(), '1') << std::endl;
+    }
+    left = preset.substr(0, preset.size() / 2);
+    right = preset.substr(preset.size() / 2, preset.size() / 2);
+  }
+  std::vector<std::string> out;
+  for (unsigned i = 0; i < h; ++i) {
+    out.push_back(left + std::string(i, '0') + right);
+  }
+  return out;
+}
+
+uint64_t
+hash_universe(uint64_t weight, uint64_t genome_size, uint64_t hash_num)
+{
+  // goldrush_path.cpp:1113-1121: size_t * const float * size_t -> float math
+  const uint64_t pow4 = (uint64_t)std::pow(4.0, (double)weight);
+  const uint64_t base = std::min<uint64_t>(pow4, 2 * genome_size);
+  volatile float f = (float)base * 0.5f;
+  f = f * (float)hash_num;
+  return (uint64_t)f;
+}
+
+uint64_t
+calc_optimal_size(uint64_t entries, unsigned hash_num, double occupancy)
+{
+  const size_t approx = (size_t)(-(double)entries * (double)hash_num / std::log(1.0 - occupancy));
+  return approx + (64 - approx % 64);
+}
+
+void
+calc_phred_average(const char* qual, size_t n, uint32_t& avg, uint32_t& delta)
+{
+  double total = 0.0, first = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    const int q = (int)(qual[i] - 33);
+    total += std::pow(10.0, -q / 10.0);
+    if (i == n / 2 - 1) {
+      first = total;
+    }
+  }
+  double second = total - first;
+  second = second / (n * 0.5);
+  first = first / (n * 0.5);
+  avg = (uint32_t)(-10 * std::log10(total / n));
+  delta = (uint32_t)std::abs((int32_t)(-10 * std::log10(first)) - (int32_t)(-10 * std::log10(second)));
+}
+
+double
+sum_phred(const char* qual, size_t n)
+{
+  double total = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const int q = (int)(qual[i] - 33);
+    total += std::pow(10.0, -q / 10.0);
+  }
+  return total;
+}
+
+namespace {
+struct CodeTable
+{
+  uint8_t t[256];
+  CodeTable()
+  {
+    for (auto& x : t) {
+      x = 4;
+    }
+    t['A'] = t['a'] = 0;
+    t['C'] = t['c'] = 1;
+    t['G'] = t['g'] = 2;
+    t['T'] = t['t'] = 3;
+  }
+};
+const CodeTable kCode;
+} // namespace
+
+bool
+pack_2bit(const char* seq, size_t n, uint32_t* out)
+{
+  uint32_t bad = 0;
+  size_t w = 0;
+  size_t i = 0;
+  for (; i + 16 <= n; i += 16, ++w) {
+    uint32_t v = 0;
+    for (unsigned j = 0; j < 16; ++j) {
+      const uint32_t c = kCode.t[(unsigned char)seq[i + j]];
+      bad |= c;
+      v |= (c & 3u) << (2 * j);
+    }
+    out[w] = v;
+  }
+  if (i < n) {
+    uint32_t v = 0;
+    for (unsigned j = 0; i + j < n; ++j) {
+      const uint32_t c = kCode.t[(unsigned char)seq[i + j]];
+      bad |= c;
+      v |= (c & 3u) << (2 * j);
+    }
+    out[w] = v;
+  }
+  return (bad & 4u) == 0;
+}
+
+} // namespace gr

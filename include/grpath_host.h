@@ -1,0 +1,142 @@
+/*
+ * grpath_host.h — C ABI of libgrpath_host.so: the host side of GoldRush-Path
+ * that sits above the engine ABI (grpath.h).  It mirrors the reference host
+ * (the .cpp files under goldrush_path/) function by function so the parity tests can call the
+ * product's host logic directly; the `goldrush-path` CLI is built from the
+ * same sources.  Pure C++17 (no HIP): the engine is reached through the
+ * function table grp_engine_vt, whose members have exactly the signatures of
+ * grpath.h (opaque handles as void*).
+ */
+#ifndef GRPATH_HOST_H
+#define GRPATH_HOST_H
+
+#include "grpath.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- engine function table (filled with the grp_* symbols of grpath.h) ---- */
+typedef struct
+{
+  int (*create)(const grp_params*, void** ctx_out);
+  void (*destroy)(void* ctx);
+  const char* (*last_error)(const void* ctx);
+  int (*reads_upload)(void* ctx, const uint32_t* packed, const uint64_t* word_off, const uint32_t* len, uint32_t n_reads, void** out);
+  void (*reads_free)(void* reads);
+  int (*bv_insert)(void* ctx, const void* reads, uint32_t first, uint32_t count);
+  int (*finalize)(void* ctx, uint64_t* pop);
+  int (*query_tiles)(void* ctx, const void* reads, uint32_t first, uint32_t count, grp_tile_summary* tiles, grp_id_count* lists, uint64_t list_cap, uint64_t* list_used, grp_query_stats* stats);
+  int (*insert_tiles)(void* ctx, const void* reads, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t id);
+  int (*reset_ids)(void* ctx);
+  int (*sync)(void* ctx);
+} grp_engine_vt;
+
+/* ---- pure functions --------------------------------------------------------- */
+/* make_seed_pattern (spaced_seeds.cpp:7-69): h NUL-terminated strings, `stride`
+ * bytes apart, into out.  log_to_stderr != 0 prints the reference's messages. */
+int gr_make_seed_pattern(const char* preset, unsigned k, unsigned weight, unsigned h, char* out, size_t stride, int log_to_stderr);
+/* hash universe (goldrush_path.cpp:1113-1121), single-precision product */
+uint64_t gr_hash_universe(uint64_t weight, uint64_t genome_size, uint64_t hash_num);
+/* MIBloomFilter::calcOptimalSize (MIBloomFilter.hpp:94-101) */
+uint64_t gr_calc_optimal_size(uint64_t entries, unsigned hash_num, double occupancy);
+/* calc_phred_average / sum_phred (calc_phred_average.cpp:8-58) */
+void gr_calc_phred_average(const char* qual, size_t n, uint32_t* avg, uint32_t* delta);
+double gr_sum_phred(const char* qual, size_t n);
+/* 2-bit packing of one read into ceil(n/16) words; returns 0, or -1 if the read
+ * holds a non-ACGT character */
+int gr_pack_2bit(const char* seq, size_t n, uint32_t* out_words);
+
+/* ---- tile decision (goldrush_path.cpp:628-889, 195-233, 341-527, 960-1040) - */
+typedef struct
+{
+  uint32_t kind; /* 2 insert whole, 3 all assigned, 4 insert trimmed, 5 assigned */
+  uint32_t num_tiles;
+  uint32_t num_assigned;
+  uint32_t trim_start;
+  uint32_t trim_end;
+  uint32_t hits;
+  uint32_t misses;
+  uint32_t pad;
+} gr_read_decision;
+
+/* decision of one read from its tile summaries (list_off indexes `lists`) */
+void gr_decide_read(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t num_tiles, const grp_tile_summary* tiles, const grp_id_count* lists, gr_read_decision* out);
+/* the intermediate results, for the parity tests: ids/bools have num_tiles entries */
+size_t gr_smooth_tiles(size_t num_tiles, const grp_tile_summary* tiles, const grp_id_count* lists, size_t threshold, uint32_t* ids_out, uint8_t* bools_out);
+void gr_find_longest_stretch(const uint8_t* bools, size_t num_tiles, long* start, long* end);
+int gr_eval_flanks(long longest_start, long longest_end, const uint32_t* ids, size_t num_tiles, size_t* trim_start, size_t* trim_end);
+
+/* ---- order-exact classifier (process_read + silver_path_check) ------------- */
+typedef struct
+{
+  uint32_t struct_size;
+  uint32_t tile_length;   /* -t */
+  uint32_t block_size;    /* -b */
+  uint32_t threshold;     /* -x */
+  uint32_t unassigned_min; /* -u */
+  uint32_t assigned_max;  /* -a */
+  uint32_t kmer_size;     /* -k */
+  uint32_t hash_num;      /* -h */
+  uint64_t target_bases;  /* uint64(r * G), goldrush_path.cpp:1223 */
+  uint64_t max_paths;     /* -M */
+  int32_t silver_path;    /* --silver_path */
+  int32_t verbose;
+  uint32_t max_window;    /* speculation window cap (reads); 0 = default */
+  uint32_t world, rank;   /* ranks sharing each window (1, 0 = single GPU) */
+} gr_classifier_params;
+
+/* one committed read, in file order */
+typedef struct
+{
+  uint32_t read;        /* index in the batch */
+  gr_read_decision dec;
+  uint32_t first_id;    /* ids_inserted after its ++ (ID of the first block) */
+  uint64_t path;        /* curr_path the read was written to */
+} gr_commit;
+
+/* called for every classified read in order; returns sum_phred of what it wrote
+ * (only used for the verbose per-path log) */
+typedef double (*gr_commit_fn)(void* user, const gr_commit* c);
+/* called when a silver path rolls over (new output file) */
+typedef void (*gr_rollover_fn)(void* user, uint64_t new_path);
+/* all-gather of `bytes` per rank (rank r's block at recv + r*bytes); NULL for world==1 */
+typedef int (*gr_allgather_fn)(void* user, const void* send, uint64_t bytes, void* recv);
+
+typedef struct gr_classifier gr_classifier;
+
+int gr_classifier_create(const gr_classifier_params* p, const grp_engine_vt* vt, void* engine_ctx, gr_classifier** out);
+void gr_classifier_destroy(gr_classifier* c);
+void gr_classifier_set_callbacks(gr_classifier* c, gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user);
+/*
+ * Classify reads [0, n_reads) of an uploaded batch, in order, exactly as the
+ * reference's serial process_read loop would (goldrush_path.cpp:1229-1256):
+ * speculative windows are queried on the GPU, committed in order, and
+ * everything after a read that inserts is queried again.  skipped_before[i]
+ * (may be NULL) = number of non-eligible records (too short / filtered) that
+ * precede read i in the file since the previous eligible read — they only
+ * advance the read counter (:907-932); skipped_after likewise for the tail.
+ * Returns GRP_OK, or a negative grp_status.  *finished is set when the
+ * reference would have exit(0)'d (path M complete, :173-176).
+ */
+int gr_classifier_run(gr_classifier* c, void* reads, const uint32_t* lens, uint32_t n_reads, const uint32_t* skipped_before, uint32_t skipped_after, int* finished);
+const char* gr_classifier_error(const gr_classifier* c);
+
+typedef struct
+{
+  uint64_t valid_reads, total_tiles, assigned_tiles, unassigned_tiles, queries, hits, misses, num_reads_in_path;
+  double phred_sum_in_path;
+  uint64_t inserted_bases, curr_path;
+  uint32_t id, ids_inserted;
+  /* speculation statistics */
+  uint64_t windows, reads_queried, reads_committed, inserts;
+} gr_classifier_state;
+void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
+
+/* ---- the CLI as a function (main of goldrush_path.cpp:1096-1275) ----------- */
+int gr_path_main(int argc, char** argv, const grp_engine_vt* vt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
