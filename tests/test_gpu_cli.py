@@ -1,0 +1,130 @@
+"""GPU end-to-end: the goldrush-path CLI (C++ host + HIP engine) must write files
+byte-identical to the oracle CLI (CPU restatement of the reference) on the same
+seeded FASTQ: silver paths (process #1 of bin/goldrush:253-260) and the golden
+path (process #2, bin/goldrush:240-248)."""
+import filecmp
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk_fastq(path, genome_len, n_reads, mean_len, min_len, seed, noisy_qual=False, lower=False, with_n=0, short=0):
+    from goldrush_amd import synth
+
+    g = synth.random_genome(genome_len, seed)
+    reads = synth.make_reads(g, n_reads, mean_len=mean_len, min_len=min_len, seed=seed + 1, noisy_qual=noisy_qual)
+    rng = np.random.default_rng(seed + 2)
+    out = []
+    for i, (rid, seq, qual) in enumerate(reads):
+        if lower and i % 7 == 0:
+            seq = seq.lower()
+        if with_n and i % with_n == 3:
+            seq = seq[:100] + b"N" + seq[101:]
+        if short and i % short == 1:
+            seq, qual = seq[:800], qual[:800]
+        if i % 11 == 5:  # low quality second half -> phred delta filter
+            h = len(qual) // 2
+            qual = qual[:h] + b"#" * (len(qual) - h)
+        out.append((rid + (b" some comment" if i % 5 == 0 else b""), seq, qual))
+    synth.write_fastq(path, out)
+    return out
+
+
+def _run_both(oracle, host, tmp_path, args, tag):
+    d_o = tmp_path / f"{tag}_o"
+    d_p = tmp_path / f"{tag}_p"
+    d_o.mkdir()
+    d_p.mkdir()
+    ro = oracle.run_cli(args + ["-p", str(d_o / "out")], timeout=900)
+    rp = subprocess.run([host.CLI_PATH] + args + ["-p", str(d_p / "out")], capture_output=True, text=True, timeout=900)
+    assert rp.returncode == ro.returncode, (rp.returncode, ro.returncode, rp.stderr[-2000:])
+    fo = sorted(os.path.basename(p) for p in glob.glob(str(d_o / "*")))
+    fp = sorted(os.path.basename(p) for p in glob.glob(str(d_p / "*")))
+    assert fo == fp, (fo, fp)
+    for f in fo:
+        assert filecmp.cmp(d_o / f, d_p / f, shallow=False), f"{f} differs"
+    return ro, rp, d_o, d_p, fo
+
+
+def _verbose_counters(stderr):
+    keep = ("Visited", "Saw:", "Assigned:", "Unassigned:", "Total queries", "Total hits", "Total misses", "Num reads", "Average Phred",
+            "m_filterSize", "expected hash space", "minimum average phred", "num_", "Total reads skipped")
+    return [l for l in stderr.splitlines() if l.strip().startswith(keep)]
+
+
+@pytest.fixture(scope="module")
+def host(native):
+    from goldrush_amd import host as h
+
+    assert os.path.exists(h.CLI_PATH), "goldrush-path binary missing: run __graft_entry__.build()"
+    return h
+
+
+def test_silver_then_golden_byte_identical(oracle, host, tmp_path):
+    fq = str(tmp_path / "reads.fq")
+    # small genome, but the filter sized (-H) like a real run so that random
+    # collisions stay below the -x threshold; tiles of 500, ID blocks of 4 tiles
+    _mk_fastq(fq, 300_000, 900, 6000, 4000, seed=5, lower=True, with_n=50, short=40)
+    common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j8", "-d5", "-x10", "-s1011011110110111101101", "-g300000", "-b4", "-H4000000"]
+    silver = common + ["-P0", "-r0.9", "--silver_path", "-M3", "-m3500", "-i", fq, "--verbose"]
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, silver, "silver")
+    assert files == ["out_1.fq", "out_2.fq", "out_3.fq"]
+    assert all(os.path.getsize(d_p / f) > 0 for f in files)
+    text = b"".join(open(d_p / f, "rb").read() for f in files)
+    assert text.count(b"_untrimmed\n") > 20 and text.count(b"_trimmed\n") > 20  # both insert kinds exercised
+    assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+    # process #2: cat the silver paths, golden-path mode, -m 0 (bin/goldrush:246-251)
+    allfq = str(tmp_path / "all.fq")
+    with open(allfq, "wb") as out:
+        for f in files:
+            out.write(open(d_p / f, "rb").read())
+    golden = common + ["-P0", "-m0", "-i", allfq, "--verbose"]
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, golden, "golden")
+    assert files == ["out.fa"] and os.path.getsize(d_p / "out.fa") > 0
+    assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+
+
+def test_designed_seed_h5_noisy_quals(oracle, host, tmp_path):
+    """no -s preset (glibc-rand seed design), h=5, explicit -P, noisy qualities,
+    fewer paths than requested (WARNING branch, normal end of file)."""
+    fq = str(tmp_path / "reads.fq")
+    _mk_fastq(fq, 150_000, 160, 8000, 6000, seed=9, noisy_qual=True)
+    args = ["-k20", "-w14", "-t500", "-u5", "-a1", "-o0.1", "-h5", "-j2", "-P12", "-d5", "-x8", "-g150000", "-b4", "-r0.9", "--silver_path", "-M5", "-m5000",
+            "-i", fq, "--verbose"]
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "h5")
+    assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+    assert ("WARNING: Expected" in rp.stderr) == ("WARNING: Expected" in ro.stderr)
+
+
+def test_cli_error_paths(oracle, host, tmp_path):
+    fa = tmp_path / "x.fa"
+    fa.write_text(">r1\nACGT\n")
+    base = ["-k22", "-w16", "-s1011011110110111101101", "-g1e5", "-P10"]
+    for extra, code in [(["-i", str(fa)], 1),            # not FASTQ (goldrush_path.cpp:247-250)
+                        ([], None)]:
+        args = base + extra + ["-p", str(tmp_path / "o")]
+        rp = subprocess.run([host.CLI_PATH] + args, capture_output=True, text=True, timeout=300)
+        ro = oracle.run_cli(args, timeout=300)
+        if code is not None:
+            assert rp.returncode == ro.returncode == code
+    # flag validation happens before any GPU work (opt.cpp:176-216)
+    for bad in (["-w16", "-g1e5"], ["-k22", "-g1e5"], ["-k22", "-w16"], ["-k22", "-w16", "-g1e5", "-s101"], ["-k3", "-w3", "-g1e5", "-s101"]):
+        rp = subprocess.run([host.CLI_PATH] + bad, capture_output=True, text=True, timeout=60)
+        ro = oracle.run_cli(bad, timeout=60)
+        assert rp.returncode == ro.returncode == 1
+        assert rp.stdout == ro.stdout  # usage text
+    rp = subprocess.run([host.CLI_PATH, "--help"], capture_output=True, text=True, timeout=60)
+    ro = oracle.run_cli(["--help"], timeout=60)
+    assert rp.returncode == ro.returncode == 0 and rp.stdout == ro.stdout
+    # all reads filtered -> exit(1) (goldrush_path.cpp:327-334)
+    fq = str(tmp_path / "short.fq")
+    _mk_fastq(fq, 50_000, 20, 3000, 2000, seed=3)
+    args = base + ["-i", fq, "-m20000", "-p", str(tmp_path / "o2")]
+    rp = subprocess.run([host.CLI_PATH] + args, capture_output=True, text=True, timeout=300)
+    ro = oracle.run_cli(args, timeout=300)
+    assert rp.returncode == ro.returncode == 1
