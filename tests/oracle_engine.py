@@ -1,0 +1,138 @@
+"""Test infrastructure: an engine function table (include/grpath_host.h,
+grp_engine_vt) backed by the CPU oracle, so the product's order-exact
+classifier can be exercised without a GPU (CPU tests, gloo world_size-2)."""
+import ctypes as C
+
+import numpy as np
+
+from goldrush_amd import host, native
+
+
+class OracleEngine:
+    def __init__(self, orc, m, seeds, tile, k, reads):
+        self.orc = orc
+        self.oseeds = orc.Seeds(seeds)
+        self.mf = orc.MiBF(m, self.oseeds, tile, k)
+        self.tile, self.k = tile, k
+        self.reads = reads
+        self.n_queries = 0
+        for s in reads:
+            self.mf.bv_insert_read(s)
+        self.mf.finalize()
+        self._keep = []
+        self.vt = self._make_vt()
+
+    def _make_vt(self):
+        vt = host.grp_engine_vt()
+        types = dict(host.VT_TYPES)
+
+        def query_tiles(ctx, reads, first, count, tiles_p, lists_p, cap, used_p, stats_p):
+            self.n_queries += count
+            res = []
+            for r in range(first, first + count):
+                res.extend(self.mf.query_read(self.reads[r]))
+            nt = len(res)
+            need = sum(len(x[2]) for x in res)
+            used_p[0] = need
+            if need > cap:
+                return native.GRP_ERR_NOMEM
+            tiles = np.ctypeslib.as_array(C.cast(tiles_p, C.POINTER(C.c_uint32)), shape=(max(nt, 1) * 6,)).view(native.tile_summary_dtype)
+            lists = np.ctypeslib.as_array(C.cast(lists_p, C.POINTER(C.c_uint32)), shape=(max(cap, 1) * 2,)).view(native.id_count_dtype)
+            off = 0
+            for i, (tid, tc, lst, ctr) in enumerate(res):
+                lst = sorted(((int(a), int(b)) for a, b in lst), key=lambda t: (-t[1], t[0]))
+                tiles[i] = (tid, tc, off, len(lst), ctr[1], ctr[2])
+                for j, (a, b) in enumerate(lst):
+                    lists[off + j] = (a, b)
+                off += len(lst)
+            return 0
+
+        def insert_tiles(ctx, reads, ri, ts, te, id_):
+            self.mf.insert_read_tiles(self.reads[ri], ts, te, id_)
+            return 0
+
+        def reset_ids(ctx):
+            self.mf.reset_ids()
+            return 0
+
+        def sync(ctx):
+            return 0
+
+        def last_error(ctx):
+            return b"oracle engine"
+
+        impl = {"query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync, "last_error": last_error}
+        for name, ftype in host.VT_TYPES:
+            if name in impl:
+                cb = ftype(impl[name])
+                self._keep.append(cb)
+                setattr(vt, name, cb)
+        return vt
+
+
+def serial_reference(orc, m, seeds, tile, k, reads, block=10, threshold=10, u=5, a=1, silver=False, target_bases=0, max_paths=1):
+    """The reference's serial loop (process_read, goldrush_path.cpp:892-1094)
+    stated with oracle primitives; returns the commit tuples the classifier
+    should produce: (read, kind, num_tiles, num_assigned, trim_start, trim_end, first_id, path)."""
+    oseeds = orc.Seeds(seeds)
+    mf = orc.MiBF(m, oseeds, tile, k)
+    for s in reads:
+        mf.bv_insert_read(s)
+    mf.finalize()
+    out = []
+    ids_inserted = 0
+    inserted_bases = 0
+    path = 1
+    finished = False
+
+    def check():
+        nonlocal path, inserted_bases, ids_inserted, finished
+        if target_bases < inserted_bases:
+            path += 1
+            if max_paths < path:
+                finished = True
+                return
+            inserted_bases = 0
+            mf.reset_ids()
+            ids_inserted = 0
+
+    for ri, seq in enumerate(reads):
+        res = mf.query_read(seq)
+        n = len(res)
+        o_ids, o_b, na = orc.smooth_tiles([r[0] for r in res], [r[2] for r in res], threshold)
+        wpath = path
+        if n - na >= u and na <= a:
+            ids_inserted += 1
+            first = ids_inserted
+            for bs in range(0, n, block):
+                mf.insert_read_tiles(seq, bs, min(bs + block, n), ids_inserted + bs // block)
+            ids_inserted += len(seq) // (tile * block)
+            inserted_bases += len(seq)
+            out.append((ri, 2, n, na, 0, 0, first, wpath))
+            if silver:
+                check()
+        elif na == n:
+            out.append((ri, 3, n, na, 0, 0, 0, wpath))
+        else:
+            ls, le = orc.find_longest_stretch(o_b)
+            good, ts, te = orc.eval_flanks(ls, le, o_ids[:n])
+            if good:
+                ids_inserted += 1
+                first = ids_inserted
+                bs = ts
+                while bs <= te:
+                    be = min(bs + block - 1, te)
+                    mf.insert_read_tiles(seq, bs, be + 1, ids_inserted + (bs - ts + 1) // block)
+                    bs += block
+                ids_inserted += (te - ts) // block
+                off = ts * tile
+                n_out = len(seq) - off if te == n - 1 else min(len(seq) - off, (te - ts + 1) * tile)
+                inserted_bases += n_out
+                out.append((ri, 4, n, na, ts, te, first, wpath))
+                if silver:
+                    check()
+            else:
+                out.append((ri, 5, n, na, 0, 0, 0, wpath))
+        if finished:
+            break
+    return out, mf

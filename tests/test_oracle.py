@@ -1,0 +1,163 @@
+"""CPU: the oracle (oracle/, CPU restatement of the reference) against its
+committed regression vectors and the algebraic properties of the published
+ntHash2 spaced-seed definition.
+
+PARITY UNPINNED: the reference ships no golden vectors for this path and cannot
+be built here (btllib, sdsl-lite, sparsehash absent), see DESIGN.md "Oracle"."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import SEED22, default_seeds, random_reads
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return json.load(open(os.path.join(GOLD, "fixtures.json")))
+
+
+def test_fixture_vectors(oracle, fx):
+    lib = oracle.load()
+    for key, exp in fx["seeds"].items():
+        p, k, w, h = key.split("|")
+        assert oracle.make_seed_pattern(p, int(k), int(w), int(h)) == exp
+    for w, g, h, occ, u, m in fx["sizing"]:
+        assert lib.orc_hash_universe(w, g, h) == u
+        assert lib.orc_calc_optimal_size(u, 1, occ) == m
+    for q, exp in fx["phred"]:
+        assert list(oracle.calc_phred_average(q.encode())) == exp
+    sd = oracle.Seeds(default_seeds(3))
+    seq = fx["hash_seq"].encode()
+    for t, exp in enumerate(fx["hash_tile40"]):
+        assert [int(v) for v in sd.tile_hashes(seq, 40, 22, t)] == exp
+    for x, d, y in fx["srol"]:
+        assert lib.orc_srol(int(x, 16), d) == int(y, 16)
+
+
+def test_fixture_end_to_end(oracle, fx, tmp_path):
+    p = oracle.Path(fx["tiny_args"] + ["-i", os.path.join(GOLD, "tiny.fq"), "-p", str(tmp_path / "out")])
+    assert p.filter_size() == fx["tiny_filter_size"]
+    assert [list(map(int, d)) for d in p.run_all()] == fx["tiny_decisions"]
+    p.close()
+    for name, sha in fx["tiny_outputs"].items():
+        assert hashlib.sha256(open(tmp_path / name, "rb").read()).hexdigest() == sha
+    # the CLI writes the same files
+    r = oracle.run_cli(fx["tiny_args"] + ["-i", os.path.join(GOLD, "tiny.fq"), "-p", str(tmp_path / "cli")])
+    assert r.returncode == 0
+    for name, sha in fx["tiny_outputs"].items():
+        assert hashlib.sha256(open(tmp_path / name.replace("out", "cli"), "rb").read()).hexdigest() == sha
+
+
+def test_split_rotate(oracle):
+    lib = oracle.load()
+    rng = np.random.default_rng(1)
+    for x in [0, 1, 1 << 32, 1 << 33, 1 << 63, 0xFFFFFFFFFFFFFFFF] + [int(v) for v in rng.integers(0, 2**63, size=50)]:
+        y = x
+        for d in range(0, 70):
+            assert lib.orc_srol(x, d) == y, (hex(x), d)
+            assert lib.orc_sror1(lib.orc_srol1(y)) == y
+            y = lib.orc_srol1(y)
+        # the low 33 and the high 31 bits never mix
+        assert bin(lib.orc_srol(x, 17) & 0x1FFFFFFFF).count("1") == bin(x & 0x1FFFFFFFF).count("1")
+    assert lib.orc_srol(0x100000000, 1) == 1 and lib.orc_srol(1 << 63, 1) == 1 << 33
+
+
+def _revcomp(s):
+    return s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+
+
+def test_hash_properties(oracle):
+    lib = oracle.load()
+    seeds = default_seeds(3)
+    sd = oracle.Seeds(seeds)
+    seq = random_reads(1, 400, 400, seed=3)[0]
+    hv = sd.multi_hash(seq).reshape(-1, 3)
+    n = len(seq)
+    assert hv.shape[0] == n - 22 + 1
+    # canonical: palindromic seeds => hash(window) == hash(revcomp(window))
+    rc = _revcomp(seq)
+    hr = sd.multi_hash(rc).reshape(-1, 3)
+    for s, span in enumerate((22, 23, 24)):
+        nv = n - span + 1
+        assert np.array_equal(hv[:nv, s], hr[:nv, s][::-1])
+    # stale frames: a seed that cannot roll keeps its last valid value
+    assert hv[-1, 1] == hv[-2, 1] and hv[-1, 2] == hv[-3, 2] and hv[-2, 2] == hv[-3, 2]
+    assert hv[-1, 0] != hv[-2, 0]
+    # don't-care positions do not matter, care positions do
+    one = oracle.Seeds([seeds[1]])
+    base = one.multi_hash(seq[:23])[0]
+    for q, c in enumerate(seeds[1]):
+        mut = bytearray(seq[:23])
+        mut[q] = ord("A") if mut[q] != ord("A") else ord("C")
+        assert (one.multi_hash(bytes(mut))[0] == base) == (c == "0"), q
+    # lower case hashes like upper case
+    assert np.array_equal(sd.multi_hash(seq.lower()), sd.multi_hash(seq))
+    # contiguous seed: the classic ntHash rolling recurrence holds
+    k = 16
+    full = oracle.Seeds(["1" * k])
+    h = full.multi_hash(seq)
+    def fwd_rev(p):
+        f = r = 0
+        for q in range(k):
+            f ^= lib.orc_srol(lib.orc_base_seed(seq[p + q]), k - 1 - q)
+            r ^= lib.orc_srol(lib.orc_base_seed(_revcomp(seq[p + q:p + q + 1])[0]), q)
+        return f, r
+    f, r = fwd_rev(0)
+    for p in range(1, 60):
+        f = lib.orc_srol1(f) ^ lib.orc_srol(lib.orc_base_seed(seq[p - 1]), k) ^ lib.orc_base_seed(seq[p + k - 1])
+        comp_out = _revcomp(seq[p - 1:p])[0]
+        comp_in = _revcomp(seq[p + k - 1:p + k])[0]
+        r = lib.orc_sror1(r ^ lib.orc_base_seed(comp_out) ^ lib.orc_srol(lib.orc_base_seed(comp_in), k))
+        assert (f + r) & 0xFFFFFFFFFFFFFFFF == int(h[p]), p
+
+
+def test_mibf_semantics(oracle):
+    sd = oracle.Seeds(default_seeds(3))
+    m = 1 << 16
+    mf = oracle.MiBF(m, sd, 200, 22)
+    reads = random_reads(3, 700, 900, seed=4)
+    for r in reads:
+        mf.bv_insert_read(r)
+    pop = mf.finalize()
+    bits = mf.bits()
+    assert pop == sum(bin(int(w)).count("1") for w in bits)
+    cum = 0
+    for pos in range(0, m, 997):
+        assert mf.rank(pos) == sum(bin(int(w)).count("1") for w in bits[: pos // 64]) + bin(int(bits[pos // 64]) & ((1 << (pos % 64)) - 1)).count("1")
+    # insert: one dedup scope per call, reservoir rule (MIBFConstructSupport.hpp:274-282)
+    mf.insert_read_tiles(reads[0], 0, 3, 5)
+    c1 = mf.counts().copy()
+    assert set(np.unique(c1)) <= {0, 1} and set(np.unique(mf.ids())) <= {0, 5}
+    mf.insert_read_tiles(reads[0], 0, 3, 9)   # same ranks again: count 2, id replaced iff (rank^9) % 2 == 1
+    ids, cnt = mf.ids(), mf.counts()
+    touched = np.flatnonzero(c1)
+    assert np.all(cnt[touched] == 2)
+    exp = np.where(((touched.astype(np.uint64) ^ np.uint64(9)) & np.uint64(0xFFFFFFFF)) % 2 == 1, 9, 5)
+    assert np.array_equal(ids[touched], exp)
+    mf.reset_ids()
+    assert not mf.ids().any() and not mf.counts().any()
+
+
+def test_path_equals_python_serial_loop(oracle, tmp_path):
+    """Two independent statements inside the test infrastructure agree: orc_path
+    (C) and the Python serial loop used by the classifier tests."""
+    from goldrush_amd import synth
+    from oracle_engine import serial_reference
+
+    g = synth.random_genome(100_000, 3)
+    reads = synth.make_reads(g, 45, mean_len=5000, min_len=3500, seed=4, max_len=8000)
+    fq = str(tmp_path / "r.fq")
+    synth.write_fastq(fq, reads)
+    args = ["-k22", "-w16", "-t500", "-u5", "-a1", "-h3", "-j2", "-P10", "-d50", "-x10", "-s" + SEED22, "-g100000", "-b4", "-H1500000", "-r0.9", "--silver_path", "-M2", "-m3000",
+            "-i", fq, "-p", str(tmp_path / "o")]
+    p = oracle.Path(args)
+    got = p.run_all()
+    m = p.filter_size()
+    p.close()
+    exp, _ = serial_reference(oracle, m, default_seeds(3), 500, 22, [r[1] for r in reads], block=4, silver=True, target_bases=90_000, max_paths=2)
+    assert [(d[0], d[1], d[2], d[3], d[4], d[5], d[6]) for d in got] == [(e[1], e[2], e[3], e[4], e[5], e[6], e[7]) for e in exp]
