@@ -10,6 +10,7 @@ import ctypes as C
 import os
 import subprocess
 import sys
+import weakref
 
 import numpy as np
 
@@ -180,11 +181,14 @@ class ReadBatch:
         self._keep = keep
         p = engine.lib.grp_reads_tile0(handle)
         self.tile0 = np.ctypeslib.as_array(p, shape=(n_reads + 1,)).copy()
+        engine._batches.add(self)
 
     def free(self):
-        if self._h:
+        # a batch must not outlive its engine (grp_reads_free touches the ctx)
+        if self._h and self.engine._h:
             self.engine.lib.grp_reads_free(self._h)
-            self._h = None
+        self._h = None
+        self.engine._batches.discard(self)
 
     def __del__(self):
         try:
@@ -207,6 +211,7 @@ class Engine:
             raise GrpError(rc, (self.lib.grp_last_error(None) or b"").decode())
         self._h = out
         self.pop = 0
+        self._batches = weakref.WeakSet()
 
     def _check(self, rc):
         if rc != GRP_OK:
@@ -214,6 +219,8 @@ class Engine:
 
     def close(self):
         if self._h:
+            for b in list(self._batches):
+                b.free()
             self.lib.grp_destroy(self._h)
             self._h = None
 
