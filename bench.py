@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py — GoldRush-Path hot path (spaced-seed ntHash + miBF query) on MI355X.
+"""bench.py — GoldRush-Path hot path (spaced-seed ntHash + miBF query / insert) on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
 driver launches one rank per GPU with torch.distributed.run.  Rank 0 prints ONE
@@ -7,20 +7,30 @@ JSON line.
 
 Workload (BASELINE.json configs[1], "C1"): 1 M synthetic ONT-like reads, mean
 25 kb, G = 100e6, k=22 w=16 h=3 tile=1000, o=0.1.  The reads are generated on the
-GPU (grp_synth_reads), so all inputs are resident in HBM before the timed region.
-A step = one pass of the hot path (hash every tile frame, probe the miBF, per-tile
-ID vote) over one batch of `--batch` reads taken in stream order.
+GPU (grp_synth_reads): all inputs are resident in HBM before the timed region.
+
+Untimed setup (reported under "aux"): bit-vector fill of all reads + rank build
+(phase 1 of goldrush-path, goldrush_path.cpp:1199-1205).
+
+A step = the order-exact classification of the next `--batch` x N reads of the
+stream (phase 2, goldrush_path.cpp:1229-1256, golden-path mode): every tile frame
+is hashed and probed (hash + miBF query), the read decisions are taken in file
+order and the accepted reads are inserted into the miBF *before* any later read
+is decided — bit-identical to the reference's serial loop, with speculative GPU
+windows in between (goldrush_amd/csrc/host/gr_classifier.cpp).  Warm-up steps
+are the first W batches of the same stream (the insert-heavy start of the path).
 
 metric  : reads/s through hash + miBF query (whole job, all ranks)
 roofline: the query kernel, ALGORITHMIC bytes = 128 B per probe (two 64-B HBM
           sectors: bit+rank block, then ID), probes = frames x h; duration from
           HIP events recorded around every launch on the library's own stream.
-cpu_baseline: the CPU oracle (restatement of the reference, OpenMP) on a bounded
-          sample of the same workload, rank 0, N=1 only.
+cpu_baseline: the CPU oracle (restatement of the reference) on a bounded sample
+          of the same workload, rank 0, N=1 only.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -35,64 +45,58 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 PRESET = "1011011110110111101101"  # bin/goldrush:70
 
 
-def filter_bits(G: int, w: int, h: int, occ: float) -> int:
-    """goldrush_path.cpp:1113-1121 (float product) + MIBloomFilter.hpp:94-101."""
-    base = min(4 ** w, 2 * G)
-    U = int(np.float32(np.float32(base) * np.float32(0.5)) * np.float32(h))
-    n = int(-float(U) / np.log(1.0 - occ))
-    return n + (64 - n % 64)
-
-
-def cpu_baseline(dr, n_sample: int, m: int, seeds, k: int, tile: int, h: int):
-    """Oracle (CPU restatement, OpenMP over tiles like the reference) timed on a
-    bounded sample: fill with the sample, insert every 3rd read as IDs, then time
-    hash + query of the sample reads."""
+def cpu_baseline(dr, n_sample: int, m: int, seeds, k: int, tile: int, budget_s: float = 25.0):
+    """The oracle's own serial loop (orc_path_process_read: hash, query, decide,
+    insert; OpenMP over tiles like the reference) over the first reads of the
+    same synthetic set, same filter size; reads/s of its classification phase."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc  # test infrastructure: used here only as the timed CPU baseline
+    from goldrush_amd import synth
 
     orc.build()
     reads = dr.download(0, n_sample)
-    oseeds = orc.Seeds(seeds)
-    mf = orc.MiBF(m, oseeds, tile, k)
-    for s in reads:
-        mf.bv_insert_read(s)
-    mf.finalize()
-    idn = 0
-    for i in range(0, n_sample, 3):
-        nt = len(reads[i]) // tile
-        idn += 1
-        for bs in range(0, nt, 10):
-            mf.insert_read_tiles(reads[i], bs, min(bs + 10, nt), idn + bs // 10)
-        idn += nt // 10
-    lib = orc.load()
-    import ctypes as C
+    tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"grp_bench_cpu_{os.getpid()}")
+    os.makedirs(tmp, exist_ok=True)
+    fq = os.path.join(tmp, "sample.fq")
+    synth.write_fastq(fq, [(b"r%d" % i, s, b"5" * len(s)) for i, s in enumerate(reads)])
+    from goldrush_amd import host
 
+    cores = int(host.load().gr_effective_cpus())  # affinity mask and cgroup quota
+    args = ["-k", str(k), "-w16", "-t", str(tile), "-h", str(len(seeds)), "-s", PRESET, "-g", "100000000", "-P10", "-d50", "-m0",
+            "-j", str(cores), "-i", fq, "-p", os.path.join(tmp, "o")]
+    p = orc.Path(args)
+    assert p.ok and p.filter_size() == m
     t0 = time.time()
     done = 0
-    for s in reads:
-        # read_hashing.cpp:29-54 + calc_num_assigned_tiles loop 1, tile by tile
-        for t in range(len(s) // tile):
-            hv = oseeds.tile_hashes(s, tile, k, t)
-            mf.query_tile(hv)
+    for i in range(p.n_reads):
+        p.process(i)
         done += 1
-        if time.time() - t0 > 25:
+        if time.time() - t0 > budget_s:
             break
     dt = time.time() - t0
-    return {"value": done / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": f"{done} of the first {n_sample} reads of the same synthetic set, same m; serial oracle (hash+query per tile)"}
+    fill_s, _ = p.timers()
+    p.close()
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    os.rmdir(tmp)
+    return {"value": done / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"first {done} reads of the same synthetic stream (filter filled with {n_sample} reads, same m={m}); oracle process_read loop "
+                      f"(hash + query + decide + insert), OpenMP over tiles, {cores} threads",
+            "fill_reads_per_s": n_sample / fill_s if fill_s > 0 else None}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--genome", type=float, default=100e6)
-    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--batch", type=int, default=8192, help="reads per GPU per step")
     ap.add_argument("--h", type=int, default=3)
-    ap.add_argument("--populate", type=int, default=4000, help="reads whose tiles are inserted as IDs before the timed region (~1x coverage)")
+    ap.add_argument("--max-window", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace", action="store_true", help="per-step timing / speculation statistics on stderr")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,50 +111,65 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from goldrush_amd import native
+    from goldrush_amd import host, native
 
-    G, k, w, tile, h = int(a.genome), 22, 16, 1000, a.h
-    seeds = [PRESET[:11] + "0" * i + PRESET[11:] for i in range(h)]
-    m = filter_bits(G, w, h, 0.1)
+    G, k, w, tile, h, block = int(a.genome), 22, 16, 1000, a.h, 10
+    hl = host.load()
+    seeds = host.make_seed_pattern(PRESET, k, w, h)
+    m = hl.gr_calc_optimal_size(hl.gr_hash_universe(w, G, h), 1, 0.1)
 
-    # ---- untimed setup: inputs resident in HBM ------------------------------
+    # ---- untimed setup: inputs resident in HBM, phase 1 -------------------------
     t0 = time.time()
     dr = native.synth_reads(a.reads, G)
     eng = native.Engine(k, h, tile, m, seeds, device=local_rank)
     rb = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
     t_synth = time.time() - t0
     t0 = time.time()
-    eng.bv_insert(rb)
+    eng.bv_insert(rb)  # every rank fills its own replica (reads are on every GPU)
     eng.sync()
     t_fill = time.time() - t0
     fill_stats = eng.kernel_stats()["fill"]
     pop = eng.finalize()
-    idn = 0
-    for r in range(min(a.populate, a.reads)):
-        nt = int(dr.lens[r]) // tile
-        idn += 1
-        for bs in range(0, nt, 10):
-            eng.insert_tiles(rb, r, bs, min(bs + 10, nt), idn + bs // 10)
-        idn += nt // 10
-    eng.sync()
 
-    # every rank owns a disjoint slice of each step's batch (reads shard; replicated miBF)
-    per_rank = a.batch
-    n_avail = a.reads - a.populate - per_rank * world
-    if n_avail <= 0:
-        raise SystemExit("--reads too small for --batch/--populate")
+    # ---- phase 2: order-exact classification, windows sharded over the ranks ----
+    allgather = None
+    if world > 1:
+        def allgather(user, send, nbytes, recv):  # noqa: E306
+            src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+            t_in = torch.from_numpy(src).cuda()
+            t_out = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
+            dist.all_gather_into_tensor(t_out, t_in)
+            dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+            dst[:] = t_out.cpu().numpy()
+            return 0
+
+    cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
+                          target_bases=int(0.9 * G), max_paths=1, silver_path=False, max_window=a.max_window, world=world, rank=rank,
+                          allgather=allgather, record=False)
+    per_step = a.batch * world
+    n_steps_avail = a.reads // per_step
+    if n_steps_avail < 1:
+        raise SystemExit("--reads too small for --batch")
+    lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
 
     def step(i: int):
-        first = a.populate + ((i * world + rank) * per_rank) % n_avail
-        return eng.query_tiles(rb, first, per_rank)
+        # the stream wraps around once exhausted (all of it is then on the path)
+        ts = time.perf_counter()
+        s0 = cls.state() if a.trace else None
+        cls.run_range(rb._h, lens, (i % n_steps_avail) * per_step, per_step)
+        if a.trace and rank == 0:
+            s1 = cls.state()
+            sys.stderr.write("step %d: %.1f ms windows=%d queried=%d inserts=%d\n" % (
+                i, (time.perf_counter() - ts) * 1e3, s1["windows"] - s0["windows"], s1["reads_queried"] - s0["reads_queried"], s1["inserts"] - s0["inserts"]))
 
     for i in range(a.warmup):
         step(i)
+    eng.sync()
     eng.reset_kernel_stats()
+    st0 = cls.state()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    eng.sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(a.warmup + i)
@@ -163,13 +182,15 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    ks = eng.kernel_stats()["query"]
+    ks = eng.kernel_stats()
+    st1 = cls.state()
 
     if rank == 0:
-        reads_done = a.steps * per_rank * world
-        avg_ms = ks["ms"] / max(ks["launches"], 1)
-        probes_per_launch = ks["units"] / max(ks["launches"], 1)
-        achieved = probes_per_launch * 128 / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kq = ks["query"]
+        reads_done = a.steps * per_step
+        avg_ms = kq["ms"] / max(kq["launches"], 1)
+        probes_per_launch = kq["units"] / max(kq["launches"], 1)
+        achieved = kq["units"] * 128 / (kq["ms"] * 1e-3) / 1e9 if kq["ms"] > 0 else 0.0
         out = {
             "metric": "reads/s through GoldRush-Path (hash + miBF query)",
             "value": reads_done / dt,
@@ -183,18 +204,19 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "C1: 1M synthetic ONT reads, mean 25 kb, G=100e6, k=22 w=16 h=%d tile=1000 o=0.1" % h,
-                       "reads": a.reads, "batch_reads_per_gpu": per_rank, "filter_bits": m, "pop": pop,
-                       "mode": "query batches against a miBF populated with %d inserted reads" % a.populate,
-                       "parallelism": "reads sharded over %d GPU(s), replicated miBF" % world},
+            "config": {"workload": "C1: 1M synthetic ONT reads, mean 25 kb, G=100e6, k=22 w=16 h=%d tile=1000 o=0.1, golden-path mode, order-exact" % h,
+                       "reads": a.reads, "batch_reads_per_gpu": a.batch, "filter_bits": m, "pop": pop,
+                       "parallelism": "each speculative window sharded over %d GPU(s), replicated miBF, decisions all-gathered" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "k_query", "avg_launch_ms": avg_ms, "probes_per_launch": probes_per_launch,
-                         "bytes_per_probe": 128},
-            "aux": {"fill_reads_per_s": a.reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] / t_fill / 1e9,
-                    "fill_s": t_fill, "synth_s": t_synth, "query_kernel_reads_per_s": a.steps * per_rank / (ks["ms"] * 1e-3) if ks["ms"] else None},
+                         "traffic": None, "kernel": "k_query", "launches": kq["launches"], "avg_launch_ms": avg_ms,
+                         "probes_per_launch": probes_per_launch, "bytes_per_probe": 128},
+            "aux": {"fill_reads_per_s": a.reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] / t_fill / 1e9, "fill_s": t_fill, "synth_s": t_synth,
+                    "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts")},
+                    "query_kernel_s": kq["ms"] * 1e-3, "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
+                    "wall_s": dt},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dr, 48, m, seeds, k, tile, h)
+            out["cpu_baseline"] = cpu_baseline(dr, 96, m, seeds, k, tile)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -57,8 +57,11 @@ struct grp_ctx
   uint64_t d_tiles_cap = 0;
   grp_id_count* d_lists = nullptr;
   uint64_t d_lists_cap = 0;
-  uint64_t* d_qctr = nullptr; // [0..2] stats, [3] list arena cursor
+  uint64_t* d_qctr = nullptr; // [3] list arena cursor (kept zero between calls)
   uint64_t* h_qctr = nullptr; // pinned
+  grp_tile_summary* h_tiles = nullptr; // pinned staging
+  uint64_t h_tiles_cap = 0;
+  grp_id_count* h_lists = nullptr; // pinned staging of the list prefix
   // insert scratch
   unsigned long long* d_dedup = nullptr;
   uint64_t dedup_cap = 0;
@@ -120,6 +123,7 @@ set_err(const grp_ctx* ctx, int code, const char* fmt, ...)
   } while (0)
 
 constexpr uint32_t FILL_CHUNK = 2048; // read positions per fill workgroup
+constexpr uint64_t LIST_PREFIX = 8192; // list entries copied back together with the tile summaries
 constexpr int THREADS = 256;
 
 // ---- ntHash (btllib::SeedNtHash, restated; see DESIGN.md "Hash") -----------
@@ -1058,6 +1062,8 @@ grp_create(const grp_params* p, grp_ctx** out)
   c->f.super = c->d_super;
   CREATE_TRY(hipMalloc(&c->d_qctr, 8 * sizeof(uint64_t)));
   CREATE_TRY(hipHostMalloc(&c->h_qctr, 8 * sizeof(uint64_t), hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc(&c->h_lists, LIST_PREFIX * sizeof(grp_id_count), hipHostMallocDefault));
+  CREATE_TRY(hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
   *out = c;
@@ -1087,6 +1093,12 @@ grp_destroy(grp_ctx* c)
   (void)hipFree(c->d_qctr);
   if (c->h_qctr) {
     (void)hipHostFree(c->h_qctr);
+  }
+  if (c->h_tiles) {
+    (void)hipHostFree(c->h_tiles);
+  }
+  if (c->h_lists) {
+    (void)hipHostFree(c->h_lists);
   }
   (void)hipFree(c->d_dedup);
   if (c->stream) {
@@ -1363,7 +1375,16 @@ grp_query_tiles(grp_ctx* c,
     HIP_TRY(c, hipMalloc(&c->d_lists, want_lists * sizeof(grp_id_count)));
     c->d_lists_cap = want_lists;
   }
-  HIP_TRY(c, hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
+  if (nt > c->h_tiles_cap) {
+    if (c->h_tiles) {
+      (void)hipHostFree(c->h_tiles);
+      c->h_tiles = nullptr;
+      c->h_tiles_cap = 0;
+    }
+    const uint64_t cap = std::max<uint64_t>(nt + nt / 4, 4096);
+    HIP_TRY(c, hipHostMalloc(&c->h_tiles, cap * sizeof(grp_tile_summary), hipHostMallocDefault));
+    c->h_tiles_cap = cap;
+  }
   const size_t lds = tab_bytes(c) + (size_t)c->hist_cap * 8 + (size_t)c->list_cap_lds * 8 + bases_bytes(c->params.tile + c->params.k + c->params.h);
   uint64_t probes = 0;
   {
@@ -1388,9 +1409,18 @@ grp_query_tiles(grp_ctx* c,
     }
   }
   HIP_TRY(c, hipGetLastError());
+  // one round trip: counters, tile summaries and the first LIST_PREFIX list
+  // entries come back together; the arena cursor is re-zeroed for the next call
+  const uint64_t prefix = std::min<uint64_t>(list_cap, LIST_PREFIX);
   HIP_TRY(c, hipMemcpyAsync(c->h_qctr, c->d_qctr, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(tiles_out, c->d_tiles, nt * sizeof(grp_tile_summary), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_tiles, c->d_tiles, nt * sizeof(grp_tile_summary), hipMemcpyDeviceToHost, c->stream));
+  if (prefix) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_lists, c->d_lists, prefix * sizeof(grp_id_count), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(c, hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  memcpy(tiles_out, c->h_tiles, nt * sizeof(grp_tile_summary));
   const uint64_t used = c->h_qctr[3];
   if (list_used) {
     *list_used = used;
@@ -1409,7 +1439,11 @@ grp_query_tiles(grp_ctx* c,
     if (!lists_out) {
       return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: lists_out is NULL");
     }
-    HIP_TRY(c, hipMemcpy(lists_out, c->d_lists, used * sizeof(grp_id_count), hipMemcpyDeviceToHost));
+    if (used <= prefix) {
+      memcpy(lists_out, c->h_lists, used * sizeof(grp_id_count));
+    } else {
+      HIP_TRY(c, hipMemcpy(lists_out, c->d_lists, used * sizeof(grp_id_count), hipMemcpyDeviceToHost));
+    }
     // canonical order inside each tile's list: count descending, id ascending
     for (uint64_t i = 0; i < nt; ++i) {
       grp_tile_summary& ts = tiles_out[i];

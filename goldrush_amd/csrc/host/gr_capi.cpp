@@ -49,6 +49,12 @@ gr_sum_phred(const char* qual, size_t n)
   return gr::sum_phred(qual, n);
 }
 
+unsigned
+gr_effective_cpus(void)
+{
+  return gr::effective_cpus();
+}
+
 int
 gr_pack_2bit(const char* seq, size_t n, uint32_t* out_words)
 {
@@ -122,8 +128,14 @@ gr_classifier_set_callbacks(gr_classifier* c, gr_commit_fn commit, gr_rollover_f
 int
 gr_classifier_run(gr_classifier* c, void* reads, const uint32_t* lens, uint32_t n_reads, const uint32_t* skipped_before, uint32_t skipped_after, int* finished)
 {
+  return gr_classifier_run_range(c, reads, lens, 0, n_reads, skipped_before, skipped_after, finished);
+}
+
+int
+gr_classifier_run_range(gr_classifier* c, void* reads, const uint32_t* lens, uint32_t first, uint32_t count, const uint32_t* skipped_before, uint32_t skipped_after, int* finished)
+{
   bool fin = false;
-  int rc = c->impl.run(reads, lens, n_reads, skipped_before, skipped_after, fin);
+  int rc = c->impl.run(reads, lens, first, count, skipped_before, skipped_after, fin);
   if (finished) {
     *finished = fin ? 1 : 0;
   }

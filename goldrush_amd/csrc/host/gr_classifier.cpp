@@ -1,6 +1,7 @@
 // See gr_classifier.hpp.  commit() is process_read() after the tile query
 // (goldrush_path.cpp:960-1094); silver_path_check() is :156-187.
 #include "gr_classifier.hpp"
+#include "gr_params.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -124,7 +125,7 @@ Classifier::query_window(void* reads, const uint32_t* lens, uint32_t first, uint
     }
     for (;;) {
       uint64_t used = 0;
-      int rc = vt_.query_tiles(ctx_, reads, my_first, my_count, tiles_.data(), lists_.data(), lists_.size(), &used, nullptr);
+      int rc = vt_.query_tiles(ctx_, reads, base_ + my_first, my_count, tiles_.data(), lists_.data(), lists_.size(), &used, nullptr);
       if (rc == GRP_ERR_NOMEM && used > lists_.size()) {
         lists_.resize(used + used / 4);
         continue;
@@ -139,7 +140,8 @@ Classifier::query_window(void* reads, const uint32_t* lens, uint32_t first, uint
     const DecideParams dp{ p_.threshold, p_.unassigned_min, p_.assigned_max };
     const uint64_t t_base = tile0_[my_first];
 #if defined(_OPENMP)
-    const int nthreads = (my_count >= 64) ? omp_get_max_threads() : 1;
+    static const int kCpus = (int)std::min<unsigned>(effective_cpus(), 32);
+    const int nthreads = (my_count >= 256) ? std::max(1, std::min(omp_get_max_threads(), kCpus)) : 1;
 #else
     const int nthreads = 1;
 #endif
@@ -230,7 +232,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
   unassigned_tiles_ += nt - d.num_assigned;
 
   gr_commit ev{};
-  ev.read = r;
+  ev.read = base_ + r;
   ev.dec = d;
   ev.path = curr_path_;
   bool inserted = false;
@@ -239,7 +241,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
     if (rc != GRP_OK) {
       return;
     }
-    int e = vt_.insert_tiles(ctx_, reads, r, ts, te, id);
+    int e = vt_.insert_tiles(ctx_, reads, base_ + r, ts, te, id);
     if (e != GRP_OK) {
       rc = e;
       err_ = std::string("insert_tiles: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
@@ -315,11 +317,16 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
 }
 
 int
-Classifier::run(void* reads, const uint32_t* lens, uint32_t n, const uint32_t* skipped_before, uint32_t skipped_after, bool& finished)
+Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, const uint32_t* skipped_before, uint32_t skipped_after, bool& finished)
 {
   finished = finished_;
   if (finished_) {
     return GRP_OK;
+  }
+  base_ = first;
+  lens += first;
+  if (skipped_before) {
+    skipped_before += first;
   }
   tile0_.resize((size_t)n + 1);
   tile0_[0] = 0;

@@ -22,7 +22,8 @@ class Classifier
 public:
   Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, void* ctx);
   void set_callbacks(gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user);
-  int run(void* reads, const uint32_t* lens, uint32_t n, const uint32_t* skipped_before, uint32_t skipped_after, bool& finished);
+  // classifies reads [first, first+n) of the batch; lens / skipped_before are indexed by absolute read number
+  int run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, const uint32_t* skipped_before, uint32_t skipped_after, bool& finished);
   void get_state(gr_classifier_state& s) const;
   // tail of main(): verbose per-path statistics (goldrush_path.cpp:1266-1270)
   void log_path_stat() const;
@@ -61,7 +62,8 @@ private:
   uint64_t n_windows_ = 0, n_queried_ = 0, n_committed_ = 0, n_inserts_ = 0;
 
   // scratch
-  std::vector<uint64_t> tile0_;
+  std::vector<uint64_t> tile0_; // tile prefix of the current range, relative to base_
+  uint32_t base_ = 0;
   std::vector<grp_tile_summary> tiles_;
   std::vector<grp_id_count> lists_;
   std::vector<gr_read_decision> dec_, dec_all_;

@@ -3,7 +3,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
+#include <sched.h>
+#include <string>
 
 namespace gr {
 
@@ -138,6 +141,26 @@ pack_2bit(const char* seq, size_t n, uint32_t* out)
     out[w] = v;
   }
   return (bad & 4u) == 0;
+}
+
+unsigned
+effective_cpus()
+{
+  unsigned n = 1;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    n = (unsigned)CPU_COUNT(&set);
+  }
+  std::ifstream f("/sys/fs/cgroup/cpu.max");
+  std::string quota;
+  double period = 0;
+  if (f >> quota >> period && quota != "max" && period > 0) {
+    const double q = std::atof(quota.c_str()) / period;
+    if (q >= 1.0 && q < n) {
+      n = (unsigned)q;
+    }
+  }
+  return n ? n : 1;
 }
 
 } // namespace gr

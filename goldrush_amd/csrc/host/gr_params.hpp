@@ -21,4 +21,7 @@ double sum_phred(const char* qual, size_t n);
 // the read holds anything else
 bool pack_2bit(const char* seq, size_t n, uint32_t* out);
 
+// CPUs this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)
+unsigned effective_cpus();
+
 } // namespace gr

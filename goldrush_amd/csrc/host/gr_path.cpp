@@ -330,7 +330,7 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
 #if defined(_OPENMP)
   // the reference uses -j for its OpenMP regions; here it only drives the host
   // side (parsing, Phred, packing, decisions) and is capped at the machine size
-  omp_set_num_threads((int)std::max<size_t>(1, std::min<size_t>(opt.jobs, (size_t)omp_get_num_procs())));
+  omp_set_num_threads((int)std::max<size_t>(1, std::min<size_t>(opt.jobs, (size_t)effective_cpus())));
 #endif
   run.seeds = make_seed_pattern(opt.seed_preset, (unsigned)opt.kmer_size, (unsigned)opt.weight, (unsigned)opt.hash_num, true);
   if (opt.hash_universe == 0) {
@@ -463,7 +463,7 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
       }
       run.cur_batch = &rb;
       run.cur_packed = &pb;
-      const int rc = cls.run(h, pb.len.data(), (uint32_t)sel.size(), skipped_before.data(), skipped, finished);
+      const int rc = cls.run(h, pb.len.data(), 0, (uint32_t)sel.size(), skipped_before.data(), skipped, finished);
       run.vt.reads_free(h);
       if (rc != GRP_OK) {
         std::cerr << "goldrush-path: " << cls.error() << std::endl;

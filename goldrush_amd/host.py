@@ -72,6 +72,7 @@ SIGNATURES = {
     "gr_calc_phred_average": (None, [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gr_sum_phred": (C.c_double, [C.c_char_p, C.c_size_t]),
     "gr_pack_2bit": (C.c_int, [C.c_char_p, C.c_size_t, _vp]),
+    "gr_effective_cpus": (C.c_uint, []),
     "gr_decide_read": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, C.POINTER(gr_read_decision)]),
     "gr_smooth_tiles": (C.c_size_t, [C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp]),
     "gr_find_longest_stretch": (None, [_vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     "gr_classifier_destroy": (None, [_vp]),
     "gr_classifier_set_callbacks": (None, [_vp, COMMIT_FN, ROLLOVER_FN, ALLGATHER_FN, _vp]),
     "gr_classifier_run": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_int)]),
+    "gr_classifier_run_range": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_int)]),
     "gr_classifier_error": (C.c_char_p, [_vp]),
     "gr_classifier_get_state": (None, [_vp, C.POINTER(gr_classifier_state)]),
     "gr_path_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(grp_engine_vt)]),
@@ -187,7 +189,7 @@ class Classifier:
     """gr_classifier over an engine (HIP engine by default)."""
 
     def __init__(self, engine_handle, vt: grp_engine_vt, tile=1000, block=10, threshold=10, unassigned_min=5, assigned_max=1, k=22, h=3,
-                 target_bases=0, max_paths=1, silver_path=False, verbose=False, max_window=0, world=1, rank=0, allgather=None):
+                 target_bases=0, max_paths=1, silver_path=False, verbose=False, max_window=0, world=1, rank=0, allgather=None, record=True):
         self.lib = load()
         self.vt = vt
         p = gr_classifier_params(C.sizeof(gr_classifier_params), tile, block, threshold, unassigned_min, assigned_max, k, h, target_bases, max_paths,
@@ -209,7 +211,8 @@ class Classifier:
         def _roll(user, path):
             self.rollovers.append(path)
 
-        self._cb = (COMMIT_FN(_commit), ROLLOVER_FN(_roll), ALLGATHER_FN(allgather) if allgather else C.cast(None, ALLGATHER_FN))
+        self._cb = (COMMIT_FN(_commit) if record else C.cast(None, COMMIT_FN), ROLLOVER_FN(_roll),
+                    ALLGATHER_FN(allgather) if allgather else C.cast(None, ALLGATHER_FN))
         self.lib.gr_classifier_set_callbacks(self._h, self._cb[0], self._cb[1], self._cb[2], None)
 
     def run(self, reads_handle, lens, skipped_before=None, skipped_after=0):
@@ -219,6 +222,14 @@ class Classifier:
         rc = self.lib.gr_classifier_run(self._h, reads_handle, _p(lens), lens.size, _p(sb), skipped_after, C.byref(fin))
         if rc != 0:
             raise RuntimeError(f"gr_classifier_run: {rc}: {self.lib.gr_classifier_error(self._h).decode()}")
+        return bool(fin.value)
+
+    def run_range(self, reads_handle, lens, first, count):
+        """reads [first, first+count) of the batch; lens = the batch's full length array"""
+        fin = C.c_int()
+        rc = self.lib.gr_classifier_run_range(self._h, reads_handle, _p(lens), first, count, None, 0, C.byref(fin))
+        if rc != 0:
+            raise RuntimeError(f"gr_classifier_run_range: {rc}: {self.lib.gr_classifier_error(self._h).decode()}")
         return bool(fin.value)
 
     def state(self) -> dict:

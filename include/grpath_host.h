@@ -46,6 +46,8 @@ double gr_sum_phred(const char* qual, size_t n);
 /* 2-bit packing of one read into ceil(n/16) words; returns 0, or -1 if the read
  * holds a non-ACGT character */
 int gr_pack_2bit(const char* seq, size_t n, uint32_t* out_words);
+/* CPUs this process may use: min(affinity mask, cgroup cpu.max quota) */
+unsigned gr_effective_cpus(void);
 
 /* ---- tile decision (goldrush_path.cpp:628-889, 195-233, 341-527, 960-1040) - */
 typedef struct
@@ -120,6 +122,9 @@ void gr_classifier_set_callbacks(gr_classifier* c, gr_commit_fn commit, gr_rollo
  * reference would have exit(0)'d (path M complete, :173-176).
  */
 int gr_classifier_run(gr_classifier* c, void* reads, const uint32_t* lens, uint32_t n_reads, const uint32_t* skipped_before, uint32_t skipped_after, int* finished);
+/* same for reads [first, first+count) of the batch; lens / skipped_before are
+ * indexed by the read's number in the batch */
+int gr_classifier_run_range(gr_classifier* c, void* reads, const uint32_t* lens, uint32_t first, uint32_t count, const uint32_t* skipped_before, uint32_t skipped_after, int* finished);
 const char* gr_classifier_error(const gr_classifier* c);
 
 typedef struct
