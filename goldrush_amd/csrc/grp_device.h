@@ -1,24 +1,37 @@
 // Device-side data layout and helpers of the gfx950 GoldRush-Path engine.
 //
-// HBM layout (DESIGN.md "Data layout"):
-//   blocks[nblk]  uint4   rank-interleaved bit vector: .x = ones before this
-//                         block relative to its superblock, .y/.z/.w = 96 data
-//                         bits.  One 16-byte load answers "bit set?" and
-//                         "rank?" for a probe (the reference's
-//                         sdsl::bit_vector_il<512> + rank_support_il<1>,
-//                         MIBloomFilter.hpp:757-759, needs a 72-byte block).
-//   super[nsb]    uint64  absolute ones before each superblock of 2^24 blocks.
-//   idc[pop]      uint2   .x = ID (MIBloomFilter m_data, :758),
-//                         .y = insert count (MIBFConstructSupport m_counts, :338).
+// HBM layout (DESIGN.md "Data layout")
+//
+// phase 1 (bit-vector fill, before grp_finalize)
+//   bv[ceil(m/32)]  uint32  plain bit vector, bit i = word i>>5, bit i&31
+//                           (byte-identical to sdsl::bit_vector's 64-bit words,
+//                           MIBFConstructSupport.hpp:140-142)
+//
+// phase 2 (after grp_finalize): the reference keeps the interleaved bit vector
+// + rank support (MIBloomFilter.hpp:757-759) and a separate ID array indexed by
+// rank (:758) — two dependent random DRAM accesses per probe.  Random 64-byte
+// gathers are bound by DRAM row activations on MI355X (~55 G sectors/s,
+// tools/gather_bench.hip), so here the bits and THEIR IDs share one 64-byte
+// bucket and a probe costs one sector:
+//   buckets[n_buckets]  64 B each:
+//       uint32 rel        ones before this bucket, relative to its superbucket
+//       uint64 bitmap     W <= 64 consecutive filter bits (bit j = position b*W+j)
+//       uint32 ids[13]    ID of the bucket's j-th set bit (MIBloomFilter m_data)
+//   W is chosen at finalize from the measured occupancy so that a bucket holds
+//   ~6 set bits on average; the rare bucket with more than 13 set bits keeps the
+//   IDs of its 14th.. set bits in a small open-addressing table keyed by rank.
+//   super[n_super]   uint64  absolute ones before each superbucket (2^22 buckets)
+//   counts[pop]      uint32  insert counts (MIBFConstructSupport m_counts, :338),
+//                            indexed by global rank; touched by inserts only
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define GRP_DEV_MAX_H 8
 #define GRP_DEV_MAX_W 32
-#define GRP_BLOCK_BITS 96u
-#define GRP_SUPER_SHIFT 24 /* blocks per superblock = 2^24 */
-#define GRP_CHUNK_BLOCKS 4096u /* rank-build chunk; divides the superblock */
+#define GRP_BUCKET_IDS 13u
+#define GRP_SUPER_SHIFT 22       /* buckets per superbucket = 2^22 (rel < 2^28) */
+#define GRP_CHUNK_BUCKETS 4096u  /* rank-build chunk; divides the superbucket */
 
 struct DevSeeds
 {
@@ -35,13 +48,20 @@ struct DevSeeds
 
 struct DevFilter
 {
-  uint4* blocks;
+  uint32_t* bv;                 // phase 1
+  uint4* buckets;               // phase 2: 4 x uint4 per bucket
   const uint64_t* super;
-  uint2* idc;
-  uint64_t m;     // filter bits
-  uint64_t m_inv; // floor((2^64-1)/m)
-  uint64_t nblk;
+  uint32_t* counts;
+  unsigned long long* ovf_keys; // rank + 1, 0 = empty
+  uint32_t* ovf_ids;
+  uint64_t ovf_mask;
+  uint64_t m;       // filter bits
+  uint64_t m_inv;   // floor((2^64-1)/m)
+  uint64_t w_magic; // floor(2^64 / W) + 1
+  uint64_t n_buckets;
   uint64_t pop;
+  uint32_t W;       // filter bits per bucket (13..64)
+  uint32_t pad;
 };
 
 struct DevReads
@@ -72,28 +92,81 @@ grp_mod_m(uint64_t x, uint64_t m, uint64_t m_inv)
   return r;
 }
 
-// ones among the `off` lowest of a block's 96 data bits
-__device__ inline uint32_t
-grp_block_rank(const uint4& b, uint32_t off)
+// pos / W for a run-time W in [13,64]: exact for pos < 2^58 with
+// magic = floor(2^64 / W) + 1
+__host__ __device__ inline uint64_t
+grp_div_w(uint64_t pos, uint64_t w_magic)
 {
-  uint32_t r = 0;
-  uint32_t w = off >> 5;
-  uint32_t bit = off & 31u;
-  uint32_t lowmask = (1u << bit) - 1u; // bit < 32
-  if (w == 0) {
-    r = __popc(b.y & lowmask);
-  } else if (w == 1) {
-    r = __popc(b.y) + __popc(b.z & lowmask);
-  } else {
-    r = __popc(b.y) + __popc(b.z) + __popc(b.w & lowmask);
-  }
-  return r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(pos, w_magic);
+#else
+  return (uint64_t)(((unsigned __int128)pos * w_magic) >> 64);
+#endif
+}
+
+// one probe, first access: bucket index, bit offset
+struct Probe
+{
+  uint64_t b;
+  uint32_t off;
+};
+
+__device__ inline Probe
+grp_locate(const DevFilter& f, uint64_t hash)
+{
+  Probe p;
+  const uint64_t pos = grp_mod_m(hash, f.m, f.m_inv);
+  p.b = grp_div_w(pos, f.w_magic);
+  p.off = (uint32_t)(pos - p.b * f.W);
+  return p;
+}
+
+// header = first 16 bytes of a bucket: {rel, bitmap lo, bitmap hi, ids[0]}
+__device__ inline uint64_t
+grp_bitmap(const uint4& hd)
+{
+  return (uint64_t)hd.y | ((uint64_t)hd.z << 32);
 }
 
 __device__ inline uint32_t
-grp_block_bit(const uint4& b, uint32_t off)
+grp_local_rank(uint64_t bm, uint32_t off)
 {
-  uint32_t w = off >> 5;
-  uint32_t word = (w == 0) ? b.y : ((w == 1) ? b.z : b.w);
-  return (word >> (off & 31u)) & 1u;
+  return (uint32_t)__popcll(bm & ((1ull << off) - 1ull)); // off < 64
+}
+
+// open-addressing table for the IDs of a bucket's 14th.. set bits
+__device__ inline uint32_t
+grp_ovf_get(const DevFilter& f, uint64_t rank)
+{
+  uint64_t slot = (rank * 0x9E3779B97F4A7C15ULL) >> 17 & f.ovf_mask;
+  for (;;) {
+    const unsigned long long k = f.ovf_keys[slot];
+    if (k == rank + 1) {
+      return f.ovf_ids[slot];
+    }
+    if (k == 0) {
+      return 0u;
+    }
+    slot = (slot + 1) & f.ovf_mask;
+  }
+}
+
+__device__ inline void
+grp_ovf_put(const DevFilter& f, uint64_t rank, uint32_t id)
+{
+  uint64_t slot = (rank * 0x9E3779B97F4A7C15ULL) >> 17 & f.ovf_mask;
+  for (;;) {
+    unsigned long long k = f.ovf_keys[slot];
+    if (k == 0) {
+      k = atomicCAS(&f.ovf_keys[slot], 0ull, (unsigned long long)(rank + 1));
+      if (k == 0) {
+        k = rank + 1;
+      }
+    }
+    if (k == rank + 1) {
+      f.ovf_ids[slot] = id;
+      return;
+    }
+    slot = (slot + 1) & f.ovf_mask;
+  }
 }

@@ -5,8 +5,8 @@
 //   k_fill        spaced-seed ntHash of every read position + test-and-set of
 //                 bit (hash % m)           (goldrush_path.cpp:304-305,
 //                 MIBFConstructSupport.hpp:134-147)
-//   k_rank_*      popcount prefix scan -> per-block relative rank + superblock
-//                 table                    (MIBFConstructSupport.hpp:165-170)
+//   k_bucket_*    popcount prefix scan -> 64-byte buckets {rank, bitmap, IDs}
+//                 (MIBFConstructSupport.hpp:165-181)
 //   k_query       fused hash -> probe (bit+rank, then ID) -> per-frame ID
 //                 dedup -> per-tile LDS count table -> top ID + count>2 list
 //                 (read_hashing.cpp:29-54, goldrush_path.cpp:544-626)
@@ -48,7 +48,9 @@ struct grp_ctx
   DevSeeds h_seeds{};
   DevSeeds* d_seeds = nullptr;
   DevFilter f{};
-  uint64_t nsb = 0;      // superblocks
+  uint64_t nsb = 0;      // superbuckets
+  uint64_t n_bv_words = 0;
+  uint64_t n_ovf = 0;    // IDs living in the overflow table
   uint64_t n_chunks = 0; // rank-build chunks
   uint64_t* d_super = nullptr;
   bool finalized = false;
@@ -245,7 +247,7 @@ k_fill(DevFilter f, DevReads rd, const DevSeeds* __restrict__ sd, uint64_t chunk
   const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[r], len, p0, np + k + H - 2u);
   __syncthreads();
 
-  uint32_t* words = reinterpret_cast<uint32_t*>(f.blocks);
+  uint32_t* words = f.bv;
   constexpr int FR = 4;
   for (uint32_t i0 = threadIdx.x; i0 < np; i0 += THREADS * FR) {
     uint64_t widx[FR][H];
@@ -265,13 +267,13 @@ k_fill(DevFilter f, DevReads rd, const DevSeeds* __restrict__ sd, uint64_t chunk
         if (ok) {
           uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + i));
           uint64_t pos = grp_mod_m(hv, f.m, f.m_inv);
-          uint64_t blk = pos / GRP_BLOCK_BITS;
-          uint32_t off = (uint32_t)(pos - blk * GRP_BLOCK_BITS);
-          widx[j][s] = blk * 4u + 1u + (off >> 5);
-          mask[j][s] = 1u << (off & 31u);
+          widx[j][s] = pos >> 5;
+          mask[j][s] = 1u << (uint32_t)(pos & 31u);
         }
       }
     }
+    // test first (plain load), set only where needed: the filter saturates and
+    // most probes find their bit already set
 #pragma unroll
     for (int j = 0; j < FR; ++j) {
 #pragma unroll
@@ -291,25 +293,58 @@ k_fill(DevFilter f, DevReads rd, const DevSeeds* __restrict__ sd, uint64_t chunk
   }
 }
 
-// ---- rank build ------------------------------------------------------------------
+// ---- finalize: plain bit vector -> 64-byte buckets -----------------------------
 
-__device__ inline uint32_t
-block_pop(const uint4& b)
-{
-  return __popc(b.y) + __popc(b.z) + __popc(b.w);
-}
-
-// per-chunk popcount
 __global__ void __launch_bounds__(THREADS)
-k_rank_chunk_sums(const uint4* __restrict__ blocks, uint64_t nblk, uint32_t* __restrict__ chunk_sum)
+k_popcount(const uint32_t* __restrict__ bv, uint64_t n_words, unsigned long long* __restrict__ out)
 {
   __shared__ uint32_t sW[THREADS / 64];
-  const uint64_t b0 = (uint64_t)blockIdx.x * GRP_CHUNK_BLOCKS;
   uint32_t acc = 0;
-  for (uint32_t i = threadIdx.x; i < GRP_CHUNK_BLOCKS; i += THREADS) {
-    uint64_t b = b0 + i;
-    if (b < nblk) {
-      acc += block_pop(blocks[b]);
+  for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * THREADS) {
+    acc += __popc(bv[i]);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) {
+    sW[threadIdx.x >> 6] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < THREADS / 64; ++w) {
+      t += sW[w];
+    }
+    atomicAdd(out, t);
+  }
+}
+
+// the W filter bits of bucket b (bv is padded with 3 zero words)
+__device__ inline uint64_t
+bucket_bits(const uint32_t* __restrict__ bv, uint64_t b, uint32_t W, uint64_t m)
+{
+  const uint64_t s = b * W;
+  const uint64_t w = s >> 5;
+  const uint32_t sh = (uint32_t)(s & 31u);
+  uint64_t v = ((uint64_t)bv[w] | ((uint64_t)bv[w + 1] << 32)) >> sh;
+  if (sh) {
+    v |= (uint64_t)bv[w + 2] << (64u - sh);
+  }
+  const uint64_t n = (s + W <= m) ? W : (m - s); // the last bucket may be short
+  if (n < 64) {
+    v &= (1ull << n) - 1ull;
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(THREADS)
+k_bucket_chunk_sums(const uint32_t* __restrict__ bv, uint64_t m, uint32_t W, uint64_t n_buckets, uint32_t* __restrict__ chunk_sum)
+{
+  __shared__ uint32_t sW[THREADS / 64];
+  const uint64_t b0 = (uint64_t)blockIdx.x * GRP_CHUNK_BUCKETS;
+  uint32_t acc = 0;
+  for (uint32_t i = threadIdx.x; i < GRP_CHUNK_BUCKETS; i += THREADS) {
+    const uint64_t b = b0 + i;
+    if (b < n_buckets) {
+      acc += (uint32_t)__popcll(bucket_bits(bv, b, W, m));
     }
   }
   acc = wave_sum(acc);
@@ -326,9 +361,9 @@ k_rank_chunk_sums(const uint4* __restrict__ blocks, uint64_t nblk, uint32_t* __r
   }
 }
 
-// single workgroup: exclusive scan of the chunk sums (uint64), superblock table, pop
+// single workgroup: exclusive scan of the chunk sums (uint64), superbucket table, pop
 __global__ void __launch_bounds__(1024)
-k_rank_scan_chunks(const uint32_t* __restrict__ chunk_sum, uint64_t n_chunks, uint64_t* __restrict__ chunk_base, uint64_t* __restrict__ super, uint64_t* __restrict__ pop_out)
+k_scan_chunks(const uint32_t* __restrict__ chunk_sum, uint64_t n_chunks, uint64_t* __restrict__ chunk_base, uint64_t* __restrict__ super, uint64_t* __restrict__ pop_out)
 {
   __shared__ uint64_t sScan[1024];
   __shared__ uint64_t sCarry;
@@ -336,14 +371,13 @@ k_rank_scan_chunks(const uint32_t* __restrict__ chunk_sum, uint64_t n_chunks, ui
     sCarry = 0;
   }
   __syncthreads();
-  const uint32_t chunks_per_super = (1u << GRP_SUPER_SHIFT) / GRP_CHUNK_BLOCKS;
+  const uint32_t chunks_per_super = (1u << GRP_SUPER_SHIFT) / GRP_CHUNK_BUCKETS;
   for (uint64_t c0 = 0; c0 < n_chunks; c0 += 1024) {
     uint64_t c = c0 + threadIdx.x;
     uint64_t v = (c < n_chunks) ? chunk_sum[c] : 0;
     sScan[threadIdx.x] = v;
     __syncthreads();
-    // Hillis-Steele inclusive scan
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
+    for (uint32_t o = 1; o < 1024; o <<= 1) { // Hillis-Steele inclusive scan
       uint64_t t = (threadIdx.x >= o) ? sScan[threadIdx.x - o] : 0;
       __syncthreads();
       sScan[threadIdx.x] += t;
@@ -367,21 +401,23 @@ k_rank_scan_chunks(const uint32_t* __restrict__ chunk_sum, uint64_t n_chunks, ui
   }
 }
 
-// write the relative rank into every block of a chunk
+// write every bucket of a chunk: {rel, bitmap, ids = 0}; count overflow entries
 __global__ void __launch_bounds__(THREADS)
-k_rank_write(uint4* __restrict__ blocks, uint64_t nblk, const uint64_t* __restrict__ chunk_base, const uint64_t* __restrict__ super)
+k_bucket_write(const uint32_t* __restrict__ bv, uint64_t m, uint32_t W, uint64_t n_buckets, uint4* __restrict__ buckets, const uint64_t* __restrict__ chunk_base, const uint64_t* __restrict__ super, unsigned long long* __restrict__ n_ovf)
 {
-  constexpr uint32_t PER = GRP_CHUNK_BLOCKS / THREADS; // consecutive blocks per thread
+  constexpr uint32_t PER = GRP_CHUNK_BUCKETS / THREADS; // consecutive buckets per thread
   __shared__ uint32_t sScan[THREADS];
   const uint64_t chunk = blockIdx.x;
-  const uint64_t b0 = chunk * GRP_CHUNK_BLOCKS + (uint64_t)threadIdx.x * PER;
-  uint32_t pc[PER];
-  uint32_t tot = 0;
+  const uint64_t b0 = chunk * GRP_CHUNK_BUCKETS + (uint64_t)threadIdx.x * PER;
+  uint64_t bm[PER];
+  uint32_t tot = 0, ovf = 0;
 #pragma unroll
   for (uint32_t i = 0; i < PER; ++i) {
-    uint64_t b = b0 + i;
-    pc[i] = (b < nblk) ? block_pop(blocks[b]) : 0u;
-    tot += pc[i];
+    const uint64_t b = b0 + i;
+    bm[i] = (b < n_buckets) ? bucket_bits(bv, b, W, m) : 0ull;
+    const uint32_t c = (uint32_t)__popcll(bm[i]);
+    tot += c;
+    ovf += (c > GRP_BUCKET_IDS) ? (c - GRP_BUCKET_IDS) : 0u;
   }
   sScan[threadIdx.x] = tot;
   __syncthreads();
@@ -391,15 +427,40 @@ k_rank_write(uint4* __restrict__ blocks, uint64_t nblk, const uint64_t* __restri
     sScan[threadIdx.x] += t;
     __syncthreads();
   }
-  const uint64_t sb = (chunk * GRP_CHUNK_BLOCKS) >> GRP_SUPER_SHIFT;
+  const uint64_t sb = (chunk * GRP_CHUNK_BUCKETS) >> GRP_SUPER_SHIFT;
   uint32_t rel = (uint32_t)(chunk_base[chunk] - super[sb]) + sScan[threadIdx.x] - tot;
 #pragma unroll
   for (uint32_t i = 0; i < PER; ++i) {
-    uint64_t b = b0 + i;
-    if (b < nblk) {
-      reinterpret_cast<uint32_t*>(&blocks[b])[0] = rel;
+    const uint64_t b = b0 + i;
+    if (b < n_buckets) {
+      buckets[b * 4 + 0] = make_uint4(rel, (uint32_t)bm[i], (uint32_t)(bm[i] >> 32), 0u);
+      buckets[b * 4 + 1] = make_uint4(0, 0, 0, 0);
+      buckets[b * 4 + 2] = make_uint4(0, 0, 0, 0);
+      buckets[b * 4 + 3] = make_uint4(0, 0, 0, 0);
     }
-    rel += pc[i];
+    rel += (uint32_t)__popcll(bm[i]);
+  }
+  ovf = wave_sum(ovf);
+  if ((threadIdx.x & 63) == 0 && ovf) {
+    atomicAdd(n_ovf, (unsigned long long)ovf);
+  }
+}
+
+// zero every ID (bucket slots), keep rel + bitmap
+__global__ void __launch_bounds__(THREADS)
+k_reset_bucket_ids(uint4* __restrict__ buckets, uint64_t n_buckets)
+{
+  // four lanes per bucket, one 16-byte piece each
+  const uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+  const uint64_t b = i >> 2;
+  const uint32_t q = (uint32_t)(i & 3u);
+  if (b >= n_buckets) {
+    return;
+  }
+  if (q == 0) {
+    reinterpret_cast<uint32_t*>(&buckets[b * 4])[3] = 0u;
+  } else {
+    buckets[b * 4 + q] = make_uint4(0, 0, 0, 0);
   }
 }
 
@@ -477,10 +538,9 @@ k_query(DevFilter f,
   uint32_t n_hit = 0, n_miss = 0;
 
   for (uint32_t f0 = threadIdx.x; f0 < frames; f0 += THREADS * FR) {
-    uint64_t blk[FR][H];
-    uint32_t off[FR][H];
-    uint4 bv[FR][H];
-    // 1) hashes -> positions -> block loads
+    Probe pr[FR][H];
+    uint4 hd[FR][H];
+    // 1) hashes -> positions -> bucket header loads (one 64-byte sector per probe)
 #pragma unroll
     for (int j = 0; j < FR; ++j) {
       const uint32_t fr = f0 + j * THREADS;
@@ -492,10 +552,7 @@ k_query(DevFilter f,
         const uint32_t last = Lp - sd->span[s];
         const uint32_t fs = min(fr, last);
         uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + (live ? fs : 0u)));
-        uint64_t pos = grp_mod_m(hv, f.m, f.m_inv);
-        uint64_t b = pos / GRP_BLOCK_BITS;
-        blk[j][s] = b;
-        off[j][s] = (uint32_t)(pos - b * GRP_BLOCK_BITS);
+        pr[j][s] = grp_locate(f, hv);
       }
     }
 #pragma unroll
@@ -503,26 +560,35 @@ k_query(DevFilter f,
       const bool live = (f0 + j * THREADS) < frames;
 #pragma unroll
       for (int s = 0; s < H; ++s) {
-        bv[j][s] = live ? f.blocks[blk[j][s]] : make_uint4(0, 0, 0, 0);
+        hd[j][s] = live ? f.buckets[pr[j][s].b * 4] : make_uint4(0, 0, 0, 0);
       }
     }
-    // 2) bit + rank -> ID loads
+    // 2) bit + local rank -> ID (same sector; slot 0 came with the header)
     uint32_t idv[FR][H];
     bool all_set[FR];
 #pragma unroll
     for (int j = 0; j < FR; ++j) {
       const bool live = (f0 + j * THREADS) < frames;
       bool all = live;
-      uint64_t rk[H];
+      uint32_t lr[H];
 #pragma unroll
       for (int s = 0; s < H; ++s) {
-        all = all && grp_block_bit(bv[j][s], off[j][s]);
-        rk[s] = f.super[blk[j][s] >> GRP_SUPER_SHIFT] + bv[j][s].x + grp_block_rank(bv[j][s], off[j][s]);
+        const uint64_t bm = grp_bitmap(hd[j][s]);
+        all = all && ((bm >> pr[j][s].off) & 1ull);
+        lr[s] = grp_local_rank(bm, pr[j][s].off);
       }
       all_set[j] = all; // atRank (MIBloomFilter.hpp:465-476)
 #pragma unroll
       for (int s = 0; s < H; ++s) {
-        idv[j][s] = all ? f.idc[rk[s]].x : 0u; // getData (:614-621)
+        uint32_t v = hd[j][s].w; // getData (:614-621)
+        if (all && lr[s] != 0u) {
+          if (lr[s] < GRP_BUCKET_IDS) {
+            v = reinterpret_cast<const uint32_t*>(f.buckets)[pr[j][s].b * 16 + 3 + lr[s]];
+          } else {
+            v = grp_ovf_get(f, f.super[pr[j][s].b >> GRP_SUPER_SHIFT] + hd[j][s].x + lr[s]);
+          }
+        }
+        idv[j][s] = all ? v : 0u;
       }
     }
     // 3) per-frame ID set -> tile count table
@@ -689,39 +755,43 @@ k_insert(DevFilter f,
   __syncthreads();
 
   for (uint32_t fr = part * THREADS + threadIdx.x; fr < frames; fr += THREADS * parts) {
-    uint64_t blk[H];
-    uint32_t off[H];
-    uint4 bv[H];
+    Probe pr[H];
+    uint4 hd[H];
 #pragma unroll
     for (int s = 0; s < H; ++s) {
       const uint32_t fs = min(fr, Lp - sd->span[s]);
-      uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + fs));
-      uint64_t pos = grp_mod_m(hv, f.m, f.m_inv);
-      blk[s] = pos / GRP_BLOCK_BITS;
-      off[s] = (uint32_t)(pos - blk[s] * GRP_BLOCK_BITS);
+      pr[s] = grp_locate(f, seed_hash(sTab, sd, s, window_at(sBases, boff + fs)));
     }
 #pragma unroll
     for (int s = 0; s < H; ++s) {
-      bv[s] = f.blocks[blk[s]];
+      hd[s] = f.buckets[pr[s].b * 4];
     }
 #pragma unroll
     for (int s = 0; s < H; ++s) {
       // getRankPos (MIBloomFilter.hpp:488-491): rank only, the bit is not tested
-      uint64_t rank = f.super[blk[s] >> GRP_SUPER_SHIFT] + bv[s].x + grp_block_rank(bv[s], off[s]);
-      if (rank >= f.pop) {
-        continue; // out of range in the reference too (position past the last set bit)
+      const uint32_t lr = grp_local_rank(grp_bitmap(hd[s]), pr[s].off);
+      const uint64_t rank = f.super[pr[s].b >> GRP_SUPER_SHIFT] + hd[s].x + lr;
+      if (rank >= f.pop || !((grp_bitmap(hd[s]) >> pr[s].off) & 1ull)) {
+        // an unset bit has no slot of its own; unreachable for reads that went
+        // through the fill (it covers a superset of all tile positions)
+        continue;
       }
       if (dedup_claim(dedup, dedup_mask, epoch_tag | rank, epoch_tag)) {
         // MIBFConstructSupport.hpp:274-282 ; the only writer of this rank in this call
-        uint2 e = f.idc[rank];
-        uint32_t count = e.y + 1u;
-        uint32_t random_num = (uint32_t)(rank ^ (uint64_t)id) % count;
+        const uint32_t count = f.counts[rank] + 1u;
+        f.counts[rank] = count;
+        const uint32_t random_num = (uint32_t)(rank ^ (uint64_t)id) % count;
         if (random_num == count - 1u) {
+          uint32_t* slot = (lr < GRP_BUCKET_IDS) ? &reinterpret_cast<uint32_t*>(f.buckets)[pr[s].b * 16 + 3 + lr] : nullptr;
+          const uint32_t old = slot ? *slot : grp_ovf_get(f, rank);
           // setData (MIBloomFilter.hpp:593-602): keep a set saturation bit
-          e.x = (e.x > 0x80000000u) ? (id | 0x80000000u) : id;
+          const uint32_t nv = (old > 0x80000000u) ? (id | 0x80000000u) : id;
+          if (slot) {
+            *slot = nv;
+          } else {
+            grp_ovf_put(f, rank, nv);
+          }
         }
-        e.y = count;
-        f.idc[rank] = e;
       }
     }
   }
@@ -729,25 +799,33 @@ k_insert(DevFilter f,
 
 // ---- inspection kernels ----------------------------------------------------------
 
+// buckets -> plain bit vector (out zeroed by the caller, 32-bit words)
 __global__ void
-k_export_bits(const uint4* __restrict__ blocks, uint64_t m, uint64_t n_words, unsigned long long* __restrict__ out)
+k_export_bits(const uint4* __restrict__ buckets, uint64_t n_buckets, uint32_t W, uint32_t* __restrict__ out)
 {
-  uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_words) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_buckets) {
     return;
   }
-  unsigned long long v = 0;
-  for (uint32_t i = 0; i < 64; ++i) {
-    uint64_t pos = w * 64 + i;
-    if (pos >= m) {
-      break;
-    }
-    uint64_t b = pos / GRP_BLOCK_BITS;
-    uint32_t off = (uint32_t)(pos - b * GRP_BLOCK_BITS);
-    uint4 bl = blocks[b];
-    v |= (unsigned long long)grp_block_bit(bl, off) << i;
+  const uint64_t bm = grp_bitmap(buckets[b * 4]);
+  if (!bm) {
+    return;
   }
-  out[w] = v;
+  const uint64_t s = b * W;
+  const uint64_t w = s >> 5;
+  const uint32_t sh = (uint32_t)(s & 31u);
+  atomicOr(&out[w], (uint32_t)(bm << sh));
+  const uint64_t rest = sh ? (bm >> (32u - sh)) : (bm >> 32) ;
+  if (sh) {
+    if ((uint32_t)rest) {
+      atomicOr(&out[w + 1], (uint32_t)rest);
+    }
+    if ((uint32_t)(rest >> 32)) {
+      atomicOr(&out[w + 2], (uint32_t)(rest >> 32));
+    }
+  } else if ((uint32_t)rest) {
+    atomicOr(&out[w + 1], (uint32_t)rest);
+  }
 }
 
 __global__ void
@@ -757,12 +835,61 @@ k_rank_positions(DevFilter f, const uint64_t* __restrict__ pos, uint64_t n, uint
   if (i >= n) {
     return;
   }
-  uint64_t p = pos[i];
-  uint64_t b = p / GRP_BLOCK_BITS;
-  uint32_t off = (uint32_t)(p - b * GRP_BLOCK_BITS);
-  uint4 bl = f.blocks[b];
-  bit[i] = (uint8_t)grp_block_bit(bl, off);
-  rank[i] = f.super[b >> GRP_SUPER_SHIFT] + bl.x + grp_block_rank(bl, off);
+  const uint64_t p = pos[i];
+  const uint64_t b = grp_div_w(p, f.w_magic);
+  const uint32_t off = (uint32_t)(p - b * f.W);
+  const uint4 hd = f.buckets[b * 4];
+  const uint64_t bm = grp_bitmap(hd);
+  bit[i] = (uint8_t)((bm >> off) & 1ull);
+  rank[i] = f.super[b >> GRP_SUPER_SHIFT] + hd.x + grp_local_rank(bm, off);
+}
+
+// ids / counts of ranks [first, first+n): one thread per bucket
+__global__ void
+k_export_ids(DevFilter f, uint64_t first, uint64_t n, uint32_t* __restrict__ ids, uint32_t* __restrict__ counts)
+{
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= f.n_buckets) {
+    return;
+  }
+  const uint4 hd = f.buckets[b * 4];
+  const uint32_t c = (uint32_t)__popcll(grp_bitmap(hd));
+  const uint64_t base = f.super[b >> GRP_SUPER_SHIFT] + hd.x;
+  for (uint32_t lr = 0; lr < c; ++lr) {
+    const uint64_t rank = base + lr;
+    if (rank >= first && rank < first + n) {
+      const uint32_t v = (lr < GRP_BUCKET_IDS) ? reinterpret_cast<const uint32_t*>(f.buckets)[b * 16 + 3 + lr] : grp_ovf_get(f, rank);
+      ids[rank - first] = v;
+      counts[rank - first] = f.counts[rank];
+    }
+  }
+}
+
+__global__ void
+k_import_ids(DevFilter f, uint64_t first, uint64_t n, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ counts)
+{
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= f.n_buckets) {
+    return;
+  }
+  const uint4 hd = f.buckets[b * 4];
+  const uint32_t c = (uint32_t)__popcll(grp_bitmap(hd));
+  const uint64_t base = f.super[b >> GRP_SUPER_SHIFT] + hd.x;
+  for (uint32_t lr = 0; lr < c; ++lr) {
+    const uint64_t rank = base + lr;
+    if (rank >= first && rank < first + n) {
+      if (ids) {
+        if (lr < GRP_BUCKET_IDS) {
+          reinterpret_cast<uint32_t*>(f.buckets)[b * 16 + 3 + lr] = ids[rank - first];
+        } else {
+          grp_ovf_put(f, rank, ids[rank - first]);
+        }
+      }
+      if (counts) {
+        f.counts[rank] = counts[rank - first];
+      }
+    }
+  }
 }
 
 template<int H>
@@ -790,33 +917,6 @@ k_debug_tile_hashes(DevReads rd, const DevSeeds* __restrict__ sd, uint32_t tile_
         out[o] = hv;
       }
     }
-  }
-}
-
-__global__ void
-k_split_idc(const uint2* __restrict__ idc, uint64_t first, uint64_t n, uint32_t* __restrict__ ids, uint32_t* __restrict__ counts)
-{
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    uint2 e = idc[first + i];
-    ids[i] = e.x;
-    counts[i] = e.y;
-  }
-}
-
-__global__ void
-k_merge_idc(uint2* __restrict__ idc, uint64_t first, uint64_t n, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ counts)
-{
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    uint2 e = idc[first + i];
-    if (ids) {
-      e.x = ids[i];
-    }
-    if (counts) {
-      e.y = counts[i];
-    }
-    idc[first + i] = e;
   }
 }
 
@@ -871,6 +971,16 @@ drain_events(grp_ctx* c)
     c->free_events.push_back(ep);
   }
   c->pending.clear();
+}
+
+uint64_t
+next_pow2_64(uint64_t v)
+{
+  uint64_t p = 1;
+  while (p < v) {
+    p <<= 1;
+  }
+  return p;
 }
 
 uint32_t
@@ -997,7 +1107,7 @@ grp_create(const grp_params* p, grp_ctx** out)
   if (p->tile < p->k + p->h - 1) {
     return set_err(nullptr, GRP_ERR_INVALID, "tile length %u shorter than the longest seed span %u", p->tile, p->k + p->h - 1);
   }
-  if (p->m < 64 || p->m >= (1ULL << 40) * GRP_BLOCK_BITS) {
+  if (p->m < 64 || p->m >= (1ULL << 50)) {
     return set_err(nullptr, GRP_ERR_INVALID, "filter size m=%llu unsupported", (unsigned long long)p->m);
   }
   int ndev = 0;
@@ -1052,14 +1162,10 @@ grp_create(const grp_params* p, grp_ctx** out)
   CREATE_TRY(hipMemcpyAsync(c->d_seeds, &c->h_seeds, sizeof(DevSeeds), hipMemcpyHostToDevice, c->stream));
   c->f.m = p->m;
   c->f.m_inv = ~0ULL / p->m;
-  c->f.nblk = (p->m + GRP_BLOCK_BITS - 1) / GRP_BLOCK_BITS;
-  c->n_chunks = (c->f.nblk + GRP_CHUNK_BLOCKS - 1) / GRP_CHUNK_BLOCKS;
-  c->nsb = ((c->f.nblk - 1) >> GRP_SUPER_SHIFT) + 1;
-  CREATE_TRY(hipMalloc(&c->f.blocks, c->f.nblk * sizeof(uint4)));
-  CREATE_TRY(hipMemsetAsync(c->f.blocks, 0, c->f.nblk * sizeof(uint4), c->stream));
-  CREATE_TRY(hipMalloc(&c->d_super, c->nsb * sizeof(uint64_t)));
-  CREATE_TRY(hipMemsetAsync(c->d_super, 0, c->nsb * sizeof(uint64_t), c->stream));
-  c->f.super = c->d_super;
+  // phase 1: plain bit vector (+3 zero pad words for the bucket builder)
+  c->n_bv_words = (p->m + 31) / 32;
+  CREATE_TRY(hipMalloc(&c->f.bv, (c->n_bv_words + 3) * sizeof(uint32_t)));
+  CREATE_TRY(hipMemsetAsync(c->f.bv, 0, (c->n_bv_words + 3) * sizeof(uint32_t), c->stream));
   CREATE_TRY(hipMalloc(&c->d_qctr, 8 * sizeof(uint64_t)));
   CREATE_TRY(hipHostMalloc(&c->h_qctr, 8 * sizeof(uint64_t), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&c->h_lists, LIST_PREFIX * sizeof(grp_id_count), hipHostMallocDefault));
@@ -1085,9 +1191,12 @@ grp_destroy(grp_ctx* c)
     (void)hipEventDestroy(ep.b);
   }
   (void)hipFree(c->d_seeds);
-  (void)hipFree(c->f.blocks);
+  (void)hipFree(c->f.bv);
+  (void)hipFree(c->f.buckets);
   (void)hipFree(c->d_super);
-  (void)hipFree(c->f.idc);
+  (void)hipFree(c->f.counts);
+  (void)hipFree(c->f.ovf_keys);
+  (void)hipFree(c->f.ovf_ids);
   (void)hipFree(c->d_tiles);
   (void)hipFree(c->d_lists);
   (void)hipFree(c->d_qctr);
@@ -1290,31 +1399,77 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
     return set_err(c, GRP_ERR_STATE, "grp_finalize called twice");
   }
   HIP_TRY(c, hipSetDevice(c->device));
+  unsigned long long* d_scalars = nullptr; // [0] pop (popcount), [1] pop (scan), [2] overflow entries
+  HIP_TRY(c, hipMalloc(&d_scalars, 3 * sizeof(unsigned long long)));
+  HIP_TRY(c, hipMemsetAsync(d_scalars, 0, 3 * sizeof(unsigned long long), c->stream));
+  Timer* t = new Timer(c, GRP_K_RANK, c->n_bv_words);
+  k_popcount<<<dim3(4096), dim3(THREADS), 0, c->stream>>>(c->f.bv, c->n_bv_words, d_scalars);
+  unsigned long long h_scalars[3] = { 0, 0, 0 };
+  HIP_TRY(c, hipMemcpyAsync(h_scalars, d_scalars, sizeof(h_scalars), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const uint64_t h_pop = h_scalars[0];
+  // bucket width: ~6 set bits per bucket on average at the measured occupancy;
+  // with W <= 13 a bucket can never overflow its 13 ID slots
+  const double occ = (double)h_pop / (double)c->f.m;
+  uint32_t W = 64;
+  if (occ > 0) {
+    const double w = 6.0 / occ;
+    W = (w >= 64.0) ? 64u : (uint32_t)w;
+  }
+  W = std::max<uint32_t>(GRP_BUCKET_IDS, std::min<uint32_t>(W, 64u));
+  c->f.W = W;
+  c->f.w_magic = (uint64_t)((((unsigned __int128)1) << 64) / W) + 1;
+  c->f.n_buckets = (c->f.m + W - 1) / W;
+  for (uint64_t q : { (uint64_t)0, (uint64_t)1, c->f.n_buckets / 2, c->f.n_buckets - 1 }) { // the division shortcut is exact
+    for (uint64_t d : { (uint64_t)0, (uint64_t)W - 1 }) {
+      const uint64_t pos = q * W + d;
+      if (grp_div_w(pos, c->f.w_magic) != q) {
+        delete t;
+        return set_err(c, GRP_ERR_INVALID, "internal: bucket division is not exact for W=%u", W);
+      }
+    }
+  }
+  c->n_chunks = (c->f.n_buckets + GRP_CHUNK_BUCKETS - 1) / GRP_CHUNK_BUCKETS;
+  c->nsb = ((c->f.n_buckets - 1) >> GRP_SUPER_SHIFT) + 1;
   uint32_t* d_chunk_sum = nullptr;
   uint64_t* d_chunk_base = nullptr;
-  uint64_t* d_pop = nullptr;
+  hipError_t e = hipMalloc(&c->f.buckets, c->f.n_buckets * 64);
+  if (e != hipSuccess) {
+    delete t;
+    return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu buckets (%.1f GB) failed: %s", (unsigned long long)c->f.n_buckets, c->f.n_buckets * 64 / 1e9, hipGetErrorString(e));
+  }
+  HIP_TRY(c, hipMalloc(&c->d_super, c->nsb * sizeof(uint64_t)));
+  c->f.super = c->d_super;
   HIP_TRY(c, hipMalloc(&d_chunk_sum, c->n_chunks * 4));
   HIP_TRY(c, hipMalloc(&d_chunk_base, c->n_chunks * 8));
-  HIP_TRY(c, hipMalloc(&d_pop, 8));
-  {
-    Timer t(c, GRP_K_RANK, c->f.nblk);
-    hipLaunchKernelGGL(k_rank_chunk_sums, dim3((uint32_t)c->n_chunks), dim3(THREADS), 0, c->stream, c->f.blocks, c->f.nblk, d_chunk_sum);
-    hipLaunchKernelGGL(k_rank_scan_chunks, dim3(1), dim3(1024), 0, c->stream, d_chunk_sum, c->n_chunks, d_chunk_base, c->d_super, d_pop);
-    hipLaunchKernelGGL(k_rank_write, dim3((uint32_t)c->n_chunks), dim3(THREADS), 0, c->stream, c->f.blocks, c->f.nblk, d_chunk_base, c->d_super);
-  }
+  k_bucket_chunk_sums<<<dim3((uint32_t)c->n_chunks), dim3(THREADS), 0, c->stream>>>(c->f.bv, c->f.m, W, c->f.n_buckets, d_chunk_sum);
+  k_scan_chunks<<<dim3(1), dim3(1024), 0, c->stream>>>(d_chunk_sum, c->n_chunks, d_chunk_base, c->d_super, reinterpret_cast<uint64_t*>(d_scalars + 1));
+  k_bucket_write<<<dim3((uint32_t)c->n_chunks), dim3(THREADS), 0, c->stream>>>(c->f.bv, c->f.m, W, c->f.n_buckets, c->f.buckets, d_chunk_base, c->d_super, d_scalars + 2);
+  delete t;
   HIP_TRY(c, hipGetLastError());
-  uint64_t h_pop = 0;
-  HIP_TRY(c, hipMemcpyAsync(&h_pop, d_pop, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(h_scalars, d_scalars, sizeof(h_scalars), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   (void)hipFree(d_chunk_sum);
   (void)hipFree(d_chunk_base);
-  (void)hipFree(d_pop);
-  c->f.pop = h_pop;
-  hipError_t e = hipMalloc(&c->f.idc, std::max<uint64_t>(h_pop, 1) * sizeof(uint2));
-  if (e != hipSuccess) {
-    return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu ID/count pairs failed: %s", (unsigned long long)h_pop, hipGetErrorString(e));
+  (void)hipFree(d_scalars);
+  if (h_scalars[1] != h_pop) {
+    return set_err(c, GRP_ERR_HIP, "internal: bucket scan counted %llu set bits, popcount %llu", h_scalars[1], (unsigned long long)h_pop);
   }
-  HIP_TRY(c, hipMemsetAsync(c->f.idc, 0, std::max<uint64_t>(h_pop, 1) * sizeof(uint2), c->stream));
+  (void)hipFree(c->f.bv); // the bits now live in the buckets
+  c->f.bv = nullptr;
+  c->f.pop = h_pop;
+  e = hipMalloc(&c->f.counts, std::max<uint64_t>(h_pop, 1) * sizeof(uint32_t));
+  if (e != hipSuccess) {
+    return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu insert counts failed: %s", (unsigned long long)h_pop, hipGetErrorString(e));
+  }
+  HIP_TRY(c, hipMemsetAsync(c->f.counts, 0, std::max<uint64_t>(h_pop, 1) * sizeof(uint32_t), c->stream));
+  const uint64_t ovf_cap = next_pow2_64(std::max<uint64_t>(2 * h_scalars[2], 1024));
+  HIP_TRY(c, hipMalloc(&c->f.ovf_keys, ovf_cap * sizeof(unsigned long long)));
+  HIP_TRY(c, hipMalloc(&c->f.ovf_ids, ovf_cap * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemsetAsync(c->f.ovf_keys, 0, ovf_cap * sizeof(unsigned long long), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->f.ovf_ids, 0, ovf_cap * sizeof(uint32_t), c->stream));
+  c->f.ovf_mask = ovf_cap - 1;
+  c->n_ovf = h_scalars[2];
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->finalized = true;
   if (pop) {
@@ -1511,7 +1666,12 @@ grp_reset_ids(grp_ctx* c)
     return set_err(c, GRP_ERR_STATE, "grp_reset_ids before grp_finalize");
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemsetAsync(c->f.idc, 0, std::max<uint64_t>(c->f.pop, 1) * sizeof(uint2), c->stream));
+  const uint64_t n4 = c->f.n_buckets * 4;
+  k_reset_bucket_ids<<<dim3((uint32_t)((n4 + THREADS - 1) / THREADS)), dim3(THREADS), 0, c->stream>>>(c->f.buckets, c->f.n_buckets);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemsetAsync(c->f.counts, 0, std::max<uint64_t>(c->f.pop, 1) * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->f.ovf_keys, 0, (c->f.ovf_mask + 1) * sizeof(unsigned long long), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->f.ovf_ids, 0, (c->f.ovf_mask + 1) * sizeof(uint32_t), c->stream));
   return GRP_OK;
 }
 
@@ -1546,9 +1706,17 @@ grp_export_bits(grp_ctx* c, uint64_t* words, uint64_t n_words)
     return set_err(c, GRP_ERR_INVALID, "grp_export_bits: n_words must be ceil(m/64)");
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  unsigned long long* d = nullptr;
-  HIP_TRY(c, hipMalloc(&d, n_words * 8));
-  hipLaunchKernelGGL(k_export_bits, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, c->stream, c->f.blocks, c->f.m, n_words, d);
+  memset(words, 0, n_words * 8);
+  if (!c->finalized) {
+    // phase 1: the device words ARE the sdsl layout (little-endian 32-bit halves)
+    HIP_TRY(c, hipMemcpyAsync(words, c->f.bv, c->n_bv_words * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GRP_OK;
+  }
+  uint32_t* d = nullptr;
+  HIP_TRY(c, hipMalloc(&d, (n_words * 2 + 3) * 4));
+  HIP_TRY(c, hipMemsetAsync(d, 0, (n_words * 2 + 3) * 4, c->stream));
+  k_export_bits<<<dim3((uint32_t)((c->f.n_buckets + 255) / 256)), dim3(256), 0, c->stream>>>(c->f.buckets, c->f.n_buckets, c->f.W, d);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(words, d, n_words * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1601,7 +1769,7 @@ grp_export_ids(grp_ctx* c, uint64_t first, uint64_t n, uint32_t* ids, uint32_t* 
   uint32_t *d_ids = nullptr, *d_cnt = nullptr;
   HIP_TRY(c, hipMalloc(&d_ids, n * 4));
   HIP_TRY(c, hipMalloc(&d_cnt, n * 4));
-  hipLaunchKernelGGL(k_split_idc, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->f.idc, first, n, d_ids, d_cnt);
+  k_export_ids<<<dim3((uint32_t)((c->f.n_buckets + 255) / 256)), dim3(256), 0, c->stream>>>(c->f, first, n, d_ids, d_cnt);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(counts, d_cnt, n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1630,7 +1798,7 @@ grp_import_ids(grp_ctx* c, uint64_t first, uint64_t n, const uint32_t* ids, cons
     HIP_TRY(c, hipMalloc(&d_cnt, n * 4));
     HIP_TRY(c, hipMemcpyAsync(d_cnt, counts, n * 4, hipMemcpyHostToDevice, c->stream));
   }
-  hipLaunchKernelGGL(k_merge_idc, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->f.idc, first, n, d_ids, d_cnt);
+  k_import_ids<<<dim3((uint32_t)((c->f.n_buckets + 255) / 256)), dim3(256), 0, c->stream>>>(c->f, first, n, d_ids, d_cnt);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   (void)hipFree(d_ids);

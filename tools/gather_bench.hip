@@ -1,0 +1,80 @@
+// Micro-benchmark: random-gather ceilings of one MI355X for the access shapes
+// of the miBF probe (calibration for the roofline discussion in DESIGN.md).
+//   mode 0: independent random 16-B loads          (one sector per load)
+//   mode 1: independent random 4-B loads
+//   mode 2: two DEPENDENT random loads per item: 16 B from table A (small),
+//           then 4/8 B from table B (large) at an index derived from the first
+//   mode 3: like 2 but UNR items in flight per lane
+// usage: gather_bench <tableA_MiB> <tableB_MiB> <items_per_lane> <mode>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+__device__ inline uint64_t mix64(uint64_t x) { x += 0x9E3779B97F4A7C15ULL; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; return x ^ (x >> 31); }
+
+template<int UNR>
+__global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ A, uint64_t nA, const uint2* __restrict__ B, uint64_t nB, int items, int mode, uint64_t* __restrict__ out)
+{
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t acc = 0;
+  for (int it = 0; it < items; it += UNR) {
+    uint64_t ia[UNR];
+    uint4 va[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      ia[u] = mix64(gid * 1315423911ULL + (uint64_t)(it + u) * 0x9E3779B97F4A7C15ULL);
+    }
+    if (mode == 0) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) va[u] = A[ia[u] % nA];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += va[u].x + va[u].w;
+    } else if (mode == 1) {
+      uint32_t v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = reinterpret_cast<const uint32_t*>(B)[ia[u] % (nB * 2)];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += v[u];
+    } else {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) va[u] = A[ia[u] % nA];
+      uint32_t v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        uint64_t ib = (ia[u] ^ ((uint64_t)va[u].x << 7) ^ va[u].y) % nB; // depends on the first load
+        v[u] = B[ib].x;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += v[u];
+    }
+  }
+  if (acc == 0x123456789ULL) out[0] = acc;
+}
+
+int main(int argc, char** argv)
+{
+  uint64_t aMiB = argc > 1 ? atoll(argv[1]) : 512, bMiB = argc > 2 ? atoll(argv[2]) : 20480;
+  int items = argc > 3 ? atoi(argv[3]) : 64, mode = argc > 4 ? atoi(argv[4]) : 2, unr = argc > 5 ? atoi(argv[5]) : 4;
+  int wgs = argc > 6 ? atoi(argv[6]) : 256 * 8 * 4;
+  uint64_t nA = aMiB * (1ull << 20) / 16, nB = bMiB * (1ull << 20) / 8;
+  uint4* A; uint2* B; uint64_t* out;
+  CK(hipMalloc(&A, nA * 16)); CK(hipMalloc(&B, nB * 8)); CK(hipMalloc(&out, 8));
+  CK(hipMemset(A, 1, nA * 16)); CK(hipMemset(B, 2, nB * 8));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(e0));
+    if (unr == 1) k_gather<1><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
+    else if (unr == 2) k_gather<2><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
+    else if (unr == 4) k_gather<4><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
+    else if (unr == 8) k_gather<8><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
+    else k_gather<16><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double n = (double)wgs * 256 * items;
+    if (rep == 2) printf("mode %d A=%lluMiB B=%lluMiB unr=%d wgs=%d: %.2f ms, %.2f G items/s, %.2f G sector-loads/s -> %.2f TB/s at 64 B/sector\n", mode, (unsigned long long)aMiB, (unsigned long long)bMiB, unr, wgs, ms, n / ms / 1e6, n * (mode >= 2 ? 2 : 1) / ms / 1e6, n * (mode >= 2 ? 2 : 1) * 64 / ms / 1e9);
+  }
+  return 0;
+}
