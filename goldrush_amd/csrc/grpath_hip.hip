@@ -51,6 +51,10 @@ struct grp_ctx
   uint64_t nsb = 0;      // superbuckets
   uint64_t n_bv_words = 0;
   uint64_t n_ovf = 0;    // IDs living in the overflow table
+  uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
+  uint32_t* d_flag_idx = nullptr;
+  uint64_t d_flag_cap = 0;
+  uint64_t n_flagged_tiles = 0; // statistics
   uint64_t n_chunks = 0; // rank-build chunks
   uint64_t* d_super = nullptr;
   bool finalized = false;
@@ -74,9 +78,6 @@ struct grp_ctx
   std::vector<EventPair> free_events;
   grp_kernel_stat kstat[GRP_K_COUNT]{};
   mutable std::string err;
-  // LDS geometry of the query kernel
-  uint32_t hist_cap = 0; // power of two
-  uint32_t list_cap_lds = 0;
 };
 
 struct grp_reads
@@ -464,14 +465,72 @@ k_reset_bucket_ids(uint4* __restrict__ buckets, uint64_t n_buckets)
   }
 }
 
+// ---- quad exchange (DPP) ------------------------------------------------------------
+
+// value of quad lane G in every lane of the quad (v_mov_b32 dpp quad_perm:[G,G,G,G])
+template<int G>
+__device__ inline uint32_t
+quad_bcast(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, G * 0x55, 0xF, 0xF, true);
+}
+
+template<int G>
+__device__ inline uint64_t
+quad_bcast64(uint64_t v)
+{
+  return (uint64_t)quad_bcast<G>((uint32_t)v) | ((uint64_t)quad_bcast<G>((uint32_t)(v >> 32)) << 32);
+}
+
+struct QuadAnswer
+{
+  uint32_t bit; // filter bit of the probe
+  uint32_t lr;  // set bits below it inside its bucket
+  uint32_t id;  // ID slot min(lr, 12) of the bucket
+  uint32_t rel; // bucket's relative rank (for the overflow table)
+};
+
+// Round G: `piece` is this lane's 16 bytes of the bucket probed by quad lane G,
+// `off` this lane's OWN bit offset (lane G's is broadcast).  Every lane of the
+// quad computes lane G's answer; lane G keeps it.
+template<int G>
+__device__ inline QuadAnswer
+quad_answer(const uint4& piece, uint32_t off, uint32_t quad_base)
+{
+  const uint32_t o = quad_bcast<G>(off);
+  // header words live in quad lane 0: {rel, bitmap lo, bitmap hi, ids[0]}
+  const uint64_t bm = (uint64_t)quad_bcast<0>(piece.y) | ((uint64_t)quad_bcast<0>(piece.z) << 32);
+  QuadAnswer a;
+  a.rel = quad_bcast<0>(piece.x);
+  a.bit = (uint32_t)((bm >> o) & 1ull);
+  a.lr = grp_local_rank(bm, o);
+  const uint32_t slot = 3u + min(a.lr, GRP_BUCKET_IDS - 1u); // dword index inside the bucket
+  const uint32_t comp = slot & 3u;
+  const uint32_t word = (comp == 0u) ? piece.x : (comp == 1u) ? piece.y : (comp == 2u) ? piece.z : piece.w;
+  a.id = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((quad_base + (slot >> 2)) << 2), (int)word);
+  return a;
+}
+
 // ---- query -------------------------------------------------------------------------
 
+// per-tile count table in LDS: open addressing, key = ID (0 = empty).  An
+// insert is only attempted while fewer than `limit` distinct IDs are stored
+// (limit <= capacity - THREADS*H - 1, so concurrent claims can never fill the
+// table and probing always terminates); otherwise the tile is flagged and
+// recomputed by the full-capacity launch.
 __device__ inline void
-hist_add(uint32_t* keys, uint32_t* cnts, uint32_t mask, uint32_t id)
+hist_add(uint32_t* keys, uint32_t* cnts, uint32_t mask, uint32_t id, uint32_t* sDistinct, uint32_t limit, uint32_t* sOverflow)
 {
+  if (*reinterpret_cast<volatile uint32_t*>(sDistinct) >= limit) {
+    *sOverflow = 1u;
+    return;
+  }
   uint32_t slot = (id * 2654435761u) & mask;
   for (;;) {
     uint32_t old = atomicCAS(&keys[slot], 0u, id);
+    if (old == 0u) {
+      atomicAdd(sDistinct, 1u);
+    }
     if (old == 0u || old == id) {
       atomicAdd(&cnts[slot], 1u);
       return;
@@ -488,14 +547,40 @@ better(uint32_t c, uint32_t id, uint32_t bc, uint32_t bid)
   return (c > bc) || (c == bc && c != 0u && id < bid);
 }
 
-template<int H, int FR>
+// WT > 0: every seed has weight WT (make_seed_pattern's seeds do) and the care
+// loop is fully unrolled; WT == 0: run-time weights
+template<int WT>
+__device__ inline uint64_t
+seed_hash_t(const ulonglong2* sTab, const DevSeeds* __restrict__ sd, uint32_t s, uint64_t w)
+{
+  if constexpr (WT == 0) {
+    return seed_hash(sTab, sd, s, w);
+  } else {
+    uint64_t fwd = 0, rev = 0;
+    const ulonglong2* t = sTab + (size_t)s * WT * 4u;
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)WT; ++i) {
+      const uint32_t b = (uint32_t)(w >> sd->shift[s][i]) & 3u;
+      const ulonglong2 e = t[i * 4u + b];
+      fwd ^= e.x;
+      rev ^= e.y;
+    }
+    return fwd + rev;
+  }
+}
+
+#define GRP_TILE_FLAGGED 0xFFFFFFFFu
+
+template<int H, int FR, int WT>
 __global__ void __launch_bounds__(THREADS)
 k_query(DevFilter f,
         DevReads rd,
         const DevSeeds* __restrict__ sd,
         uint32_t tile_len,
         uint64_t tile_begin,
+        const uint32_t* __restrict__ tile_idx, // NULL: tile = tile_begin + blockIdx.x
         uint32_t hist_cap,
+        uint32_t distinct_limit,
         uint32_t list_cap_lds,
         grp_tile_summary* __restrict__ tiles_out,
         grp_id_count* __restrict__ lists_out,
@@ -508,12 +593,12 @@ k_query(DevFilter f,
   uint32_t* sCnts = sKeys + hist_cap;
   grp_id_count* sList = reinterpret_cast<grp_id_count*>(sCnts + hist_cap);
   uint32_t* sBases = reinterpret_cast<uint32_t*>(sList + list_cap_lds);
-  __shared__ uint32_t sListN;
-  __shared__ uint32_t sRed[3 * (THREADS / 64)];
+  __shared__ uint32_t sListN, sDistinct, sOverflow, sListOff;
+  __shared__ uint32_t sRed[2 * (THREADS / 64)];
   __shared__ uint32_t sBest[2 * (THREADS / 64)];
-  __shared__ uint32_t sListOff;
 
-  const uint64_t t = tile_begin + blockIdx.x;
+  const uint32_t out_idx = tile_idx ? tile_idx[blockIdx.x] : blockIdx.x;
+  const uint64_t t = tile_begin + out_idx;
   const uint32_t r = rd.tile_read[t];
   const uint32_t ti = (uint32_t)(t - rd.tile0[r]);
   const uint32_t len = rd.len[r];
@@ -531,78 +616,86 @@ k_query(DevFilter f,
   }
   if (threadIdx.x == 0) {
     sListN = 0;
+    sDistinct = 0;
+    sOverflow = 0;
   }
   __syncthreads();
 
   const uint32_t hmask = hist_cap - 1u;
   uint32_t n_hit = 0, n_miss = 0;
+  uint32_t last[H];
+#pragma unroll
+  for (int s = 0; s < H; ++s) {
+    // a seed that can no longer roll keeps its last value
+    // (multiLensfrHashIterator.hpp:49-68): its frame index is clamped
+    last[s] = Lp - sd->span[s];
+  }
+  const uint32_t sub = threadIdx.x & 3u;         // my 16-byte piece of a bucket
+  const uint32_t quad_base = (threadIdx.x & 63u) & ~3u;
 
-  for (uint32_t f0 = threadIdx.x; f0 < frames; f0 += THREADS * FR) {
-    Probe pr[FR][H];
-    uint4 hd[FR][H];
-    // 1) hashes -> positions -> bucket header loads (one 64-byte sector per probe)
+  // Every lane owns FR frames per pass; the 64-byte bucket of each probe is
+  // read by the lane's quad with ONE coalesced access (4 x 16 B) and the bitmap /
+  // ID slot are exchanged inside the quad with DPP / bpermute.  Random 16-byte
+  // loads issued per lane run at ~27 G/s on MI355X, quad-coalesced bucket reads
+  // at ~48 G buckets/s (tools/gather_bench.hip modes 7 / 10).
+  const uint32_t passes = (frames + THREADS * FR - 1u) / (THREADS * FR);
+  for (uint32_t pass = 0; pass < passes; ++pass) {
+    uint64_t bk[FR][H];
+    uint32_t off[FR][H];
+    uint4 piece[FR][H][4];
+    // 1) hashes -> positions.  Frames past the end recompute the last frame: all
+    //    lanes stay active (the quad exchange needs them) and all addresses valid
 #pragma unroll
     for (int j = 0; j < FR; ++j) {
-      const uint32_t fr = f0 + j * THREADS;
-      const bool live = fr < frames;
+      const uint32_t fr = min((pass * FR + j) * THREADS + threadIdx.x, frames - 1u);
 #pragma unroll
       for (int s = 0; s < H; ++s) {
-        // a seed that can no longer roll keeps its last value
-        // (multiLensfrHashIterator.hpp:49-68): clamp its frame index
-        const uint32_t last = Lp - sd->span[s];
-        const uint32_t fs = min(fr, last);
-        uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + (live ? fs : 0u)));
-        pr[j][s] = grp_locate(f, hv);
+        const uint64_t hv = seed_hash_t<WT>(sTab, sd, s, window_at(sBases, boff + min(fr, last[s])));
+        const Probe p = grp_locate(f, hv);
+        bk[j][s] = p.b;
+        off[j][s] = p.off;
       }
     }
+    // 2) round g: the quad reads the bucket of its lane g's probe
 #pragma unroll
     for (int j = 0; j < FR; ++j) {
-      const bool live = (f0 + j * THREADS) < frames;
 #pragma unroll
       for (int s = 0; s < H; ++s) {
-        hd[j][s] = live ? f.buckets[pr[j][s].b * 4] : make_uint4(0, 0, 0, 0);
+        piece[j][s][0] = f.buckets[quad_bcast64<0>(bk[j][s]) * 4 + sub];
+        piece[j][s][1] = f.buckets[quad_bcast64<1>(bk[j][s]) * 4 + sub];
+        piece[j][s][2] = f.buckets[quad_bcast64<2>(bk[j][s]) * 4 + sub];
+        piece[j][s][3] = f.buckets[quad_bcast64<3>(bk[j][s]) * 4 + sub];
       }
     }
-    // 2) bit + local rank -> ID (same sector; slot 0 came with the header)
-    uint32_t idv[FR][H];
-    bool all_set[FR];
+    // 3) bit test + ID slot, exchanged inside the quad; per-frame ID set -> tile count table
 #pragma unroll
     for (int j = 0; j < FR; ++j) {
-      const bool live = (f0 + j * THREADS) < frames;
+      const bool live = ((pass * FR + j) * THREADS + threadIdx.x) < frames;
       bool all = live;
-      uint32_t lr[H];
+      uint32_t idv[H];
 #pragma unroll
       for (int s = 0; s < H; ++s) {
-        const uint64_t bm = grp_bitmap(hd[j][s]);
-        all = all && ((bm >> pr[j][s].off) & 1ull);
-        lr[s] = grp_local_rank(bm, pr[j][s].off);
-      }
-      all_set[j] = all; // atRank (MIBloomFilter.hpp:465-476)
-#pragma unroll
-      for (int s = 0; s < H; ++s) {
-        uint32_t v = hd[j][s].w; // getData (:614-621)
-        if (all && lr[s] != 0u) {
-          if (lr[s] < GRP_BUCKET_IDS) {
-            v = reinterpret_cast<const uint32_t*>(f.buckets)[pr[j][s].b * 16 + 3 + lr[s]];
-          } else {
-            v = grp_ovf_get(f, f.super[pr[j][s].b >> GRP_SUPER_SHIFT] + hd[j][s].x + lr[s]);
-          }
+        QuadAnswer a0 = quad_answer<0>(piece[j][s][0], off[j][s], quad_base);
+        QuadAnswer a1 = quad_answer<1>(piece[j][s][1], off[j][s], quad_base);
+        QuadAnswer a2 = quad_answer<2>(piece[j][s][2], off[j][s], quad_base);
+        QuadAnswer a3 = quad_answer<3>(piece[j][s][3], off[j][s], quad_base);
+        const QuadAnswer mine = (sub == 0) ? a0 : (sub == 1) ? a1 : (sub == 2) ? a2 : a3;
+        all = all && mine.bit; // atRank (MIBloomFilter.hpp:465-476)
+        uint32_t d = mine.id;  // getData (:614-621)
+        if (mine.lr >= GRP_BUCKET_IDS && live) { // 14th.. set bit of its bucket: rare side table
+          d = grp_ovf_get(f, f.super[bk[j][s] >> GRP_SUPER_SHIFT] + mine.rel + mine.lr);
         }
-        idv[j][s] = all ? v : 0u;
+        idv[s] = d;
       }
-    }
-    // 3) per-frame ID set -> tile count table
-#pragma unroll
-    for (int j = 0; j < FR; ++j) {
-      if (!all_set[j]) {
+      if (!all) {
         continue;
       }
       uint32_t ids[H];
 #pragma unroll
       for (int s = 0; s < H; ++s) {
-        uint32_t d = idv[j][s];
+        const uint32_t d = idv[s];
         // saturation bit stripped exactly as goldrush_path.cpp:573-594
-        uint32_t id = (d > 0x80000000u) ? (d & 0x7FFFFFFFu) : d;
+        const uint32_t id = (d > 0x80000000u) ? (d & 0x7FFFFFFFu) : d;
         if (id == 0u) {
           ++n_miss;
         } else {
@@ -615,7 +708,7 @@ k_query(DevFilter f,
         }
         ids[s] = id;
         if (id != 0u && !dup) {
-          hist_add(sKeys, sCnts, hmask, id);
+          hist_add(sKeys, sCnts, hmask, id, &sDistinct, distinct_limit, &sOverflow);
         }
       }
     }
@@ -656,8 +749,8 @@ k_query(DevFilter f,
   if ((threadIdx.x & 63) == 0) {
     sBest[2 * wave] = bc;
     sBest[2 * wave + 1] = bid;
-    sRed[3 * wave] = n_hit;
-    sRed[3 * wave + 1] = n_miss;
+    sRed[2 * wave] = n_hit;
+    sRed[2 * wave + 1] = n_miss;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -667,26 +760,30 @@ k_query(DevFilter f,
         bc = sBest[2 * w];
         bid = sBest[2 * w + 1];
       }
-      hsum += sRed[3 * w];
-      msum += sRed[3 * w + 1];
+      hsum += sRed[2 * w];
+      msum += sRed[2 * w + 1];
     }
     const uint32_t n = sListN;
+    const bool flagged = sOverflow != 0u || n > list_cap_lds;
     uint64_t lo = 0;
-    if (n) {
+    if (n && !flagged) {
       lo = atomicAdd(&ctr[3], (unsigned long long)n);
     }
     sListOff = (uint32_t)lo;
+    if (flagged) {
+      sListN = 0; // nothing is copied out; the full-capacity launch redoes this tile
+    }
     grp_tile_summary ts;
     ts.top_id = bid;
     ts.top_count = bc;
     ts.list_off = (uint32_t)lo;
-    ts.list_n = n;
+    ts.list_n = flagged ? GRP_TILE_FLAGGED : n;
     ts.hits = hsum;
     ts.misses = msum;
-    tiles_out[blockIdx.x] = ts;
+    tiles_out[out_idx] = ts;
   }
   __syncthreads();
-  const uint32_t n = min(sListN, list_cap_lds);
+  const uint32_t n = sListN;
   const uint64_t lo = sListOff;
   for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
     if (lo + i < lists_cap) {
@@ -1029,17 +1126,60 @@ ensure_lds(grp_ctx* c, K kernel, size_t bytes)
     default: { constexpr int HH = 8; CALL; } break;                                                                    \
   }
 
+struct QueryGeom
+{
+  uint32_t hist_cap;
+  uint32_t distinct_limit;
+  uint32_t list_cap_lds;
+  size_t lds;
+};
+
+// full = worst case (every probe of the tile a different ID); small = the common
+// case at a fraction of the LDS (more workgroups per CU); flagged tiles are redone
+QueryGeom
+query_geom(const grp_ctx* c, bool full)
+{
+  const uint32_t h = c->params.h, tile = c->params.tile;
+  const uint64_t max_ids = (uint64_t)tile * h;
+  QueryGeom g;
+  const uint32_t cap_full = next_pow2(max_ids + (uint64_t)THREADS * h + 2);
+  if (full || cap_full <= 2048) {
+    g.hist_cap = cap_full;
+    g.list_cap_lds = (uint32_t)(max_ids / 3 + 1);
+  } else {
+    g.hist_cap = 2048;
+    g.list_cap_lds = 256;
+  }
+  g.distinct_limit = g.hist_cap - THREADS * h - 1;
+  g.lds = tab_bytes(c) + (size_t)g.hist_cap * 8 + (size_t)g.list_cap_lds * 8 + bases_bytes(tile + c->params.k + h);
+  return g;
+}
+
 template<int HH>
 int
-launch_query(grp_ctx* c, const grp_reads* r, uint64_t nt, uint64_t t0, uint64_t list_cap, size_t lds)
+launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, const uint32_t* d_tile_idx, const QueryGeom& g, uint64_t list_cap)
 {
-  auto kern = k_query<HH, 2>;
-  int rc = ensure_lds(c, kern, lds);
-  if (rc != GRP_OK) {
-    return rc;
+  auto go = [&](auto kern) -> int {
+    int rc = ensure_lds(c, kern, g.lds);
+    if (rc != GRP_OK) {
+      return rc;
+    }
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, c->d_tiles, c->d_lists, list_cap, reinterpret_cast<unsigned long long*>(c->d_qctr));
+    return GRP_OK;
+  };
+  // 2 frames per lane and pass: 2*H*4 quad reads in flight per lane (measured best on MI355X)
+  if constexpr (HH == 3) {
+    // tuning hook (developer only): GRP_QUERY_VARIANT = "<frames per lane>,<unrolled weight>"
+    static const char* v = getenv("GRP_QUERY_VARIANT");
+    if (v) {
+      const std::string sv(v);
+      if (sv == "1,0") return go(k_query<HH, 1, 0>);
+      if (sv == "4,0") return go(k_query<HH, 4, 0>);
+      if (sv == "2,16" && c->uniform_weight == 16) return go(k_query<HH, 2, 16>);
+      if (sv == "1,16" && c->uniform_weight == 16) return go(k_query<HH, 1, 16>);
+    }
   }
-  kern<<<dim3((uint32_t)nt), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, c->hist_cap, c->list_cap_lds, c->d_tiles, c->d_lists, list_cap, reinterpret_cast<unsigned long long*>(c->d_qctr));
-  return GRP_OK;
+  return go(k_query<HH, 2, 0>);
 }
 
 int
@@ -1077,6 +1217,12 @@ build_seed_tables(grp_ctx* c)
   }
   if (sd.wmax == 0) {
     return set_err(c, GRP_ERR_INVALID, "seeds have weight 0");
+  }
+  c->uniform_weight = sd.wmax;
+  for (uint32_t s2 = 0; s2 < sd.h; ++s2) {
+    if (sd.weight[s2] != sd.wmax) {
+      c->uniform_weight = 0;
+    }
   }
   return GRP_OK;
 }
@@ -1139,15 +1285,13 @@ grp_create(const grp_params* p, grp_ctx** out)
   if (rc != GRP_OK) {
     return fail(rc);
   }
-  // LDS geometry of the query kernel: count table sized so that even
-  // tile*h distinct IDs fit at load <= 0.75; list bound = floor(tile*h/3)
-  uint64_t max_ids = (uint64_t)p->tile * p->h;
-  c->hist_cap = next_pow2((max_ids * 4 + 2) / 3);
-  c->list_cap_lds = (uint32_t)(max_ids / 3 + 1);
-  size_t lds = tab_bytes(c) + (size_t)c->hist_cap * 8 + (size_t)c->list_cap_lds * 8 + bases_bytes(p->tile + p->k + p->h);
-  if (lds > 160 * 1024 - 256) {
-    set_err(c, GRP_ERR_INVALID, "tile*h=%llu needs %zu B of LDS per workgroup (limit 160 KiB)", (unsigned long long)max_ids, lds);
-    return fail(GRP_ERR_INVALID);
+  // LDS geometry of the query kernel's worst-case launch must fit one workgroup
+  {
+    const QueryGeom g = query_geom(c, true);
+    if (g.lds > 160 * 1024 - 512) {
+      set_err(c, GRP_ERR_INVALID, "tile*h=%llu needs %zu B of LDS per workgroup (limit 160 KiB)", (unsigned long long)p->tile * p->h, g.lds);
+      return fail(GRP_ERR_INVALID);
+    }
   }
 #define CREATE_TRY(expr)                                                                                               \
   do {                                                                                                                 \
@@ -1210,6 +1354,7 @@ grp_destroy(grp_ctx* c)
     (void)hipHostFree(c->h_lists);
   }
   (void)hipFree(c->d_dedup);
+  (void)hipFree(c->d_flag_idx);
   if (c->stream) {
     (void)hipStreamDestroy(c->stream);
   }
@@ -1540,7 +1685,6 @@ grp_query_tiles(grp_ctx* c,
     HIP_TRY(c, hipHostMalloc(&c->h_tiles, cap * sizeof(grp_tile_summary), hipHostMallocDefault));
     c->h_tiles_cap = cap;
   }
-  const size_t lds = tab_bytes(c) + (size_t)c->hist_cap * 8 + (size_t)c->list_cap_lds * 8 + bases_bytes(c->params.tile + c->params.k + c->params.h);
   uint64_t probes = 0;
   {
     const uint32_t tile = c->params.tile, k = c->params.k;
@@ -1555,25 +1699,69 @@ grp_query_tiles(grp_ctx* c,
       probes += ((uint64_t)(ntile - 1) * tile + (Lp - k + 1)) * c->params.h;
     }
   }
+  const uint64_t prefix = std::min<uint64_t>(list_cap, LIST_PREFIX);
+  // one round trip: counters, tile summaries and the first LIST_PREFIX list
+  // entries come back together; the arena cursor is re-zeroed for the next call
+  auto fetch = [&]() -> int {
+    HIP_TRY(c, hipMemcpyAsync(c->h_qctr, c->d_qctr, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_tiles, c->d_tiles, nt * sizeof(grp_tile_summary), hipMemcpyDeviceToHost, c->stream));
+    if (prefix) {
+      HIP_TRY(c, hipMemcpyAsync(c->h_lists, c->d_lists, prefix * sizeof(grp_id_count), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GRP_OK;
+  };
   {
+    const QueryGeom g = query_geom(c, false);
     Timer t(c, GRP_K_QUERY, probes);
     int lrc = GRP_OK;
-    DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, nt, t0, list_cap, lds));
+    DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, nt, t0, nullptr, g, list_cap));
     if (lrc != GRP_OK) {
       return lrc;
     }
   }
   HIP_TRY(c, hipGetLastError());
-  // one round trip: counters, tile summaries and the first LIST_PREFIX list
-  // entries come back together; the arena cursor is re-zeroed for the next call
-  const uint64_t prefix = std::min<uint64_t>(list_cap, LIST_PREFIX);
-  HIP_TRY(c, hipMemcpyAsync(c->h_qctr, c->d_qctr, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->h_tiles, c->d_tiles, nt * sizeof(grp_tile_summary), hipMemcpyDeviceToHost, c->stream));
-  if (prefix) {
-    HIP_TRY(c, hipMemcpyAsync(c->h_lists, c->d_lists, prefix * sizeof(grp_id_count), hipMemcpyDeviceToHost, c->stream));
+  int frc = fetch();
+  if (frc != GRP_OK) {
+    return frc;
   }
-  HIP_TRY(c, hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // tiles whose ID set did not fit the small LDS table: redo them with the
+  // worst-case geometry (same kernel, same arithmetic)
+  std::vector<uint32_t> flagged;
+  for (uint64_t i = 0; i < nt; ++i) {
+    if (c->h_tiles[i].list_n == GRP_TILE_FLAGGED) {
+      flagged.push_back((uint32_t)i);
+    }
+  }
+  if (!flagged.empty()) {
+    c->n_flagged_tiles += flagged.size();
+    if (flagged.size() > c->d_flag_cap) {
+      (void)hipFree(c->d_flag_idx);
+      c->d_flag_idx = nullptr;
+      c->d_flag_cap = 0;
+      HIP_TRY(c, hipMalloc(&c->d_flag_idx, flagged.size() * 4 * 2));
+      c->d_flag_cap = flagged.size() * 2;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_flag_idx, flagged.data(), flagged.size() * 4, hipMemcpyHostToDevice, c->stream));
+    // continue the list arena where the first launch stopped
+    uint64_t cursor[4] = { 0, 0, 0, c->h_qctr[3] };
+    HIP_TRY(c, hipMemcpyAsync(c->d_qctr, cursor, sizeof(cursor), hipMemcpyHostToDevice, c->stream));
+    {
+      const QueryGeom g = query_geom(c, true);
+      Timer t(c, GRP_K_QUERY, 0);
+      int lrc = GRP_OK;
+      DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, flagged.size(), t0, c->d_flag_idx, g, list_cap));
+      if (lrc != GRP_OK) {
+        return lrc;
+      }
+    }
+    HIP_TRY(c, hipGetLastError());
+    frc = fetch();
+    if (frc != GRP_OK) {
+      return frc;
+    }
+  }
   drain_events(c);
   memcpy(tiles_out, c->h_tiles, nt * sizeof(grp_tile_summary));
   const uint64_t used = c->h_qctr[3];
@@ -1637,6 +1825,7 @@ grp_insert_tiles(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t til
   if (want > c->dedup_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_dedup);
+  (void)hipFree(c->d_flag_idx);
     c->d_dedup = nullptr;
     c->dedup_cap = 0;
     HIP_TRY(c, hipMalloc(&c->d_dedup, want * 8));

@@ -38,6 +38,64 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ A, uin
       for (int u = 0; u < UNR; ++u) v[u] = reinterpret_cast<const uint32_t*>(B)[ia[u] % (nB * 2)];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) acc += v[u];
+    } else if (mode == 8) { // 8-B header, then a DEPENDENT 4-B slot of the same 64-B bucket
+      const uint64_t nb = nA / 4;
+      uint2 h2[UNR];
+      uint32_t v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) h2[u] = reinterpret_cast<const uint2*>(A)[(ia[u] % nb) * 8];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = reinterpret_cast<const uint32_t*>(A)[(ia[u] % nb) * 16 + 2 + ((h2[u].y ^ ia[u]) % 14)];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += h2[u].x + v[u];
+    } else if (mode == 9 || mode == 10) {
+      // cooperative: G lanes read one whole 64-B bucket with one coalesced access;
+      // every lane still owns `items` probes, processed G at a time via shuffles
+      const int G = (mode == 9) ? 8 : 4;
+      const uint64_t nb = nA / 4;
+      const int lane = threadIdx.x & 63;
+      const int sub = lane % G;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        for (int g = 0; g < G; ++g) {
+          // the probe of lane (group base + g)
+          const uint64_t idx = __shfl(ia[u], (lane / G) * G + g, 64) % nb;
+          if (mode == 9) {
+            uint2 t = reinterpret_cast<const uint2*>(A)[idx * 8 + sub];
+            const uint32_t want = (uint32_t)(idx >> 3) % 8u;
+            uint32_t got = __shfl(t.y, (lane / G) * G + want, 64);
+            if (sub == g) acc += got + t.x;
+          } else {
+            uint4 t = A[idx * 4 + sub];
+            const uint32_t want = (uint32_t)(idx >> 3) % 4u;
+            uint32_t got = __shfl(t.w, (lane / G) * G + want, 64);
+            if (sub == g) acc += got + t.x;
+          }
+        }
+      }
+    } else if (mode == 4 || mode == 5 || mode == 6 || mode == 7) {
+      // bucket-shaped accesses on table A viewed as 64-byte buckets
+      const uint64_t nb = nA / 4;
+      uint32_t v[UNR];
+      if (mode == 4) { // 16-B header, then a DEPENDENT 4-B slot of the same 64-B bucket
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) va[u] = A[(ia[u] % nb) * 4];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = reinterpret_cast<const uint32_t*>(A)[(ia[u] % nb) * 16 + 3 + ((va[u].y ^ ia[u]) % 13)];
+      } else if (mode == 5) { // header and slot issued together (independent)
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) va[u] = A[(ia[u] % nb) * 4];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = reinterpret_cast<const uint32_t*>(A)[(ia[u] % nb) * 16 + 3 + (ia[u] >> 40) % 13];
+      } else if (mode == 6) { // one 8-B load per bucket
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { uint2 t = reinterpret_cast<const uint2*>(A)[(ia[u] % nb) * 8]; va[u] = make_uint4(t.x, t.y, 0, 0); v[u] = 0; }
+      } else { // one 16-B load per bucket
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { va[u] = A[(ia[u] % nb) * 4]; v[u] = 0; }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += va[u].x + va[u].w + v[u];
     } else {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) va[u] = A[ia[u] % nA];
@@ -74,7 +132,7 @@ int main(int argc, char** argv)
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     double n = (double)wgs * 256 * items;
-    if (rep == 2) printf("mode %d A=%lluMiB B=%lluMiB unr=%d wgs=%d: %.2f ms, %.2f G items/s, %.2f G sector-loads/s -> %.2f TB/s at 64 B/sector\n", mode, (unsigned long long)aMiB, (unsigned long long)bMiB, unr, wgs, ms, n / ms / 1e6, n * (mode >= 2 ? 2 : 1) / ms / 1e6, n * (mode >= 2 ? 2 : 1) * 64 / ms / 1e9);
+    if (rep == 2) printf("mode %d A=%lluMiB B=%lluMiB unr=%d wgs=%d: %.2f ms, %.2f G items/s, %.2f G sector-loads/s -> %.2f TB/s at 64 B/sector\n", mode, (unsigned long long)aMiB, (unsigned long long)bMiB, unr, wgs, ms, n / ms / 1e6, n * ((mode == 2 || mode == 3) ? 2 : 1) / ms / 1e6, n * ((mode == 2 || mode == 3) ? 2 : 1) * 64 / ms / 1e9);
   }
   return 0;
 }
