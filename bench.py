@@ -191,6 +191,15 @@ def main():
         avg_ms = kq["ms"] / max(kq["launches"], 1)
         probes_per_launch = kq["units"] / max(kq["launches"], 1)
         achieved = kq["units"] * 128 / (kq["ms"] * 1e-3) / 1e9 if kq["ms"] > 0 else 0.0
+        # HBM bytes per launch: PMC counters cannot be read from inside this process; the
+        # per-probe figure comes from the committed rocprofv3 --pmc pass of the same kernel
+        # (profiles/r01_v4_pmc_summary.json: TCC_EA0_RDREQ x 64 B = FETCH_SIZE x 1024 B)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_summary.json")))
+            traffic = pmc["k_query<3, 2, 0>"]["hbm_bytes_per_probe"] * probes_per_launch
+        except Exception:
+            pass
         out = {
             "metric": "reads/s through GoldRush-Path (hash + miBF query)",
             "value": reads_done / dt,
@@ -208,7 +217,7 @@ def main():
                        "reads": a.reads, "batch_reads_per_gpu": a.batch, "filter_bits": m, "pop": pop,
                        "parallelism": "each speculative window sharded over %d GPU(s), replicated miBF, decisions all-gathered" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "kernel": "k_query", "launches": kq["launches"], "avg_launch_ms": avg_ms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC pass of the same kernel, scaled by probes)", "kernel": "k_query", "launches": kq["launches"], "avg_launch_ms": avg_ms,
                          "probes_per_launch": probes_per_launch, "bytes_per_probe": 128},
             "aux": {"fill_reads_per_s": a.reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] / t_fill / 1e9, "fill_s": t_fill, "synth_s": t_synth,
                     "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts")},
