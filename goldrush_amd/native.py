@@ -265,6 +265,8 @@ class Engine:
     def query_tiles(self, batch: ReadBatch, first: int = 0, count: int | None = None, list_cap: int | None = None):
         """Returns (tiles[structured], lists[structured], stats dict)."""
         count = batch.n_reads - first if count is None else count
+        if first < 0 or count < 0 or first + count > batch.n_reads:
+            raise GrpError(GRP_ERR_INVALID, f"reads [{first}, {first + count}) outside the batch of {batch.n_reads}")
         nt = int(batch.tile0[first + count] - batch.tile0[first])
         tiles = np.zeros(nt, dtype=tile_summary_dtype)
         cap = list_cap if list_cap is not None else max(4 * nt, 1024)

@@ -179,3 +179,114 @@ def test_errors_are_loud(native):
     eng.finalize()
     with pytest.raises(native.GrpError):
         eng.bv_insert(b)  # bit vector immutable after finalize
+
+
+def test_bucket_overflow_side_table(oracle, native):
+    """Occupancy ~0.2 -> buckets of W~30 bits, some with more than 13 set bits: their
+    14th.. IDs live in the side table; inserts, queries, export and reset must still
+    match the oracle bit for bit."""
+    lib = oracle.load()
+    m = 300_032
+    eng, oseeds, omf, _ = _mk(oracle, native, m=m)
+    reads = random_reads(6, 3000, 5000, seed=61)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    for s in reads:
+        omf.bv_insert_read(s)
+    pop = eng.finalize()
+    assert pop == omf.finalize()
+    assert 0.12 < pop / m < 0.35
+    bits = omf.bits()
+    # at least one 64-bit aligned window of the chosen width holds > 13 set bits
+    assert np.array_equal(eng.export_bits(), bits)
+    rng = np.random.default_rng(3)
+    ids = rng.integers(1, 50, size=pop, dtype=np.uint32)
+    cnt = rng.integers(0, 4, size=pop, dtype=np.uint32)
+    eng.import_ids(0, ids=ids, counts=cnt)
+    omf.ids()[:] = ids
+    omf.counts()[:] = cnt
+    gi, gc = eng.export_ids()
+    assert np.array_equal(gi, ids) and np.array_equal(gc, cnt)
+    _compare_queries(eng, omf, b, reads)
+    for ri in (0, 2, 4):
+        nt = len(reads[ri]) // TILE
+        eng.insert_tiles(b, ri, 0, nt, 1000 + ri)
+        omf.insert_read_tiles(reads[ri], 0, nt, 1000 + ri)
+    gi, gc = eng.export_ids()
+    assert np.array_equal(gi, omf.ids()) and np.array_equal(gc, omf.counts())
+    _compare_queries(eng, omf, b, reads)
+    eng.reset_ids()
+    omf.reset_ids()
+    gi, gc = eng.export_ids()
+    assert not gi.any() and not gc.any()
+    # partial export / import windows
+    eng.import_ids(100, ids=np.arange(1, 51, dtype=np.uint32))
+    gi, _ = eng.export_ids(90, 70)
+    assert gi[:10].sum() == 0 and np.array_equal(gi[10:60], np.arange(1, 51)) and gi[60:].sum() == 0
+
+
+def test_ragged_and_degenerate_batches(oracle, native):
+    """Empty batch, reads shorter than a tile (0 tiles), exactly one tile, one and two
+    tiles (no smoothing), a read whose last tile is clipped to a single frame."""
+    eng, oseeds, omf, m = _mk(oracle, native)
+    empty = eng.upload([])
+    eng.bv_insert(empty)
+    reads = [random_reads(1, n, n, seed=70 + i)[0] for i, n in enumerate((999, 1000, 1021, 1999, 2000, 2021, 2022, 3000 + 21, 500, 24))]
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    for s in reads:
+        omf.bv_insert_read(s)
+    assert eng.finalize() == omf.finalize()
+    assert np.array_equal(eng.export_bits(), omf.bits())
+    tiles, lists, st = eng.query_tiles(empty)
+    assert len(tiles) == 0 and st["queries"] == 0
+    assert [int(x) for x in np.diff(b.tile0)] == [len(r) // TILE for r in reads]
+    for ri in (1, 3, 5, 7):
+        nt = len(reads[ri]) // TILE
+        eng.insert_tiles(b, ri, 0, nt, 10 + ri)
+        omf.insert_read_tiles(reads[ri], 0, nt, 10 + ri)
+    eng.insert_tiles(b, 0, 0, 0, 99)  # empty tile range: no-op
+    _compare_queries(eng, omf, b, reads)
+    # sub-ranges of the batch, including ranges that hold no tile at all
+    t, l, s = eng.query_tiles(b, 8, 2)
+    assert len(t) == 0
+    t, l, s = eng.query_tiles(b, 3, 3)
+    exp = [r for i in (3, 4, 5) for r in omf.query_read(reads[i])]
+    assert [(int(x["top_id"]), int(x["top_count"])) for x in t] == [(e[0], e[1]) for e in exp]
+    with pytest.raises(native.GrpError):
+        eng.query_tiles(b, 5, 50)
+    with pytest.raises(native.GrpError):
+        eng.insert_tiles(b, 1, 0, 5, 1)  # read 1 has one tile
+
+
+def test_max_geometry_h8_span32(oracle, native):
+    """Implementation limits: h = 8 seeds, longest span k + h - 1 = 32."""
+    k, h, tile = 25, 8, 300
+    preset = "1101101110111011101110111"  # 25 wide, palindromic halves not required by the engine
+    half = len(preset) // 2
+    seeds = [preset[:half] + "0" * i + preset[half:half * 2] for i in range(h)]
+    # spans must be k+i with k = 2*half
+    k = 2 * half
+    seeds = [preset[:half] + "0" * i + preset[half:2 * half] for i in range(h)]
+    m = oracle.load().orc_calc_optimal_size(300_000, 1, 0.1)
+    eng = native.Engine(k, h, tile, m, seeds)
+    oseeds = oracle.Seeds(seeds)
+    omf = oracle.MiBF(m, oseeds, tile, k)
+    reads = random_reads(4, 700, 1500, seed=81)
+    b = eng.upload(reads)
+    for ri, seq in enumerate(reads):
+        for t in range(len(seq) // tile):
+            assert np.array_equal(eng.tile_hashes(b, ri, t), oseeds.tile_hashes(seq, tile, k, t))
+    eng.bv_insert(b)
+    for s in reads:
+        omf.bv_insert_read(s)
+    assert eng.finalize() == omf.finalize()
+    assert np.array_equal(eng.export_bits(), omf.bits())
+    eng.insert_tiles(b, 1, 0, len(reads[1]) // tile, 7)
+    omf.insert_read_tiles(reads[1], 0, len(reads[1]) // tile, 7)
+    tiles, lists, st = eng.query_tiles(b)
+    ti = 0
+    for seq in reads:
+        for res in omf.query_read(seq):
+            assert (int(tiles[ti]["top_id"]), int(tiles[ti]["top_count"])) == (res[0], res[1])
+            ti += 1
