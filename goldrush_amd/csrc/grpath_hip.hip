@@ -13,6 +13,7 @@
 //   k_insert      hash -> rank -> exact per-call rank dedup -> reservoir rule
 //                 (MIBFConstructSupport.hpp:247-283)
 #include "grp_device.h"
+#include "host/gr_tiles_core.hpp"
 
 #include "../../include/grpath.h"
 
@@ -54,6 +55,15 @@ struct grp_ctx
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
   uint32_t* d_flag_idx = nullptr;
   uint64_t d_flag_cap = 0;
+  std::vector<uint32_t> h_flagged;
+  // decide scratch
+  uint32_t* d_dec_ids = nullptr;
+  uint8_t* d_dec_asg = nullptr;
+  uint64_t* d_dec_scratch = nullptr;
+  uint64_t d_dec_cap = 0;
+  grp_read_decision* d_dec = nullptr;
+  grp_read_decision* h_dec = nullptr; // pinned
+  uint64_t dec_cap = 0;
   uint64_t n_flagged_tiles = 0; // statistics
   uint64_t n_chunks = 0; // rank-build chunks
   uint64_t* d_super = nullptr;
@@ -585,7 +595,9 @@ k_query(DevFilter f,
         grp_tile_summary* __restrict__ tiles_out,
         grp_id_count* __restrict__ lists_out,
         uint64_t lists_cap,
-        unsigned long long* __restrict__ ctr)
+        unsigned long long* __restrict__ ctr,
+        uint32_t* __restrict__ flagged_out, // indices of flagged tiles (NULL in the redo launch)
+        uint32_t flagged_cap)
 {
   extern __shared__ uint4 smem4[];
   ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
@@ -772,6 +784,10 @@ k_query(DevFilter f,
     sListOff = (uint32_t)lo;
     if (flagged) {
       sListN = 0; // nothing is copied out; the full-capacity launch redoes this tile
+      const unsigned long long fi = atomicAdd(&ctr[4], 1ull);
+      if (flagged_out && fi < flagged_cap) {
+        flagged_out[fi] = out_idx;
+      }
     }
     grp_tile_summary ts;
     ts.top_id = bid;
@@ -788,6 +804,61 @@ k_query(DevFilter f,
   for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
     if (lo + i < lists_cap) {
       lists_out[lo + i] = sList[i];
+    }
+  }
+}
+
+// ---- read decision --------------------------------------------------------------
+
+// One lane per read: threshold + smoothing passes + flank test (the shared
+// host/device core, csrc/host/gr_tiles_core.hpp).  The per-read scratch (ids,
+// flags, 64-bit work array) sits in LDS for reads of up to DECIDE_LDS_TILES tiles
+// and in a global scratch slice otherwise.
+constexpr int DECIDE_THREADS = 64;
+constexpr uint32_t DECIDE_LDS_TILES = 48;
+
+__global__ void __launch_bounds__(DECIDE_THREADS)
+k_decide(DevReads rd,
+         uint32_t first,
+         uint32_t count,
+         grp_decide_params dp,
+         const grp_tile_summary* __restrict__ tiles,
+         const grp_id_count* __restrict__ lists,
+         uint64_t lists_cap,
+         uint32_t* __restrict__ g_ids,
+         uint8_t* __restrict__ g_asg,
+         uint64_t* __restrict__ g_scratch,
+         grp_read_decision* __restrict__ out)
+{
+  __shared__ uint64_t sScratch[DECIDE_THREADS][DECIDE_LDS_TILES];
+  __shared__ uint32_t sIds[DECIDE_THREADS][DECIDE_LDS_TILES];
+  __shared__ uint8_t sAsg[DECIDE_THREADS][DECIDE_LDS_TILES];
+  const uint32_t j = blockIdx.x * DECIDE_THREADS + threadIdx.x;
+  if (j >= count) {
+    return;
+  }
+  const uint64_t t_base = rd.tile0[first];
+  const uint64_t a = rd.tile0[first + j] - t_base;
+  const uint64_t n = rd.tile0[first + j + 1] - rd.tile0[first + j];
+  uint32_t* ids = (n <= DECIDE_LDS_TILES) ? sIds[threadIdx.x] : g_ids + a;
+  uint8_t* asg = (n <= DECIDE_LDS_TILES) ? sAsg[threadIdx.x] : g_asg + a;
+  uint64_t* scratch = (n <= DECIDE_LDS_TILES) ? sScratch[threadIdx.x] : g_scratch + a;
+  grp_read_decision d;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (tiles[a + i].list_n == GRP_TILE_FLAGGED || (uint64_t)tiles[a + i].list_off + tiles[a + i].list_n > lists_cap) {
+      // this window is decided again after the flagged tiles have been redone /
+      // the list arena has been enlarged
+      d = grp_read_decision{};
+      out[j] = d;
+      return;
+    }
+  }
+  gr::core::decide(dp.threshold, dp.unassigned_min, dp.assigned_max, (size_t)n, tiles + a, lists, ids, asg, scratch, d);
+  out[j] = d;
+  if (n <= DECIDE_LDS_TILES) { // keep the per-tile result inspectable (grp_debug_tile_states)
+    for (uint64_t i = 0; i < n; ++i) {
+      g_ids[a + i] = ids[i];
+      g_asg[a + i] = asg[i];
     }
   }
 }
@@ -1164,7 +1235,7 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     if (rc != GRP_OK) {
       return rc;
     }
-    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, c->d_tiles, c->d_lists, list_cap, reinterpret_cast<unsigned long long*>(c->d_qctr));
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, c->d_tiles, c->d_lists, list_cap, reinterpret_cast<unsigned long long*>(c->d_qctr), d_tile_idx ? nullptr : c->d_flag_idx, (uint32_t)c->d_flag_cap);
     return GRP_OK;
   };
   // 2 frames per lane and pass: 2*H*4 quad reads in flight per lane (measured best on MI355X)
@@ -1355,6 +1426,13 @@ grp_destroy(grp_ctx* c)
   }
   (void)hipFree(c->d_dedup);
   (void)hipFree(c->d_flag_idx);
+  (void)hipFree(c->d_dec_ids);
+  (void)hipFree(c->d_dec_asg);
+  (void)hipFree(c->d_dec_scratch);
+  (void)hipFree(c->d_dec);
+  if (c->h_dec) {
+    (void)hipHostFree(c->h_dec);
+  }
   if (c->stream) {
     (void)hipStreamDestroy(c->stream);
   }
@@ -1625,6 +1703,105 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
 
 // ---- query --------------------------------------------------------------------------
 
+} // extern "C"
+
+namespace {
+
+struct QueryRun
+{
+  uint64_t t0 = 0, nt = 0, probes = 0;
+  uint64_t used = 0;    // list arena entries
+  uint64_t flagged = 0; // tiles redone with the worst-case geometry
+};
+
+template<typename T>
+int
+ensure_dev(grp_ctx* c, T*& p, uint64_t& cap, uint64_t want)
+{
+  if (want > cap) {
+    (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const uint64_t n = want + want / 4 + 64;
+    HIP_TRY(c, hipMalloc(&p, n * sizeof(T)));
+    cap = n;
+  }
+  return GRP_OK;
+}
+
+uint64_t
+count_probes(const grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count)
+{
+  const uint32_t tile = c->params.tile, k = c->params.k;
+  uint64_t probes = 0;
+  for (uint32_t i = first; i < first + count; ++i) {
+    const uint32_t ntile = r->len[i] / tile;
+    if (ntile == 0) {
+      continue;
+    }
+    // all tiles but the last have `tile` frames; the last may be clipped
+    const uint32_t start = (ntile - 1) * tile;
+    const uint32_t Lp = std::min(tile + k - 1, r->len[i] - start);
+    probes += ((uint64_t)(ntile - 1) * tile + (Lp - k + 1)) * c->params.h;
+  }
+  return probes;
+}
+
+// Enqueue the query kernel for the window (results stay in c->d_tiles /
+// c->d_lists).  No synchronisation.
+int
+enqueue_query(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, uint64_t list_cap, QueryRun& q)
+{
+  q.t0 = r->tile0[first];
+  q.nt = r->tile0[first + count] - q.t0;
+  q.probes = count_probes(c, r, first, count);
+  int rc = ensure_dev(c, c->d_tiles, c->d_tiles_cap, q.nt);
+  if (rc == GRP_OK) {
+    rc = ensure_dev(c, c->d_lists, c->d_lists_cap, std::max<uint64_t>(list_cap, 1));
+  }
+  if (rc == GRP_OK) {
+    rc = ensure_dev(c, c->d_flag_idx, c->d_flag_cap, q.nt);
+  }
+  if (rc != GRP_OK) {
+    return rc;
+  }
+  const QueryGeom g = query_geom(c, false);
+  Timer t(c, GRP_K_QUERY, q.probes);
+  int lrc = GRP_OK;
+  DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, q.nt, q.t0, nullptr, g, list_cap));
+  if (lrc != GRP_OK) {
+    return lrc;
+  }
+  HIP_TRY(c, hipGetLastError());
+  return GRP_OK;
+}
+
+// tiles whose ID set did not fit the small LDS table (indices collected on the
+// device): redo them with the worst-case geometry — same kernel, same arithmetic.
+// Expects h_qctr to hold the counters of the first launch.
+int
+enqueue_redo_flagged(grp_ctx* c, const grp_reads* r, uint64_t list_cap, QueryRun& q)
+{
+  q.flagged = c->h_qctr[4];
+  c->n_flagged_tiles += q.flagged;
+  // continue the list arena where the first launch stopped
+  uint64_t cursor[8] = { 0, 0, 0, c->h_qctr[3], 0, 0, 0, 0 };
+  HIP_TRY(c, hipMemcpyAsync(c->d_qctr, cursor, sizeof(cursor), hipMemcpyHostToDevice, c->stream));
+  const QueryGeom g = query_geom(c, true);
+  Timer t(c, GRP_K_QUERY, 0);
+  int lrc = GRP_OK;
+  DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, q.flagged, q.t0, c->d_flag_idx, g, list_cap));
+  if (lrc != GRP_OK) {
+    return lrc;
+  }
+  HIP_TRY(c, hipGetLastError());
+  return GRP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
 int
 grp_query_tiles(grp_ctx* c,
                 const grp_reads* r,
@@ -1643,8 +1820,7 @@ grp_query_tiles(grp_ctx* c,
     return set_err(c, GRP_ERR_STATE, "grp_query_tiles before grp_finalize");
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint64_t t0 = r->tile0[first], t1 = r->tile0[first + count];
-  const uint64_t nt = t1 - t0;
+  const uint64_t nt = r->tile0[first + count] - r->tile0[first];
   if (list_used) {
     *list_used = 0;
   }
@@ -1660,21 +1836,6 @@ grp_query_tiles(grp_ctx* c,
   if (!tiles_out) {
     return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: tiles_out is NULL");
   }
-  if (nt > c->d_tiles_cap) {
-    (void)hipFree(c->d_tiles);
-    c->d_tiles = nullptr;
-    c->d_tiles_cap = 0;
-    HIP_TRY(c, hipMalloc(&c->d_tiles, nt * sizeof(grp_tile_summary)));
-    c->d_tiles_cap = nt;
-  }
-  const uint64_t want_lists = std::max<uint64_t>(list_cap, 1);
-  if (want_lists > c->d_lists_cap) {
-    (void)hipFree(c->d_lists);
-    c->d_lists = nullptr;
-    c->d_lists_cap = 0;
-    HIP_TRY(c, hipMalloc(&c->d_lists, want_lists * sizeof(grp_id_count)));
-    c->d_lists_cap = want_lists;
-  }
   if (nt > c->h_tiles_cap) {
     if (c->h_tiles) {
       (void)hipHostFree(c->h_tiles);
@@ -1685,25 +1846,16 @@ grp_query_tiles(grp_ctx* c,
     HIP_TRY(c, hipHostMalloc(&c->h_tiles, cap * sizeof(grp_tile_summary), hipHostMallocDefault));
     c->h_tiles_cap = cap;
   }
-  uint64_t probes = 0;
-  {
-    const uint32_t tile = c->params.tile, k = c->params.k;
-    for (uint32_t i = first; i < first + count; ++i) {
-      uint32_t ntile = r->len[i] / tile;
-      if (ntile == 0) {
-        continue;
-      }
-      // all tiles but the last have `tile` frames; the last may be clipped
-      uint32_t start = (ntile - 1) * tile;
-      uint32_t Lp = std::min(tile + k - 1, r->len[i] - start);
-      probes += ((uint64_t)(ntile - 1) * tile + (Lp - k + 1)) * c->params.h;
-    }
+  QueryRun q;
+  int rc = enqueue_query(c, r, first, count, list_cap, q);
+  if (rc != GRP_OK) {
+    return rc;
   }
   const uint64_t prefix = std::min<uint64_t>(list_cap, LIST_PREFIX);
   // one round trip: counters, tile summaries and the first LIST_PREFIX list
-  // entries come back together; the arena cursor is re-zeroed for the next call
+  // entries come back together; the counters are re-zeroed for the next call
   auto fetch = [&]() -> int {
-    HIP_TRY(c, hipMemcpyAsync(c->h_qctr, c->d_qctr, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_qctr, c->d_qctr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->h_tiles, c->d_tiles, nt * sizeof(grp_tile_summary), hipMemcpyDeviceToHost, c->stream));
     if (prefix) {
       HIP_TRY(c, hipMemcpyAsync(c->h_lists, c->d_lists, prefix * sizeof(grp_id_count), hipMemcpyDeviceToHost, c->stream));
@@ -1712,54 +1864,17 @@ grp_query_tiles(grp_ctx* c,
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return GRP_OK;
   };
-  {
-    const QueryGeom g = query_geom(c, false);
-    Timer t(c, GRP_K_QUERY, probes);
-    int lrc = GRP_OK;
-    DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, nt, t0, nullptr, g, list_cap));
-    if (lrc != GRP_OK) {
-      return lrc;
-    }
+  rc = fetch();
+  if (rc != GRP_OK) {
+    return rc;
   }
-  HIP_TRY(c, hipGetLastError());
-  int frc = fetch();
-  if (frc != GRP_OK) {
-    return frc;
-  }
-  // tiles whose ID set did not fit the small LDS table: redo them with the
-  // worst-case geometry (same kernel, same arithmetic)
-  std::vector<uint32_t> flagged;
-  for (uint64_t i = 0; i < nt; ++i) {
-    if (c->h_tiles[i].list_n == GRP_TILE_FLAGGED) {
-      flagged.push_back((uint32_t)i);
+  if (c->h_qctr[4]) {
+    rc = enqueue_redo_flagged(c, r, list_cap, q);
+    if (rc == GRP_OK) {
+      rc = fetch();
     }
-  }
-  if (!flagged.empty()) {
-    c->n_flagged_tiles += flagged.size();
-    if (flagged.size() > c->d_flag_cap) {
-      (void)hipFree(c->d_flag_idx);
-      c->d_flag_idx = nullptr;
-      c->d_flag_cap = 0;
-      HIP_TRY(c, hipMalloc(&c->d_flag_idx, flagged.size() * 4 * 2));
-      c->d_flag_cap = flagged.size() * 2;
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->d_flag_idx, flagged.data(), flagged.size() * 4, hipMemcpyHostToDevice, c->stream));
-    // continue the list arena where the first launch stopped
-    uint64_t cursor[4] = { 0, 0, 0, c->h_qctr[3] };
-    HIP_TRY(c, hipMemcpyAsync(c->d_qctr, cursor, sizeof(cursor), hipMemcpyHostToDevice, c->stream));
-    {
-      const QueryGeom g = query_geom(c, true);
-      Timer t(c, GRP_K_QUERY, 0);
-      int lrc = GRP_OK;
-      DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, flagged.size(), t0, c->d_flag_idx, g, list_cap));
-      if (lrc != GRP_OK) {
-        return lrc;
-      }
-    }
-    HIP_TRY(c, hipGetLastError());
-    frc = fetch();
-    if (frc != GRP_OK) {
-      return frc;
+    if (rc != GRP_OK) {
+      return rc;
     }
   }
   drain_events(c);
@@ -1769,7 +1884,7 @@ grp_query_tiles(grp_ctx* c,
     *list_used = used;
   }
   if (stats) {
-    stats->queries = probes / c->params.h; /* one query per frame (goldrush_path.cpp:567-568) */
+    stats->queries = q.probes / c->params.h; /* one query per frame (goldrush_path.cpp:567-568) */
     for (uint64_t i = 0; i < nt; ++i) {
       stats->hits += tiles_out[i].hits;
       stats->misses += tiles_out[i].misses;
@@ -1800,6 +1915,109 @@ grp_query_tiles(grp_ctx* c,
   return GRP_OK;
 }
 
+int
+grp_classify_reads(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, grp_read_decision* out)
+{
+  if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads || !dp || (!out && count)) {
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_reads: bad argument");
+  }
+  if (!c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_reads before grp_finalize");
+  }
+  if (count == 0) {
+    return GRP_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t nt = r->tile0[first + count] - r->tile0[first];
+  if (nt > (1u << 30)) {
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_reads: %llu tiles in one call (limit 2^30)", (unsigned long long)nt);
+  }
+  // decision buffers + scratch for reads too long for the LDS path
+  if (count > c->dec_cap) {
+    (void)hipFree(c->d_dec);
+    c->d_dec = nullptr;
+    if (c->h_dec) {
+      (void)hipHostFree(c->h_dec);
+      c->h_dec = nullptr;
+    }
+    c->dec_cap = 0;
+    const uint64_t cap = std::max<uint64_t>((uint64_t)count + count / 4, 1024);
+    HIP_TRY(c, hipMalloc(&c->d_dec, cap * sizeof(grp_read_decision)));
+    HIP_TRY(c, hipHostMalloc(&c->h_dec, cap * sizeof(grp_read_decision), hipHostMallocDefault));
+    c->dec_cap = cap;
+  }
+  if (nt + 1 > c->d_dec_cap) {
+    (void)hipFree(c->d_dec_ids);
+    (void)hipFree(c->d_dec_asg);
+    (void)hipFree(c->d_dec_scratch);
+    c->d_dec_ids = nullptr;
+    c->d_dec_asg = nullptr;
+    c->d_dec_scratch = nullptr;
+    c->d_dec_cap = 0;
+    const uint64_t cap = nt + nt / 4 + 64;
+    HIP_TRY(c, hipMalloc(&c->d_dec_ids, cap * 4));
+    HIP_TRY(c, hipMalloc(&c->d_dec_asg, cap));
+    HIP_TRY(c, hipMalloc(&c->d_dec_scratch, cap * 8));
+    c->d_dec_cap = cap;
+  }
+  uint64_t list_cap = std::max<uint64_t>(c->d_lists_cap, 4 * nt + 4096);
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    QueryRun q;
+    if (nt) {
+      int rc = enqueue_query(c, r, first, count, list_cap, q);
+      if (rc != GRP_OK) {
+        return rc;
+      }
+    }
+    auto enqueue_decide = [&]() -> int {
+      Timer t(c, GRP_K_DECIDE, count);
+      k_decide<<<dim3((count + DECIDE_THREADS - 1) / DECIDE_THREADS), dim3(DECIDE_THREADS), 0, c->stream>>>(
+        r->dev, first, count, *dp, c->d_tiles, c->d_lists, list_cap, c->d_dec_ids, c->d_dec_asg, c->d_dec_scratch, c->d_dec);
+      HIP_TRY(c, hipGetLastError());
+      return GRP_OK;
+    };
+    auto fetch = [&]() -> int {
+      HIP_TRY(c, hipMemcpyAsync(c->h_qctr, c->d_qctr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_dec, c->d_dec, (size_t)count * sizeof(grp_read_decision), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      return GRP_OK;
+    };
+    // optimistic: decide right behind the query, one round trip in the common case
+    int rc = enqueue_decide();
+    if (rc == GRP_OK) {
+      rc = fetch();
+    }
+    if (rc != GRP_OK) {
+      return rc;
+    }
+    if (c->h_qctr[3] > list_cap) { // list arena too small: grow and redo the window
+      list_cap = c->h_qctr[3] + c->h_qctr[3] / 4 + 4096;
+      continue;
+    }
+    if (c->h_qctr[4]) { // some tiles needed the worst-case table: redo them, decide again
+      rc = enqueue_redo_flagged(c, r, list_cap, q);
+      if (rc == GRP_OK) {
+        rc = enqueue_decide();
+      }
+      if (rc == GRP_OK) {
+        rc = fetch();
+      }
+      if (rc != GRP_OK) {
+        return rc;
+      }
+      if (c->h_qctr[3] > list_cap) {
+        list_cap = c->h_qctr[3] + c->h_qctr[3] / 4 + 4096;
+        continue;
+      }
+    }
+    drain_events(c);
+    memcpy(out, c->h_dec, (size_t)count * sizeof(grp_read_decision));
+    return GRP_OK;
+  }
+  return set_err(c, GRP_ERR_NOMEM, "grp_classify_reads: list arena kept overflowing");
+}
+
 // ---- insert -------------------------------------------------------------------------
 
 int
@@ -1825,7 +2043,6 @@ grp_insert_tiles(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t til
   if (want > c->dedup_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_dedup);
-  (void)hipFree(c->d_flag_idx);
     c->d_dedup = nullptr;
     c->dedup_cap = 0;
     HIP_TRY(c, hipMalloc(&c->d_dedup, want * 8));
@@ -2021,6 +2238,18 @@ grp_debug_tile_hashes(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_
   HIP_TRY(c, hipMemcpyAsync(out, d, nv * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   (void)hipFree(d);
+  return GRP_OK;
+}
+
+int
+grp_debug_tile_states(grp_ctx* c, uint64_t n_tiles, uint32_t* ids, uint8_t* assigned)
+{
+  if (!c || !ids || !assigned || n_tiles > c->d_dec_cap) {
+    return set_err(c, GRP_ERR_INVALID, "grp_debug_tile_states: no such window");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy(ids, c->d_dec_ids, n_tiles * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(assigned, c->d_dec_asg, n_tiles, hipMemcpyDeviceToHost));
   return GRP_OK;
 }
 

@@ -117,7 +117,18 @@ Classifier::query_window(void* reads, const uint32_t* lens, uint32_t first, uint
   const uint32_t my_first = std::min<uint64_t>((uint64_t)first + (uint64_t)p_.rank * q, (uint64_t)first + count);
   const uint32_t my_count = std::min<uint32_t>(q, first + count - my_first);
   dec_.assign(q, gr_read_decision{});
-  if (my_count) {
+  // tiny windows (insert-heavy phases) are latency-bound: one kernel + host decision
+  // is shorter than two kernels
+  if (my_count >= 16 && vt_.classify_reads) {
+    // query + decision on the device: 32 bytes per read come back
+    const grp_decide_params dp{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
+    int rc = vt_.classify_reads(ctx_, reads, base_ + my_first, my_count, &dp, dec_.data());
+    if (rc != GRP_OK) {
+      err_ = std::string("classify_reads: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+      return rc;
+    }
+    n_queried_ += my_count;
+  } else if (my_count) {
     const uint64_t nt = tile0_[my_first + my_count] - tile0_[my_first];
     tiles_.resize(nt ? nt : 1);
     if (lists_.size() < 4 * nt + 1024) {

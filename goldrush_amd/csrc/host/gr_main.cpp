@@ -23,6 +23,9 @@ hip_engine()
   vt.insert_tiles = [](void* c, const void* r, uint32_t ri, uint32_t ts, uint32_t te, uint32_t id) { return grp_insert_tiles(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), ri, ts, te, id); };
   vt.reset_ids = [](void* c) { return grp_reset_ids(static_cast<grp_ctx*>(c)); };
   vt.sync = [](void* c) { return grp_sync(static_cast<grp_ctx*>(c)); };
+  vt.classify_reads = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, grp_read_decision* out) {
+    return grp_classify_reads(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, out);
+  };
   return vt;
 }
 

@@ -51,8 +51,7 @@ struct TileWorkspace
 {
   std::vector<uint32_t> ids;
   std::vector<uint8_t> asg;
-  std::vector<std::pair<size_t, size_t>> runs;
-  std::vector<std::pair<uint32_t, uint32_t>> by_id;
+  std::vector<uint64_t> scratch;
 };
 
 // threshold + smoothing passes; ids/asg are outputs (size num_tiles).

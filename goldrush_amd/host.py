@@ -54,6 +54,7 @@ VT_TYPES = [
     ("insert_tiles", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)),
     ("reset_ids", C.CFUNCTYPE(C.c_int, _vp)),
     ("sync", C.CFUNCTYPE(C.c_int, _vp)),
+    ("classify_reads", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp)),
 ]
 
 

@@ -21,8 +21,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libgrpath_hip.so")
 
 GRP_OK = 0
 GRP_ERR_INVALID, GRP_ERR_NO_DEVICE, GRP_ERR_HIP, GRP_ERR_STATE, GRP_ERR_NOMEM = -1, -2, -3, -4, -5
-GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_COUNT = 0, 1, 2, 3, 4
-KERNEL_NAMES = ("fill", "rank", "query", "insert")
+GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_COUNT = 0, 1, 2, 3, 4, 5
+KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide")
 
 
 class GrpError(RuntimeError):
@@ -48,6 +48,14 @@ tile_summary_dtype = np.dtype([("top_id", "<u4"), ("top_count", "<u4"), ("list_o
 id_count_dtype = np.dtype([("id", "<u4"), ("count", "<u4")])
 
 
+class grp_decide_params(C.Structure):
+    _fields_ = [("threshold", C.c_uint32), ("unassigned_min", C.c_uint32), ("assigned_max", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+decision_dtype = np.dtype([("kind", "<u4"), ("num_tiles", "<u4"), ("num_assigned", "<u4"), ("trim_start", "<u4"), ("trim_end", "<u4"),
+                           ("hits", "<u4"), ("misses", "<u4"), ("pad", "<u4")])
+
+
 class grp_query_stats(C.Structure):
     _fields_ = [("queries", C.c_uint64), ("hits", C.c_uint64), ("misses", C.c_uint64)]
 
@@ -69,6 +77,7 @@ SIGNATURES = {
     "grp_bv_insert": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32]),
     "grp_finalize": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "grp_query_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(grp_query_stats)]),
+    "grp_classify_reads": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp]),
     "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_reset_ids": (C.c_int, [_vp]),
     "grp_sync": (C.c_int, [_vp]),
@@ -79,6 +88,7 @@ SIGNATURES = {
     "grp_export_ids": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp]),
     "grp_import_ids": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp]),
     "grp_debug_tile_hashes": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "grp_debug_tile_states": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     "grp_set_timing": (C.c_int, [_vp, C.c_int]),
     "grp_get_kernel_stats": (C.c_int, [_vp, C.POINTER(grp_kernel_stat)]),
     "grp_reset_kernel_stats": (C.c_int, [_vp]),
@@ -280,6 +290,23 @@ class Engine:
                 continue
             self._check(rc)
             return tiles, lists[: used.value], {"queries": st.queries, "hits": st.hits, "misses": st.misses}
+
+    def classify_reads(self, batch: ReadBatch, first: int = 0, count: int | None = None, threshold=10, unassigned_min=5, assigned_max=1):
+        """Query + decision on the device; returns an array of decision_dtype."""
+        count = batch.n_reads - first if count is None else count
+        if first < 0 or count < 0 or first + count > batch.n_reads:
+            raise GrpError(GRP_ERR_INVALID, f"reads [{first}, {first + count}) outside the batch of {batch.n_reads}")
+        out = np.zeros(count, dtype=decision_dtype)
+        dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
+        self._check(self.lib.grp_classify_reads(self._h, batch._h, first, count, C.byref(dp), _ptr(out)))
+        return out
+
+    def tile_states(self, n_tiles: int):
+        """(ids, assigned) per tile after the smoothing passes of the last classify_reads window."""
+        ids = np.zeros(max(n_tiles, 1), dtype=np.uint32)
+        asg = np.zeros(max(n_tiles, 1), dtype=np.uint8)
+        self._check(self.lib.grp_debug_tile_states(self._h, n_tiles, _ptr(ids), _ptr(asg)))
+        return ids[:n_tiles], asg[:n_tiles]
 
     def insert_tiles(self, batch: ReadBatch, read_idx: int, tile_start: int, tile_end: int, id_: int):
         self._check(self.lib.grp_insert_tiles(self._h, batch._h, read_idx, tile_start, tile_end, id_))

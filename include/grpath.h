@@ -185,6 +185,46 @@ int grp_query_tiles(grp_ctx* ctx,
                     uint64_t* list_used,
                     grp_query_stats* stats);
 
+/* ---- phase 2: tile query + read decision on the device --------------------- */
+typedef struct
+{
+  uint32_t threshold;      /* -x */
+  uint32_t unassigned_min; /* -u */
+  uint32_t assigned_max;   /* -a */
+  uint32_t reserved;
+} grp_decide_params;
+
+/* one read's decision: 32 bytes, trivially copyable (what ranks exchange) */
+typedef struct
+{
+  uint32_t kind;         /* 2 insert whole read ("_untrimmed"), 3 every tile assigned,
+                            4 insert trimmed ("_trimmed"), 5 assigned (wood path) */
+  uint32_t num_tiles;
+  uint32_t num_assigned; /* after the smoothing passes */
+  uint32_t trim_start;   /* valid for kind 4 */
+  uint32_t trim_end;
+  uint32_t hits;         /* summed over the read's tiles */
+  uint32_t misses;
+  uint32_t pad;
+} grp_read_decision;
+
+/*
+ * Replaces, for reads [first, first+count) of the batch: the hashing producer,
+ * the whole of calc_num_assigned_tiles (goldrush_path.cpp:529-890: per-tile
+ * query, threshold, smoothing passes P1..P10) and the decision of process_read
+ * (:960-1040: unassigned rule, find_longest_stretch :195-233, eval_flanks
+ * :341-527).  Same query kernel as grp_query_tiles followed by a decision kernel
+ * (one lane per read); only the 32-byte decisions come back.  Read-only on the
+ * miBF; the caller still has to commit the decisions in file order and issue
+ * the inserts (grp_insert_tiles).  Synchronous.
+ */
+int grp_classify_reads(grp_ctx* ctx,
+                       const grp_reads* reads,
+                       uint32_t first,
+                       uint32_t count,
+                       const grp_decide_params* params,
+                       grp_read_decision* decisions_out);
+
 /* ---- phase 2: ID insert ---------------------------------------------------- */
 /*
  * Replaces: miBFCS.insertMIBF(*miBF, hashed_values, tile_start, tile_end, id)
@@ -237,6 +277,10 @@ int grp_debug_tile_hashes(grp_ctx* ctx,
                           uint64_t cap,
                           uint64_t* n_values);
 
+/* per-tile IDs / assigned flags after the smoothing passes of the LAST
+ * grp_classify_reads window (tiles in window order); n_tiles = tiles of that window */
+int grp_debug_tile_states(grp_ctx* ctx, uint64_t n_tiles, uint32_t* ids, uint8_t* assigned);
+
 /* ---- measurement ------------------------------------------------------------ */
 enum
 {
@@ -244,7 +288,8 @@ enum
   GRP_K_RANK = 1,     /* rank build kernels (finalize) */
   GRP_K_QUERY = 2,    /* fused hash + probe + tile histogram kernel */
   GRP_K_INSERT = 3,   /* ID insert kernel */
-  GRP_K_COUNT = 4
+  GRP_K_DECIDE = 4,   /* read decision kernel */
+  GRP_K_COUNT = 5
 };
 
 typedef struct

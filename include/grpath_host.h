@@ -30,6 +30,8 @@ typedef struct
   int (*insert_tiles)(void* ctx, const void* reads, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t id);
   int (*reset_ids)(void* ctx);
   int (*sync)(void* ctx);
+  /* optional (may be NULL): query + decision on the device, grp_classify_reads */
+  int (*classify_reads)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, grp_read_decision* out);
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */
@@ -50,17 +52,7 @@ int gr_pack_2bit(const char* seq, size_t n, uint32_t* out_words);
 unsigned gr_effective_cpus(void);
 
 /* ---- tile decision (goldrush_path.cpp:628-889, 195-233, 341-527, 960-1040) - */
-typedef struct
-{
-  uint32_t kind; /* 2 insert whole, 3 all assigned, 4 insert trimmed, 5 assigned */
-  uint32_t num_tiles;
-  uint32_t num_assigned;
-  uint32_t trim_start;
-  uint32_t trim_end;
-  uint32_t hits;
-  uint32_t misses;
-  uint32_t pad;
-} gr_read_decision;
+typedef grp_read_decision gr_read_decision; /* see grpath.h */
 
 /* decision of one read from its tile summaries (list_off indexes `lists`) */
 void gr_decide_read(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t num_tiles, const grp_tile_summary* tiles, const grp_id_count* lists, gr_read_decision* out);

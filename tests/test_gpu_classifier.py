@@ -96,3 +96,50 @@ def test_full_size_properties(native):
     tiles, lists, st = eng.query_tiles(rb, 5, 1)
     assert not tiles["top_id"].any() and st["hits"] == 0 and st["misses"] == 3 * st["queries"]
     dr.free()
+
+
+def test_device_decisions_match_host_and_oracle(oracle, native):
+    """grp_classify_reads (decision kernel) == host decide on grp_query_tiles output
+    == oracle smoothing/decision, on the same miBF state; includes reads longer than
+    the kernel's LDS scratch (global-scratch path) and very short reads."""
+    from goldrush_amd import host, synth
+
+    tile, k, h = 250, 22, 3
+    seeds = default_seeds(h)
+    g = synth.random_genome(200_000, 31)
+    reads = [r[1] for r in synth.make_reads(g, 70, mean_len=6000, min_len=2000, seed=32, max_len=30000)]
+    reads += [g[1000:1000 + 20000].tobytes(), g[50000:50000 + 700].tobytes(), g[60000:60000 + 249].tobytes()]  # 80 tiles, 2 tiles, 0 tiles
+    m = oracle.load().orc_calc_optimal_size(3_000_000, 1, 0.1)
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    eng.finalize()
+    nid = 0
+    for ri in range(0, 40, 3):  # populate IDs from a subset of the reads
+        nt = len(reads[ri]) // tile
+        nid += 1
+        for bs in range(0, nt, 4):
+            eng.insert_tiles(b, ri, bs, min(bs + 4, nt), nid + bs // 4)
+        nid += nt // 4
+    dec = eng.classify_reads(b, threshold=10, unassigned_min=5, assigned_max=1)
+    tiles, lists, _ = eng.query_tiles(b)
+    lists_arr = np.ascontiguousarray(lists) if len(lists) else np.zeros(1, dtype=native.id_count_dtype)
+    kinds = set()
+    for ri in range(len(reads)):
+        a, e = int(b.tile0[ri]), int(b.tile0[ri + 1])
+        n = e - a
+        t = np.ascontiguousarray(tiles[a:e]) if n else np.zeros(1, dtype=native.tile_summary_dtype)
+        d = host.decide_read(t, lists_arr, n, threshold=10, unassigned_min=5, assigned_max=1)
+        got = dec[ri]
+        assert (int(got["kind"]), int(got["num_tiles"]), int(got["num_assigned"]), int(got["trim_start"]), int(got["trim_end"]), int(got["hits"]), int(got["misses"])) == \
+               (d.kind, d.num_tiles, d.num_assigned, d.trim_start, d.trim_end, d.hits, d.misses), ri
+        # oracle on the same summaries
+        ol = [np.array([(int(x["id"]), int(x["count"])) for x in lists[int(tt["list_off"]): int(tt["list_off"]) + int(tt["list_n"])]], dtype=oracle.id_count_dtype) for tt in tiles[a:e]]
+        o_ids, o_b, na = oracle.smooth_tiles([int(tt["top_id"]) for tt in tiles[a:e]], ol, 10)
+        assert na == int(got["num_assigned"]), ri
+        kinds.add(int(got["kind"]))
+    assert len(kinds) >= 3, kinds
+    assert int(dec[-3]["num_tiles"]) == 80 and int(dec[-1]["num_tiles"]) == 0 and int(dec[-1]["kind"]) == 3
+    # sub-window
+    sub = eng.classify_reads(b, 10, 7)
+    assert np.array_equal(sub, dec[10:17])
