@@ -33,7 +33,19 @@ now_s()
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-constexpr size_t BATCH_RECORDS = 16384;
+// records / bases per host batch (one grp_reads upload each).  GRP_BATCH_RECORDS
+// overrides the record count (tests use it to exercise the batch boundaries).
+size_t
+batch_records()
+{
+  static const size_t n = [] {
+    const char* e = getenv("GRP_BATCH_RECORDS");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (size_t)v : (size_t)16384;
+  }();
+  return n;
+}
+#define BATCH_RECORDS batch_records()
 constexpr size_t BATCH_BASES = size_t(384) << 20;
 
 struct PackedBatch

@@ -35,13 +35,14 @@ def _mk_fastq(path, genome_len, n_reads, mean_len, min_len, seed, noisy_qual=Fal
     return out
 
 
-def _run_both(oracle, host, tmp_path, args, tag):
+def _run_both(oracle, host, tmp_path, args, tag, env=None):
     d_o = tmp_path / f"{tag}_o"
     d_p = tmp_path / f"{tag}_p"
     d_o.mkdir()
     d_p.mkdir()
     ro = oracle.run_cli(args + ["-p", str(d_o / "out")], timeout=900)
-    rp = subprocess.run([host.CLI_PATH] + args + ["-p", str(d_p / "out")], capture_output=True, text=True, timeout=900)
+    rp = subprocess.run([host.CLI_PATH] + args + ["-p", str(d_p / "out")], capture_output=True, text=True, timeout=900,
+                        env=dict(os.environ, **(env or {})))
     assert rp.returncode == ro.returncode, (rp.returncode, ro.returncode, rp.stderr[-2000:])
     fo = sorted(os.path.basename(p) for p in glob.glob(str(d_o / "*")))
     fp = sorted(os.path.basename(p) for p in glob.glob(str(d_p / "*")))
@@ -128,3 +129,16 @@ def test_cli_error_paths(oracle, host, tmp_path):
     rp = subprocess.run([host.CLI_PATH] + args, capture_output=True, text=True, timeout=300)
     ro = oracle.run_cli(args, timeout=300)
     assert rp.returncode == ro.returncode == 1
+
+
+@pytest.mark.parametrize("batch", ["1", "7", "64"])
+def test_batch_boundaries(oracle, host, tmp_path, batch):
+    """Tiny host batches: the filter set, the skipped-read counter, the classifier
+    state and the silver-path rollover all have to carry across grp_reads uploads."""
+    fq = str(tmp_path / "reads.fq")
+    _mk_fastq(fq, 200_000, 420, 6000, 4000, seed=15, lower=True, with_n=17, short=9)
+    args = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j4", "-d5", "-x10", "-s1011011110110111101101", "-g200000", "-b4", "-H3000000",
+            "-P0", "-r0.9", "--silver_path", "-M2", "-m3500", "-i", fq, "--verbose"]
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "b" + batch, env={"GRP_BATCH_RECORDS": batch})
+    assert len(files) == 2
+    assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
