@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--max-window", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace", action="store_true", help="per-step timing / speculation statistics on stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for single-GPU plumbing tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="developer: all ranks use GPU 0 (plumbing test on a 1-GPU box, use with --backend gloo)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,10 +109,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if a.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend)
+    coll_dev = "cuda" if a.backend == "nccl" else "cpu"
     from goldrush_amd import host, native
 
     G, k, w, tile, h, block = int(a.genome), 22, 16, 1000, a.h, 10
@@ -136,8 +144,8 @@ def main():
     if world > 1:
         def allgather(user, send, nbytes, recv):  # noqa: E306
             src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
-            t_in = torch.from_numpy(src).cuda()
-            t_out = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
+            t_in = torch.from_numpy(src).to(coll_dev)
+            t_out = torch.empty(nbytes * world, dtype=torch.uint8, device=coll_dev)
             dist.all_gather_into_tensor(t_out, t_in)
             dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
             dst[:] = t_out.cpu().numpy()
@@ -179,7 +187,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ks = eng.kernel_stats()
