@@ -82,6 +82,15 @@ struct grp_ctx
   unsigned long long* d_dedup = nullptr;
   uint64_t dedup_cap = 0;
   uint32_t epoch = 0;
+  // whole-read insert table
+  unsigned long long* d_ir_keys = nullptr;
+  unsigned long long* d_ir_masks = nullptr;
+  unsigned long long* d_ir_locs = nullptr;
+  uint32_t* d_ir_slots = nullptr;
+  uint32_t* d_ir_counter = nullptr;
+  uint64_t ir_cap = 0;
+  uint32_t ir_parity = 0;
+  uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE);
   // timing
   bool timing = true;
   std::vector<EventPair> pending;
@@ -965,6 +974,135 @@ k_insert(DevFilter f,
   }
 }
 
+// ---- whole-read insert (all ID blocks of a read in two launches) ------------------
+//
+// process_read inserts a read as consecutive blocks of `block` tiles, one
+// insertMIBF call (= one dedup scope, one ID) per block, in order
+// (goldrush_path.cpp:982-990, 1040-1051).  k_insert_collect gathers, for every
+// distinct rank of the read, the SET of blocks that touch it (bit j = block j);
+// k_insert_apply then replays the blocks in ascending order per rank:
+// c = ++count; if (uint32(rank ^ id_j) % c == c-1) id = id_j — identical to the
+// sequential calls because different ranks never interact.
+struct InsertTable
+{
+  unsigned long long* keys;  // rank + 1, 0 = free (left clean by k_insert_apply)
+  unsigned long long* masks; // blocks touching the rank
+  unsigned long long* locs;  // dword index of the ID slot, or ~0 for the overflow table
+  uint32_t* slots;           // claimed slots, in claim order
+  uint32_t* counter;         // [2], alternating per call
+  uint64_t cap_mask;
+};
+
+template<int H>
+__global__ void __launch_bounds__(THREADS)
+k_insert_collect(DevFilter f, DevReads rd, const DevSeeds* __restrict__ sd, uint32_t tile_len, uint32_t read_idx, uint32_t tile_start, uint32_t block_tiles, InsertTable tb, uint32_t parity)
+{
+  extern __shared__ uint4 smem4[];
+  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
+  uint32_t* sBases = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
+
+  const uint32_t parts = (tile_len + THREADS - 1) / THREADS;
+  const uint32_t tj = blockIdx.x / parts; // tile inside the inserted range
+  const uint32_t ti = tile_start + tj;
+  const uint32_t part = blockIdx.x % parts;
+  const unsigned long long block_bit = 1ull << (tj / block_tiles);
+  const uint32_t len = rd.len[read_idx];
+  const uint32_t k = sd->k;
+  const uint32_t start = ti * tile_len;
+  const uint32_t Lp = min(tile_len + k - 1u, len - start);
+  const uint32_t frames = (Lp >= k) ? (Lp - k + 1u) : 0u;
+
+  load_tab(sTab, sd);
+  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[read_idx], len, start, Lp);
+  __syncthreads();
+
+  for (uint32_t fr = part * THREADS + threadIdx.x; fr < frames; fr += THREADS * parts) {
+    Probe pr[H];
+    uint4 hd[H];
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+      const uint32_t fs = min(fr, Lp - sd->span[s]);
+      pr[s] = grp_locate(f, seed_hash(sTab, sd, s, window_at(sBases, boff + fs)));
+    }
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+      hd[s] = f.buckets[pr[s].b * 4];
+    }
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+      const uint64_t bm = grp_bitmap(hd[s]);
+      const uint32_t lr = grp_local_rank(bm, pr[s].off);
+      const uint64_t rank = f.super[pr[s].b >> GRP_SUPER_SHIFT] + hd[s].x + lr;
+      if (rank >= f.pop || !((bm >> pr[s].off) & 1ull)) {
+        continue; // see k_insert
+      }
+      const unsigned long long key = rank + 1;
+      uint64_t slot = (key * 0x9E3779B97F4A7C15ULL) >> 20 & tb.cap_mask;
+      for (;;) {
+        unsigned long long cur = tb.keys[slot];
+        if (cur == 0) {
+          cur = atomicCAS(&tb.keys[slot], 0ull, key);
+          if (cur == 0) { // claimed: remember where the rank's ID lives
+            tb.locs[slot] = (lr < GRP_BUCKET_IDS) ? (unsigned long long)(pr[s].b * 16 + 3 + lr) : ~0ull;
+            tb.slots[atomicAdd(&tb.counter[parity], 1u)] = (uint32_t)slot;
+            cur = key;
+          }
+        }
+        if (cur == key) {
+          break;
+        }
+        slot = (slot + 1) & tb.cap_mask;
+      }
+      atomicOr(&tb.masks[slot], block_bit);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(THREADS)
+k_insert_apply(DevFilter f, InsertTable tb, uint32_t parity, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset)
+{
+  const uint32_t n = tb.counter[parity];
+  const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+  if (i == 0) {
+    tb.counter[parity ^ 1u] = 0; // the next call's counter
+  }
+  if (i >= n) {
+    return;
+  }
+  const uint32_t slot = tb.slots[i];
+  const uint64_t rank = tb.keys[slot] - 1;
+  unsigned long long mask = tb.masks[slot];
+  const unsigned long long loc = tb.locs[slot];
+  tb.keys[slot] = 0;
+  tb.masks[slot] = 0;
+  uint32_t count = f.counts[rank];
+  uint32_t new_id = 0;
+  bool write = false;
+  while (mask) {
+    const uint32_t j = (uint32_t)__ffsll((long long)mask) - 1u;
+    mask &= mask - 1;
+    // MIBFConstructSupport.hpp:274-282, block j's call
+    ++count;
+    const uint32_t id = first_id + (j * block_tiles + id_offset) / block_tiles;
+    if ((uint32_t)(rank ^ (uint64_t)id) % count == count - 1u) {
+      new_id = id;
+      write = true;
+    }
+  }
+  f.counts[rank] = count;
+  if (write) {
+    uint32_t* p = (loc != ~0ull) ? &reinterpret_cast<uint32_t*>(f.buckets)[loc] : nullptr;
+    const uint32_t old = p ? *p : grp_ovf_get(f, rank);
+    // setData (MIBloomFilter.hpp:593-602): keep a set saturation bit
+    const uint32_t nv = (old > 0x80000000u) ? (new_id | 0x80000000u) : new_id;
+    if (p) {
+      *p = nv;
+    } else {
+      grp_ovf_put(f, rank, nv);
+    }
+  }
+}
+
 // ---- inspection kernels ----------------------------------------------------------
 
 // buckets -> plain bit vector (out zeroed by the caller, 32-bit words)
@@ -1104,7 +1242,7 @@ struct Timer
   {
     c->kstat[kind].launches += 1;
     c->kstat[kind].units += units;
-    if (!c->timing) {
+    if (!c->timing || !(c->timing_mask & (1u << kind))) {
       return;
     }
     if (!c->free_events.empty()) {
@@ -1425,6 +1563,11 @@ grp_destroy(grp_ctx* c)
     (void)hipHostFree(c->h_lists);
   }
   (void)hipFree(c->d_dedup);
+  (void)hipFree(c->d_ir_keys);
+  (void)hipFree(c->d_ir_masks);
+  (void)hipFree(c->d_ir_locs);
+  (void)hipFree(c->d_ir_slots);
+  (void)hipFree(c->d_ir_counter);
   (void)hipFree(c->d_flag_idx);
   (void)hipFree(c->d_dec_ids);
   (void)hipFree(c->d_dec_asg);
@@ -2066,6 +2209,71 @@ grp_insert_tiles(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t til
 }
 
 int
+grp_insert_read(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset)
+{
+  if (!c || !r || r->ctx != c || read_idx >= r->n_reads || block_tiles == 0 || id_offset > 1) {
+    return set_err(c, GRP_ERR_INVALID, "grp_insert_read: bad argument");
+  }
+  if (!c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_insert_read before grp_finalize");
+  }
+  const uint64_t ntile = r->tile0[read_idx + 1] - r->tile0[read_idx];
+  if (tile_start > tile_end || tile_end > ntile) {
+    return set_err(c, GRP_ERR_INVALID, "grp_insert_read: tiles [%u,%u) outside the read's %llu tiles", tile_start, tile_end, (unsigned long long)ntile);
+  }
+  if (tile_start == tile_end) {
+    return GRP_OK;
+  }
+  const uint32_t nt = tile_end - tile_start;
+  const uint32_t n_blocks = (nt + block_tiles - 1) / block_tiles;
+  if (n_blocks > 64) { // more ID blocks than mask bits: one launch per block
+    for (uint32_t j = 0; j < n_blocks; ++j) {
+      const uint32_t bs = tile_start + j * block_tiles;
+      int rc = grp_insert_tiles(c, r, read_idx, bs, std::min(bs + block_tiles, tile_end), first_id + (j * block_tiles + id_offset) / block_tiles);
+      if (rc != GRP_OK) {
+        return rc;
+      }
+    }
+    return GRP_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t max_ranks = (uint64_t)nt * c->params.tile * c->params.h;
+  const uint64_t want = next_pow2_64(max_ranks * 2);
+  if (want > c->ir_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_ir_keys);
+    (void)hipFree(c->d_ir_masks);
+    (void)hipFree(c->d_ir_locs);
+    (void)hipFree(c->d_ir_slots);
+    c->d_ir_keys = c->d_ir_masks = c->d_ir_locs = nullptr;
+    c->d_ir_slots = nullptr;
+    c->ir_cap = 0;
+    HIP_TRY(c, hipMalloc(&c->d_ir_keys, want * 8));
+    HIP_TRY(c, hipMalloc(&c->d_ir_masks, want * 8));
+    HIP_TRY(c, hipMalloc(&c->d_ir_locs, want * 8));
+    HIP_TRY(c, hipMalloc(&c->d_ir_slots, want * 4));
+    HIP_TRY(c, hipMemsetAsync(c->d_ir_keys, 0, want * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_ir_masks, 0, want * 8, c->stream));
+    if (!c->d_ir_counter) {
+      HIP_TRY(c, hipMalloc(&c->d_ir_counter, 2 * sizeof(uint32_t)));
+      HIP_TRY(c, hipMemsetAsync(c->d_ir_counter, 0, 2 * sizeof(uint32_t), c->stream));
+    }
+    c->ir_cap = want;
+  }
+  InsertTable tb{ c->d_ir_keys, c->d_ir_masks, c->d_ir_locs, c->d_ir_slots, c->d_ir_counter, c->ir_cap - 1 };
+  const uint32_t parity = c->ir_parity;
+  c->ir_parity ^= 1u;
+  const size_t lds = tab_bytes(c) + bases_bytes(c->params.tile + c->params.k + c->params.h);
+  {
+    Timer t(c, GRP_K_INSERT, max_ranks);
+    DISPATCH_H(c->params.h, (k_insert_collect<HH><<<dim3(nt * ((c->params.tile + THREADS - 1) / THREADS)), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, read_idx, tile_start, block_tiles, tb, parity)));
+    k_insert_apply<<<dim3((uint32_t)((max_ranks + THREADS - 1) / THREADS)), dim3(THREADS), 0, c->stream>>>(c->f, tb, parity, block_tiles, first_id, id_offset);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return GRP_OK;
+}
+
+int
 grp_reset_ids(grp_ctx* c)
 {
   if (!c || !c->finalized) {
@@ -2262,6 +2470,9 @@ grp_set_timing(grp_ctx* c, int enabled)
     return GRP_ERR_INVALID;
   }
   c->timing = enabled != 0;
+  if (enabled >= 2) {
+    c->timing_mask = ~0u; // also the latency-critical insert launches
+  }
   return GRP_OK;
 }
 

@@ -259,13 +259,26 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
     }
   };
 
+  // all ID blocks of the read in one engine call (same result as the block loop)
+  auto insert_read = [&](uint32_t ts, uint32_t te_excl, uint32_t id_offset) {
+    int e = vt_.insert_read(ctx_, reads, base_ + r, ts, te_excl, block, ids_inserted_, id_offset);
+    if (e != GRP_OK) {
+      rc = e;
+      err_ = std::string("insert_read: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+    }
+  };
+
   switch (d.kind) {
     case DEC_INSERT_WHOLE: {
       // :978-1011
       ++ids_inserted_;
       ev.first_id = ids_inserted_;
-      for (uint32_t bs = 0; bs < nt; bs += block) {
-        insert_block(bs, std::min(bs + block, nt), ids_inserted_ + (uint32_t)(bs / block));
+      if (vt_.insert_read) {
+        insert_read(0, nt, 0);
+      } else {
+        for (uint32_t bs = 0; bs < nt; bs += block) {
+          insert_block(bs, std::min(bs + block, nt), ids_inserted_ + (uint32_t)(bs / block));
+        }
       }
       ids_inserted_ = ids_inserted_ + (uint32_t)(len / ((size_t)tile * block));
       const double ph = commit_cb_ ? commit_cb_(user_, &ev) : 0.0;
@@ -292,9 +305,13 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       const uint32_t ts = d.trim_start, te = d.trim_end;
       ++ids_inserted_;
       ev.first_id = ids_inserted_;
-      for (uint64_t bs = ts; bs <= te; bs += block) {
-        const uint64_t be = std::min<uint64_t>(bs + block - 1, te);
-        insert_block((uint32_t)bs, (uint32_t)be + 1, ids_inserted_ + (uint32_t)((bs - ts + 1) / block));
+      if (vt_.insert_read) {
+        insert_read(ts, te + 1, 1);
+      } else {
+        for (uint64_t bs = ts; bs <= te; bs += block) {
+          const uint64_t be = std::min<uint64_t>(bs + block - 1, te);
+          insert_block((uint32_t)bs, (uint32_t)be + 1, ids_inserted_ + (uint32_t)((bs - ts + 1) / block));
+        }
       }
       ids_inserted_ = ids_inserted_ + (uint32_t)((te - ts) / block);
       // new_seq = seq.substr(ts*tile, te == nt-1 ? npos : (te-ts+1)*tile)

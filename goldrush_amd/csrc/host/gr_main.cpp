@@ -26,6 +26,9 @@ hip_engine()
   vt.classify_reads = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, grp_read_decision* out) {
     return grp_classify_reads(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, out);
   };
+  vt.insert_read = [](void* c, const void* r, uint32_t ri, uint32_t ts, uint32_t te, uint32_t block, uint32_t first_id, uint32_t off) {
+    return grp_insert_read(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), ri, ts, te, block, first_id, off);
+  };
   return vt;
 }
 

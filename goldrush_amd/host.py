@@ -55,6 +55,7 @@ VT_TYPES = [
     ("reset_ids", C.CFUNCTYPE(C.c_int, _vp)),
     ("sync", C.CFUNCTYPE(C.c_int, _vp)),
     ("classify_reads", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp)),
+    ("insert_read", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)),
 ]
 
 

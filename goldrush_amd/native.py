@@ -79,6 +79,7 @@ SIGNATURES = {
     "grp_query_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(grp_query_stats)]),
     "grp_classify_reads": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp]),
     "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "grp_insert_read": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_reset_ids": (C.c_int, [_vp]),
     "grp_sync": (C.c_int, [_vp]),
     "grp_filter_bits": (C.c_uint64, [_vp]),
@@ -310,6 +311,9 @@ class Engine:
 
     def insert_tiles(self, batch: ReadBatch, read_idx: int, tile_start: int, tile_end: int, id_: int):
         self._check(self.lib.grp_insert_tiles(self._h, batch._h, read_idx, tile_start, tile_end, id_))
+
+    def insert_read(self, batch: ReadBatch, read_idx: int, tile_start: int, tile_end: int, block_tiles: int, first_id: int, id_offset: int = 0):
+        self._check(self.lib.grp_insert_read(self._h, batch._h, read_idx, tile_start, tile_end, block_tiles, first_id, id_offset))
 
     def reset_ids(self):
         self._check(self.lib.grp_reset_ids(self._h))

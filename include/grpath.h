@@ -244,6 +244,28 @@ int grp_insert_tiles(grp_ctx* ctx,
                      uint32_t id);
 
 /*
+ * Replaces the whole insert loop of process_read for one read
+ * (goldrush_path.cpp:982-990 whole read, :1040-1051 trimmed read): consecutive
+ * blocks of block_tiles tiles starting at tile_start, one insertMIBF call (one
+ * dedup scope, one ID) per block, in order.  Block j covers tiles
+ * [tile_start + j*block_tiles, min(tile_start + (j+1)*block_tiles, tile_end)) and
+ * gets the ID  first_id + (j*block_tiles + id_offset) / block_tiles
+ * (id_offset 0 = the whole-read rule uint32(block_start / block), :985-986;
+ *  id_offset 1 = the trimmed rule uint32((block_start - trim_start + 1) / block),
+ *  :1045-1047).  Two launches for the whole read instead of one per block; the
+ * result is identical to the sequence of grp_insert_tiles calls.  Asynchronous,
+ * stream-ordered like grp_insert_tiles.
+ */
+int grp_insert_read(grp_ctx* ctx,
+                    const grp_reads* reads,
+                    uint32_t read_idx,
+                    uint32_t tile_start,
+                    uint32_t tile_end,
+                    uint32_t block_tiles,
+                    uint32_t first_id,
+                    uint32_t id_offset);
+
+/*
  * Replaces: miBFCS.reset_counts(); mibf->reset_ID_vector()
  * (goldrush_path.cpp:180-181 -> MIBFConstructSupport.hpp:183-186,
  * MIBloomFilter.hpp:679-682).  Bit vector and rank structure untouched.
@@ -300,7 +322,8 @@ typedef struct
                          on the context's stream around each launch */
 } grp_kernel_stat;
 
-/* enable / disable per-launch HIP-event timing (default on) */
+/* 0: no per-launch HIP-event timing; 1 (default): fill, rank, query and decide
+ * launches are timed; 2: the latency-critical insert launches too */
 int grp_set_timing(grp_ctx* ctx, int enabled);
 /* drains outstanding events (synchronises) and returns cumulative stats */
 int grp_get_kernel_stats(grp_ctx* ctx, grp_kernel_stat out[GRP_K_COUNT]);

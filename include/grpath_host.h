@@ -32,6 +32,8 @@ typedef struct
   int (*sync)(void* ctx);
   /* optional (may be NULL): query + decision on the device, grp_classify_reads */
   int (*classify_reads)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, grp_read_decision* out);
+  /* optional (may be NULL): all ID blocks of one read at once, grp_insert_read */
+  int (*insert_read)(void* ctx, const void* reads, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset);
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */

@@ -290,3 +290,53 @@ def test_max_geometry_h8_span32(oracle, native):
         for res in omf.query_read(seq):
             assert (int(tiles[ti]["top_id"]), int(tiles[ti]["top_count"])) == (res[0], res[1])
             ti += 1
+
+
+def test_insert_read_equals_block_loop(oracle, native):
+    """grp_insert_read (two launches for all ID blocks of a read) == the reference's
+    sequence of insertMIBF calls, including ranks shared by several blocks (a read
+    built from a repeated segment) and the trimmed-read ID rule."""
+    eng, oseeds, omf, m = _mk(oracle, native, m=oracle.load().orc_calc_optimal_size(400_000, 1, 0.1))
+    unit = random_reads(1, 1700, 1700, seed=91)[0]
+    rep = (unit * 8)[:12500]                       # blocks of 3 tiles share k-mers across blocks
+    reads = random_reads(4, 4000, 9000, seed=92) + [rep, random_reads(1, 70000, 70000, seed=93)[0]]
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    for s in reads:
+        omf.bv_insert_read(s)
+    assert eng.finalize() == omf.finalize()
+    next_id = 0
+    # whole-read rule (goldrush_path.cpp:982-994), block of 3 tiles
+    for ri in (4, 0, 4, 2):
+        seq = reads[ri]
+        nt = len(seq) // TILE
+        next_id += 1
+        eng.insert_read(b, ri, 0, nt, 3, next_id, 0)
+        for bs in range(0, nt, 3):
+            omf.insert_read_tiles(seq, bs, min(bs + 3, nt), next_id + bs // 3)
+        next_id += len(seq) // (TILE * 3)
+        ids, counts = eng.export_ids()
+        assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts()), ri
+    assert omf.counts().max() >= 4  # shared ranks really were replayed block by block
+    # trimmed rule (:1040-1053): tiles [ts, te], IDs first + (bs - ts + 1) // block
+    for ri, ts, te, blk in ((1, 1, len(reads[1]) // TILE - 1, 2), (3, 0, len(reads[3]) // TILE - 2, 1), (4, 2, 11, 4)):
+        seq = reads[ri]
+        next_id += 1
+        eng.insert_read(b, ri, ts, te + 1, blk, next_id, 1)
+        bs = ts
+        while bs <= te:
+            be = min(bs + blk - 1, te)
+            omf.insert_read_tiles(seq, bs, be + 1, next_id + (bs - ts + 1) // blk)
+            bs += blk
+        next_id += (te - ts) // blk
+        ids, counts = eng.export_ids()
+        assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts()), (ri, ts, te)
+    # more than 64 blocks: falls back to one launch per block
+    seq = reads[5]
+    nt = len(seq) // TILE
+    eng.insert_read(b, 5, 0, nt, 1, 5000, 0)
+    for bs in range(nt):
+        omf.insert_read_tiles(seq, bs, bs + 1, 5000 + bs)
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts())
+    _compare_queries(eng, omf, b, reads)
