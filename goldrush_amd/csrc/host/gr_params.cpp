@@ -69,13 +69,30 @@ calc_optimal_size(uint64_t entries, unsigned hash_num, double occupancy)
   return approx + (64 - approx % 64);
 }
 
+namespace {
+// pow(10.0, -(c - 33) / 10.0) for every char value: the same libm call the
+// reference makes per base (calc_phred_average.cpp:21-24), made once
+struct DelogTable
+{
+  double v[256];
+  DelogTable()
+  {
+    for (int c = 0; c < 256; ++c) {
+      const int q = (int)((char)c - 33);
+      v[c] = std::pow(10.0, -q / 10.0);
+    }
+  }
+};
+const DelogTable kDelog;
+} // namespace
+
 void
 calc_phred_average(const char* qual, size_t n, uint32_t& avg, uint32_t& delta)
 {
+  // same left-to-right double summation as the reference => bit-identical sums
   double total = 0.0, first = 0.0;
   for (size_t i = 0; i < n; ++i) {
-    const int q = (int)(qual[i] - 33);
-    total += std::pow(10.0, -q / 10.0);
+    total += kDelog.v[(unsigned char)qual[i]];
     if (i == n / 2 - 1) {
       first = total;
     }
@@ -92,8 +109,7 @@ sum_phred(const char* qual, size_t n)
 {
   double total = 0;
   for (size_t i = 0; i < n; ++i) {
-    const int q = (int)(qual[i] - 33);
-    total += std::pow(10.0, -q / 10.0);
+    total += kDelog.v[(unsigned char)qual[i]];
   }
   return total;
 }
