@@ -78,6 +78,11 @@ struct grp_ctx
   grp_tile_summary* h_tiles = nullptr; // pinned staging
   uint64_t h_tiles_cap = 0;
   grp_id_count* h_lists = nullptr; // pinned staging of the list prefix
+  // small windows: kernel writes straight into mapped host memory
+  grp_tile_summary* h_small_tiles = nullptr;
+  grp_id_count* h_small_lists = nullptr;
+  grp_tile_summary* dmap_small_tiles = nullptr;
+  grp_id_count* dmap_small_lists = nullptr;
   // insert scratch
   unsigned long long* d_dedup = nullptr;
   uint64_t dedup_cap = 0;
@@ -146,6 +151,8 @@ set_err(const grp_ctx* ctx, int code, const char* fmt, ...)
 
 constexpr uint32_t FILL_CHUNK = 2048; // read positions per fill workgroup
 constexpr uint64_t LIST_PREFIX = 8192; // list entries copied back together with the tile summaries
+constexpr uint32_t SMALL_TILES = 256;  // windows up to this many tiles use the direct (zero-copy) path
+constexpr uint32_t SMALL_STRIDE = 32;  // list entries per tile in the direct path
 constexpr int THREADS = 256;
 
 // ---- ntHash (btllib::SeedNtHash, restated; see DESIGN.md "Hash") -----------
@@ -606,7 +613,9 @@ k_query(DevFilter f,
         uint64_t lists_cap,
         unsigned long long* __restrict__ ctr,
         uint32_t* __restrict__ flagged_out, // indices of flagged tiles (NULL in the redo launch)
-        uint32_t flagged_cap)
+        uint32_t flagged_cap,
+        uint32_t direct_stride) // != 0: tile i owns lists_out[i*stride ..) (no arena, no counters:
+                                // small windows write straight into mapped host memory)
 {
   extern __shared__ uint4 smem4[];
   ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
@@ -785,17 +794,21 @@ k_query(DevFilter f,
       msum += sRed[2 * w + 1];
     }
     const uint32_t n = sListN;
-    const bool flagged = sOverflow != 0u || n > list_cap_lds;
+    const bool flagged = sOverflow != 0u || n > list_cap_lds || (direct_stride != 0u && n > direct_stride);
     uint64_t lo = 0;
-    if (n && !flagged) {
+    if (direct_stride != 0u) {
+      lo = (uint64_t)out_idx * direct_stride;
+    } else if (n && !flagged) {
       lo = atomicAdd(&ctr[3], (unsigned long long)n);
     }
     sListOff = (uint32_t)lo;
     if (flagged) {
       sListN = 0; // nothing is copied out; the full-capacity launch redoes this tile
-      const unsigned long long fi = atomicAdd(&ctr[4], 1ull);
-      if (flagged_out && fi < flagged_cap) {
-        flagged_out[fi] = out_idx;
+      if (direct_stride == 0u) {
+        const unsigned long long fi = atomicAdd(&ctr[4], 1ull);
+        if (flagged_out && fi < flagged_cap) {
+          flagged_out[fi] = out_idx;
+        }
       }
     }
     grp_tile_summary ts;
@@ -1366,14 +1379,18 @@ query_geom(const grp_ctx* c, bool full)
 
 template<int HH>
 int
-launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, const uint32_t* d_tile_idx, const QueryGeom& g, uint64_t list_cap)
+launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, const uint32_t* d_tile_idx, const QueryGeom& g, uint64_t list_cap, grp_tile_summary* out_tiles = nullptr, grp_id_count* out_lists = nullptr, uint32_t direct_stride = 0)
 {
+  if (!out_tiles) {
+    out_tiles = c->d_tiles;
+    out_lists = c->d_lists;
+  }
   auto go = [&](auto kern) -> int {
     int rc = ensure_lds(c, kern, g.lds);
     if (rc != GRP_OK) {
       return rc;
     }
-    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, c->d_tiles, c->d_lists, list_cap, reinterpret_cast<unsigned long long*>(c->d_qctr), d_tile_idx ? nullptr : c->d_flag_idx, (uint32_t)c->d_flag_cap);
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->d_qctr), d_tile_idx ? nullptr : c->d_flag_idx, (uint32_t)c->d_flag_cap, direct_stride);
     return GRP_OK;
   };
   // 2 frames per lane and pass: 2*H*4 quad reads in flight per lane (measured best on MI355X)
@@ -1522,6 +1539,10 @@ grp_create(const grp_params* p, grp_ctx** out)
   CREATE_TRY(hipMalloc(&c->d_qctr, 8 * sizeof(uint64_t)));
   CREATE_TRY(hipHostMalloc(&c->h_qctr, 8 * sizeof(uint64_t), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&c->h_lists, LIST_PREFIX * sizeof(grp_id_count), hipHostMallocDefault));
+  CREATE_TRY(hipHostMalloc(&c->h_small_tiles, SMALL_TILES * sizeof(grp_tile_summary), hipHostMallocMapped));
+  CREATE_TRY(hipHostMalloc(&c->h_small_lists, (size_t)SMALL_TILES * SMALL_STRIDE * sizeof(grp_id_count), hipHostMallocMapped));
+  CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->dmap_small_tiles), c->h_small_tiles, 0));
+  CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->dmap_small_lists), c->h_small_lists, 0));
   CREATE_TRY(hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
@@ -1561,6 +1582,12 @@ grp_destroy(grp_ctx* c)
   }
   if (c->h_lists) {
     (void)hipHostFree(c->h_lists);
+  }
+  if (c->h_small_tiles) {
+    (void)hipHostFree(c->h_small_tiles);
+  }
+  if (c->h_small_lists) {
+    (void)hipHostFree(c->h_small_lists);
   }
   (void)hipFree(c->d_dedup);
   (void)hipFree(c->d_ir_keys);
@@ -1978,6 +2005,63 @@ grp_query_tiles(grp_ctx* c,
   }
   if (!tiles_out) {
     return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: tiles_out is NULL");
+  }
+  if (nt <= SMALL_TILES) {
+    // latency path (insert-heavy phases query one read at a time): the kernel
+    // writes summaries and lists straight into mapped host memory, no copies,
+    // no counters; one stream synchronisation
+    const uint64_t t0 = r->tile0[first];
+    const uint64_t probes = count_probes(c, r, first, count);
+    {
+      const QueryGeom g = query_geom(c, false);
+      Timer t(c, GRP_K_QUERY, probes);
+      int lrc = GRP_OK;
+      DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, nt, t0, nullptr, g, (uint64_t)SMALL_TILES * SMALL_STRIDE, c->dmap_small_tiles, c->dmap_small_lists, SMALL_STRIDE));
+      if (lrc != GRP_OK) {
+        return lrc;
+      }
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    bool any_flagged = false;
+    uint64_t used = 0;
+    for (uint64_t i = 0; i < nt; ++i) {
+      any_flagged = any_flagged || c->h_small_tiles[i].list_n == GRP_TILE_FLAGGED;
+      used += c->h_small_tiles[i].list_n;
+    }
+    if (!any_flagged) {
+      if (list_used) {
+        *list_used = used;
+      }
+      if (used > list_cap) {
+        return set_err(c, GRP_ERR_NOMEM, "grp_query_tiles: %llu list entries needed, capacity %llu", (unsigned long long)used, (unsigned long long)list_cap);
+      }
+      uint64_t off = 0;
+      for (uint64_t i = 0; i < nt; ++i) {
+        grp_tile_summary ts = c->h_small_tiles[i];
+        grp_id_count* src = c->h_small_lists + i * SMALL_STRIDE;
+        if (ts.list_n) {
+          memcpy(lists_out + off, src, ts.list_n * sizeof(grp_id_count));
+          if (ts.list_n > 1) {
+            std::sort(lists_out + off, lists_out + off + ts.list_n, [](const grp_id_count& a, const grp_id_count& b) {
+              return a.count != b.count ? a.count > b.count : a.id < b.id;
+            });
+          }
+        }
+        ts.list_off = (uint32_t)off;
+        off += ts.list_n;
+        tiles_out[i] = ts;
+        if (stats) {
+          stats->hits += ts.hits;
+          stats->misses += ts.misses;
+        }
+      }
+      if (stats) {
+        stats->queries = probes / c->params.h;
+      }
+      return GRP_OK;
+    }
+    // a tile needs the worst-case table or a longer list: take the general path
   }
   if (nt > c->h_tiles_cap) {
     if (c->h_tiles) {
