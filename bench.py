@@ -133,8 +133,31 @@ def main():
     rb = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
     t_synth = time.time() - t0
     t0 = time.time()
-    eng.bv_insert(rb)  # every rank fills its own replica (reads are on every GPU)
-    eng.sync()
+    if world == 1:
+        eng.bv_insert(rb)
+        eng.sync()
+    else:
+        # the fill shards by reads; the merge is a bitwise OR, done as an
+        # all-gather of the plain bit vectors (RCCL has no OR reduction) + local ORs
+        shard = (a.reads + world - 1) // world
+        lo, hi = min(rank * shard, a.reads), min((rank + 1) * shard, a.reads)
+        eng.bv_insert(rb, lo, hi - lo)
+        eng.sync()
+        nbytes = eng.bv_words() * 4
+        mine = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        eng.bv_export_device(mine.data_ptr())
+        if coll_dev == "cuda":
+            allbv = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
+            dist.all_gather_into_tensor(allbv, mine)
+        else:
+            tmp = torch.empty(nbytes * world, dtype=torch.uint8)
+            dist.all_gather_into_tensor(tmp, mine.cpu())
+            allbv = tmp.cuda()
+        torch.cuda.synchronize()
+        for p in range(world):
+            if p != rank:
+                eng.bv_merge_device(allbv.data_ptr() + p * nbytes)
+        del allbv, mine
     t_fill = time.time() - t0
     fill_stats = eng.kernel_stats()["fill"]
     pop = eng.finalize()
@@ -142,13 +165,21 @@ def main():
     # ---- phase 2: order-exact classification, windows sharded over the ranks ----
     allgather = None
     if world > 1:
+        bufs = {}  # per message size: device in/out tensors + pinned host mirror (no allocation per window)
+
         def allgather(user, send, nbytes, recv):  # noqa: E306
             src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
-            t_in = torch.from_numpy(src).to(coll_dev)
-            t_out = torch.empty(nbytes * world, dtype=torch.uint8, device=coll_dev)
-            dist.all_gather_into_tensor(t_out, t_in)
             dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
-            dst[:] = t_out.cpu().numpy()
+            b = bufs.get(nbytes)
+            if b is None:
+                pin = coll_dev == "cuda"
+                b = (torch.empty(nbytes, dtype=torch.uint8, device=coll_dev), torch.empty(nbytes * world, dtype=torch.uint8, device=coll_dev),
+                     torch.empty(nbytes * world, dtype=torch.uint8, pin_memory=pin))
+                bufs[nbytes] = b
+            b[0].copy_(torch.from_numpy(src), non_blocking=True)
+            dist.all_gather_into_tensor(b[1], b[0])
+            b[2].copy_(b[1])  # device -> pinned host, synchronises
+            dst[:] = b[2].numpy()
             return 0
 
     cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
@@ -227,7 +258,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC pass of the same kernel, scaled by probes)", "kernel": "k_query", "launches": kq["launches"], "avg_launch_ms": avg_ms,
                          "probes_per_launch": probes_per_launch, "bytes_per_probe": 128},
-            "aux": {"fill_reads_per_s": a.reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] / t_fill / 1e9, "fill_s": t_fill, "synth_s": t_synth,
+            "aux": {"fill_reads_per_s": a.reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill,
+                    "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors all-gathered and OR-merged" % world, "synth_s": t_synth,
                     "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts")},
                     "query_kernel_s": kq["ms"] * 1e-3, "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
                     "wall_s": dt},

@@ -320,6 +320,19 @@ k_fill(DevFilter f, DevReads rd, const DevSeeds* __restrict__ sd, uint64_t chunk
   }
 }
 
+// dst |= src, 16 bytes per lane (streaming)
+__global__ void __launch_bounds__(THREADS)
+k_bv_or(uint4* __restrict__ dst, const uint4* __restrict__ src, uint64_t n4, uint32_t* __restrict__ dst_tail, const uint32_t* __restrict__ src_tail, uint32_t n_tail)
+{
+  for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * THREADS) {
+    const uint4 a = dst[i], b = src[i];
+    dst[i] = make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n_tail) {
+    dst_tail[threadIdx.x] |= src_tail[threadIdx.x];
+  }
+}
+
 // ---- finalize: plain bit vector -> 64-byte buckets -----------------------------
 
 __global__ void __launch_bounds__(THREADS)
@@ -1779,6 +1792,52 @@ grp_bv_insert(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count)
     HIP_TRY(c, hipGetLastError());
     b += nb;
   }
+  return GRP_OK;
+}
+
+int
+grp_bv_words(const grp_ctx* c, uint64_t* n_words32)
+{
+  if (!c || !n_words32) {
+    return GRP_ERR_INVALID;
+  }
+  *n_words32 = c->n_bv_words;
+  return GRP_OK;
+}
+
+int
+grp_bv_export_device(grp_ctx* c, void* d_dst)
+{
+  if (!c || !d_dst) {
+    return GRP_ERR_INVALID;
+  }
+  if (c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_bv_export_device after grp_finalize");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(d_dst, c->f.bv, c->n_bv_words * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return GRP_OK;
+}
+
+int
+grp_bv_merge_device(grp_ctx* c, const void* d_src)
+{
+  if (!c || !d_src) {
+    return GRP_ERR_INVALID;
+  }
+  if (c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_bv_merge_device after grp_finalize: the bit vector is immutable");
+  }
+  if ((reinterpret_cast<uintptr_t>(d_src) & 15u) != 0) {
+    return set_err(c, GRP_ERR_INVALID, "grp_bv_merge_device: source must be 16-byte aligned");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t n4 = c->n_bv_words / 4;
+  const uint32_t tail = (uint32_t)(c->n_bv_words - n4 * 4);
+  k_bv_or<<<dim3(4096), dim3(THREADS), 0, c->stream>>>(reinterpret_cast<uint4*>(c->f.bv), static_cast<const uint4*>(d_src), n4, c->f.bv + n4 * 4, static_cast<const uint32_t*>(d_src) + n4 * 4, tail);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return GRP_OK;
 }
 

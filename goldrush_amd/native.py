@@ -75,6 +75,9 @@ SIGNATURES = {
     "grp_reads_free": (None, [_vp]),
     "grp_reads_tile0": (C.POINTER(C.c_uint64), [_vp]),
     "grp_bv_insert": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32]),
+    "grp_bv_words": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "grp_bv_export_device": (C.c_int, [_vp, _vp]),
+    "grp_bv_merge_device": (C.c_int, [_vp, _vp]),
     "grp_finalize": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "grp_query_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(grp_query_stats)]),
     "grp_classify_reads": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp]),
@@ -265,6 +268,17 @@ class Engine:
     def bv_insert(self, batch: ReadBatch, first: int = 0, count: int | None = None):
         count = batch.n_reads - first if count is None else count
         self._check(self.lib.grp_bv_insert(self._h, batch._h, first, count))
+
+    def bv_words(self) -> int:
+        n = C.c_uint64()
+        self._check(self.lib.grp_bv_words(self._h, C.byref(n)))
+        return n.value
+
+    def bv_export_device(self, d_ptr: int):
+        self._check(self.lib.grp_bv_export_device(self._h, C.c_void_p(d_ptr)))
+
+    def bv_merge_device(self, d_ptr: int):
+        self._check(self.lib.grp_bv_merge_device(self._h, C.c_void_p(d_ptr)))
 
     def finalize(self) -> int:
         pop = C.c_uint64()

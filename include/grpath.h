@@ -124,6 +124,21 @@ const uint64_t* grp_reads_tile0(const grp_reads* reads);
 int grp_bv_insert(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count);
 
 /*
+ * Multi-GPU fill: the fill is order-free and its merge is a
+ * bitwise OR, so every rank fills the reads of its shard and the bit vectors are
+ * OR-merged before grp_finalize.  RCCL has no OR reduction; the exchange is an
+ * all-gather of the plain bit vectors (done by the caller, e.g. torch.distributed
+ * on device buffers) followed by local ORs:
+ *   grp_bv_words          number of 32-bit words of the plain bit vector
+ *   grp_bv_export_device  copy it into caller-provided DEVICE memory
+ *   grp_bv_merge_device   bv |= another rank's copy (device memory, 16-B aligned)
+ * All three are only valid before grp_finalize.
+ */
+int grp_bv_words(const grp_ctx* ctx, uint64_t* n_words32);
+int grp_bv_export_device(grp_ctx* ctx, void* d_dst);
+int grp_bv_merge_device(grp_ctx* ctx, const void* d_src);
+
+/*
  * Replaces: miBFCS.setup(); miBFCS.getEmptyMIBF()
  * (goldrush_path.cpp:1203-1205 -> MIBFConstructSupport.hpp:165-181,
  * MIBloomFilter.hpp:165-184, getPop :538-546).  Builds the rank structure,

@@ -340,3 +340,30 @@ def test_insert_read_equals_block_loop(oracle, native):
     ids, counts = eng.export_ids()
     assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts())
     _compare_queries(eng, omf, b, reads)
+
+
+def test_sharded_fill_or_merge(oracle, native):
+    """Multi-GPU fill path on one device: two contexts fill disjoint read shards, the
+    bit vectors are exchanged through device memory and OR-merged; the result equals
+    the single-context fill (and the oracle)."""
+    eng, oseeds, omf, m = _mk(oracle, native)
+    reads = random_reads(10, 1500, 6000, seed=101)
+    seeds = default_seeds(3)
+    a = native.Engine(K, 3, TILE, m, seeds)
+    b2 = native.Engine(K, 3, TILE, m, seeds)
+    ba, bb = a.upload(reads), b2.upload(reads)
+    a.bv_insert(ba, 0, 5)
+    b2.bv_insert(bb, 5, 5)
+    lib = native.load()
+    n = a.bv_words()
+    assert n == (m + 31) // 32
+    buf = lib.grp_synth_alloc(n * 4 + 64)
+    b2.bv_export_device(buf)
+    a.bv_merge_device(buf)
+    lib.grp_synth_free(buf)
+    for s in reads:
+        omf.bv_insert_read(s)
+    assert a.finalize() == omf.finalize()
+    assert np.array_equal(a.export_bits(), omf.bits())
+    with pytest.raises(native.GrpError):
+        a.bv_merge_device(1 << 20)  # after finalize
