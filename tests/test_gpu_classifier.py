@@ -143,3 +143,29 @@ def test_device_decisions_match_host_and_oracle(oracle, native):
     # sub-window
     sub = eng.classify_reads(b, 10, 7)
     assert np.array_equal(sub, dec[10:17])
+
+
+def test_hip_classifier_h5_designed_seed(oracle, native):
+    """C4-like geometry through the whole product path: h = 5 designed (not preset)
+    seeds, 5 silver paths, tile 300, ID blocks of 3 tiles."""
+    from goldrush_amd import host, synth
+    from oracle_engine import serial_reference
+
+    tile, k, h, block = 300, 20, 5, 3
+    seeds = host.make_seed_pattern("", k, 14, h)
+    assert seeds == oracle.make_seed_pattern("", k, 14, h)
+    g = synth.random_genome(120_000, 41)
+    reads = [r[1] for r in synth.make_reads(g, 90, mean_len=4000, min_len=2500, seed=42, max_len=8000)]
+    m = oracle.load().orc_calc_optimal_size(2_500_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, threshold=8, silver=True, target_bases=60_000, max_paths=5)
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    assert eng.finalize() == mf_ref.pop
+    cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=8, k=k, h=h, target_bases=60_000, max_paths=5, silver_path=True)
+    cls.run(b._h, b.lens)
+    eng.sync()
+    assert [c[:8] for c in cls.commits] == exp
+    assert len(cls.rollovers) >= 2
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
