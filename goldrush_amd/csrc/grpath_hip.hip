@@ -95,6 +95,7 @@ struct grp_ctx
   uint32_t* d_ir_counter = nullptr;
   uint64_t ir_cap = 0;
   uint32_t ir_parity = 0;
+  double* d_delog = nullptr; // 10^(-Q/10) table for the FASTQ ingest
   uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE);
   // timing
   bool timing = true;
@@ -1602,6 +1603,7 @@ grp_destroy(grp_ctx* c)
   if (c->h_small_lists) {
     (void)hipHostFree(c->h_small_lists);
   }
+  (void)hipFree(c->d_delog);
   (void)hipFree(c->d_dedup);
   (void)hipFree(c->d_ir_keys);
   (void)hipFree(c->d_ir_masks);
@@ -2650,3 +2652,5 @@ grp_stream(grp_ctx* c)
 }
 
 } // extern "C"
+
+#include "grp_ingest.inc"

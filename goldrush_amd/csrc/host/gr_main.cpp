@@ -3,6 +3,7 @@
 // on an MI355X through libgrpath_hip.so.  There is no CPU path.
 #include "../../../include/grpath.h"
 #include "../../../include/grpath_host.h"
+#include "../../../include/grpath_ingest.h"
 
 static grp_engine_vt
 hip_engine()
@@ -29,6 +30,14 @@ hip_engine()
   vt.insert_read = [](void* c, const void* r, uint32_t ri, uint32_t ts, uint32_t te, uint32_t block, uint32_t first_id, uint32_t off) {
     return grp_insert_read(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), ri, ts, te, block, first_id, off);
   };
+  vt.fastq_parse = [](void* c, const char* text, uint64_t n, int fin, void** out, uint64_t* nrec, uint64_t* used, int* stopped) {
+    return grp_fastq_parse(static_cast<grp_ctx*>(c), text, n, fin, reinterpret_cast<grp_fastq**>(out), nrec, used, stopped);
+  };
+  vt.fastq_records = [](void* fq, grp_fastq_record* out) { return grp_fastq_records(static_cast<grp_fastq*>(fq), out); };
+  vt.fastq_pack = [](void* c, void* fq, const uint32_t* sel, uint32_t n, void** out) {
+    return grp_fastq_pack(static_cast<grp_ctx*>(c), static_cast<grp_fastq*>(fq), sel, n, reinterpret_cast<grp_reads**>(out));
+  };
+  vt.fastq_free = [](void* fq) { grp_fastq_free(static_cast<grp_fastq*>(fq)); };
   return vt;
 }
 

@@ -97,6 +97,12 @@ calc_phred_average(const char* qual, size_t n, uint32_t& avg, uint32_t& delta)
       first = total;
     }
   }
+  phred_from_sums(total, first, n, avg, delta);
+}
+
+void
+phred_from_sums(double total, double first, size_t n, uint32_t& avg, uint32_t& delta)
+{
   double second = total - first;
   second = second / (n * 0.5);
   first = first / (n * 0.5);

@@ -48,36 +48,15 @@ batch_records()
 #define BATCH_RECORDS batch_records()
 constexpr size_t BATCH_BASES = size_t(384) << 20;
 
-struct PackedBatch
+size_t
+ingest_chunk_bytes()
 {
-  std::vector<uint32_t> packed;
-  std::vector<uint64_t> word_off;
-  std::vector<uint32_t> len;
-  std::vector<uint32_t> src; // record index in the RecordBatch
-};
-
-// pack the selected records (2 bits / base); returns false if one of them is not ACGT
-void
-pack_selected(const RecordBatch& rb, const std::vector<uint32_t>& sel, PackedBatch& pb)
-{
-  const size_t n = sel.size();
-  pb.src = sel;
-  pb.len.resize(n);
-  pb.word_off.resize(n + 1);
-  uint64_t w = 0;
-  for (size_t i = 0; i < n; ++i) {
-    pb.word_off[i] = w;
-    pb.len[i] = (uint32_t)rb.rec[sel[i]].seq_len;
-    w += (rb.rec[sel[i]].seq_len + 15) / 16;
-  }
-  pb.word_off[n] = w;
-  pb.packed.resize(w ? w : 1);
-#if defined(_OPENMP)
-#pragma omp parallel for schedule(dynamic, 16)
-#endif
-  for (size_t i = 0; i < n; ++i) {
-    pack_2bit(rb.seq(sel[i]), rb.rec[sel[i]].seq_len, pb.packed.data() + pb.word_off[i]);
-  }
+  static const size_t n = [] {
+    const char* e = getenv("GRP_INGEST_CHUNK");
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? (size_t)v : (size_t)256 << 20;
+  }();
+  return n;
 }
 
 struct PathRun
@@ -88,9 +67,6 @@ struct PathRun
   std::vector<std::string> seeds;
   std::unordered_set<std::string> filter_out_reads;
   std::ofstream out;
-  // classification sink
-  const RecordBatch* cur_batch = nullptr;
-  const PackedBatch* cur_packed = nullptr;
 
   int fail_engine(const char* what)
   {
@@ -98,6 +74,255 @@ struct PathRun
     return 1;
   }
 };
+
+// ---- record sources -----------------------------------------------------------
+// A batch of consecutive FASTQ records; offsets are relative to `text`.
+struct Rec
+{
+  size_t id_off, id_len, seq_off, seq_len, qual_off, qual_len;
+};
+
+struct Batch
+{
+  const char* text = nullptr;
+  std::vector<Rec> rec;
+  std::vector<uint32_t> avg, delta; // calc_phred_average, valid where stats() ran
+  std::vector<uint8_t> non_acgt;    // find_first_not_of("ACGTacgt") != npos
+  bool seq_is_upper = false;        // the host reader folds case while copying
+  std::string id_str(size_t i) const { return std::string(text + rec[i].id_off, rec[i].id_len); }
+};
+
+class RecordSource
+{
+public:
+  virtual ~RecordSource() {}
+  virtual bool ok() const = 0;
+  virtual bool is_fastq() = 0;
+  virtual bool next(Batch& b) = 0;
+  // Phred statistics (and the ACGT check) of the records with seq_len >= min_len
+  virtual void stats(Batch& b, size_t min_len, bool need_acgt) = 0;
+  // the selected records as a batch of packed reads on the device
+  virtual int upload(Batch& b, const std::vector<uint32_t>& sel, std::vector<uint32_t>& lens, void** reads) = 0;
+};
+
+// host reader + host packing (engines without the ingest entry points)
+class HostSource : public RecordSource
+{
+public:
+  HostSource(PathRun& run)
+    : run_(run)
+    , fq_(run.opt.input)
+  {}
+  bool ok() const override { return fq_.ok(); }
+  bool is_fastq() override { return fq_.is_fastq(); }
+  bool next(Batch& b) override
+  {
+    if (!fq_.next_batch(rb_, BATCH_RECORDS, BATCH_BASES)) {
+      return false;
+    }
+    b.text = rb_.text.data();
+    b.rec.resize(rb_.rec.size());
+    for (size_t i = 0; i < rb_.rec.size(); ++i) {
+      const RecordRef& r = rb_.rec[i];
+      b.rec[i] = Rec{ r.id_off, r.id_len, r.seq_off, r.seq_len, r.qual_off, r.qual_len };
+    }
+    b.seq_is_upper = true;
+    return true;
+  }
+  void stats(Batch& b, size_t min_len, bool need_acgt) override
+  {
+    const size_t n = b.rec.size();
+    b.avg.assign(n, 0);
+    b.delta.assign(n, 0);
+    b.non_acgt.assign(n, 0);
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 8)
+#endif
+    for (size_t i = 0; i < n; ++i) {
+      const Rec& r = b.rec[i];
+      if (r.seq_len < min_len) {
+        continue;
+      }
+      calc_phred_average(b.text + r.qual_off, r.qual_len, b.avg[i], b.delta[i]);
+      if (need_acgt) {
+        const char* s = b.text + r.seq_off; // already upper-cased
+        for (size_t j = 0; j < r.seq_len; ++j) {
+          const char c = s[j];
+          if (c != 'A' && c != 'C' && c != 'G' && c != 'T') {
+            b.non_acgt[i] = 1;
+            break;
+          }
+        }
+      }
+    }
+  }
+  int upload(Batch& b, const std::vector<uint32_t>& sel, std::vector<uint32_t>& lens, void** reads) override
+  {
+    const size_t n = sel.size();
+    lens.resize(n);
+    word_off_.resize(n + 1);
+    uint64_t w = 0;
+    for (size_t i = 0; i < n; ++i) {
+      word_off_[i] = w;
+      lens[i] = (uint32_t)b.rec[sel[i]].seq_len;
+      w += (b.rec[sel[i]].seq_len + 15) / 16;
+    }
+    word_off_[n] = w;
+    packed_.resize(w ? w : 1);
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (size_t i = 0; i < n; ++i) {
+      pack_2bit(b.text + b.rec[sel[i]].seq_off, b.rec[sel[i]].seq_len, packed_.data() + word_off_[i]);
+    }
+    return run_.vt.reads_upload(run_.ctx, packed_.data(), word_off_.data(), lens.data(), (uint32_t)n, reads);
+  }
+
+private:
+  PathRun& run_;
+  FastqStream fq_;
+  RecordBatch rb_;
+  std::vector<uint32_t> packed_;
+  std::vector<uint64_t> word_off_;
+};
+
+// raw text chunks parsed, filtered and packed on the GPU (grpath_ingest.h)
+class GpuSource : public RecordSource
+{
+public:
+  GpuSource(PathRun& run)
+    : run_(run)
+  {
+    fp_ = fopen(run.opt.input.c_str(), "rb");
+    buf_.resize(ingest_chunk_bytes());
+  }
+  ~GpuSource() override
+  {
+    release();
+    if (fp_) {
+      fclose(fp_);
+    }
+  }
+  bool ok() const override { return fp_ != nullptr; }
+  bool is_fastq() override
+  {
+    if (!fp_) {
+      return false;
+    }
+    const int c = fgetc(fp_);
+    if (c == EOF) {
+      return false;
+    }
+    ungetc(c, fp_);
+    return c == '@';
+  }
+  bool next(Batch& b) override
+  {
+    release();
+    while (!done_) {
+      if (tail_len_ && tail_off_) {
+        memmove(buf_.data(), buf_.data() + tail_off_, tail_len_);
+      }
+      size_t fill = tail_len_;
+      tail_off_ = 0;
+      while (!eof_ && fill < buf_.size()) {
+        const size_t got = fread(buf_.data() + fill, 1, buf_.size() - fill, fp_);
+        if (got == 0) {
+          eof_ = true;
+        }
+        fill += got;
+      }
+      if (fill == 0) {
+        done_ = true;
+        break;
+      }
+      uint64_t n_rec = 0, used = 0;
+      int stopped = 0;
+      if (run_.vt.fastq_parse(run_.ctx, buf_.data(), fill, eof_ ? 1 : 0, &fq_, &n_rec, &used, &stopped) != GRP_OK) {
+        std::cerr << "goldrush-path: FASTQ ingest: " << (run_.vt.last_error ? run_.vt.last_error(run_.ctx) : "failed") << std::endl;
+        failed_ = true;
+        done_ = true;
+        break;
+      }
+      if (n_rec == 0 && !eof_ && !stopped) {
+        // a record longer than the buffer: enlarge and retry with the same bytes
+        release();
+        tail_len_ = fill;
+        buf_.resize(buf_.size() * 2);
+        continue;
+      }
+      tail_off_ = (size_t)used;
+      tail_len_ = fill - (size_t)used;
+      if (eof_ || stopped) {
+        done_ = true;
+      }
+      if (n_rec == 0) {
+        release();
+        continue;
+      }
+      meta_.resize(n_rec);
+      run_.vt.fastq_records(fq_, meta_.data());
+      b.text = buf_.data();
+      b.rec.resize(n_rec);
+      for (size_t i = 0; i < n_rec; ++i) {
+        const grp_fastq_record& m = meta_[i];
+        b.rec[i] = Rec{ (size_t)m.id_off, m.id_len, (size_t)m.seq_off, m.seq_len, (size_t)m.qual_off, m.qual_len };
+      }
+      b.seq_is_upper = false;
+      return true;
+    }
+    return false;
+  }
+  void stats(Batch& b, size_t min_len, bool) override
+  {
+    const size_t n = b.rec.size();
+    b.avg.assign(n, 0);
+    b.delta.assign(n, 0);
+    b.non_acgt.assign(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+      b.non_acgt[i] = (meta_[i].flags & GRP_FQ_NON_ACGT) ? 1 : 0;
+      if (b.rec[i].seq_len >= min_len) {
+        // the device summed left to right in double; log10 / truncation happen here
+        phred_from_sums(meta_[i].phred_sum, meta_[i].phred_first, b.rec[i].qual_len, b.avg[i], b.delta[i]);
+      }
+    }
+  }
+  int upload(Batch& b, const std::vector<uint32_t>& sel, std::vector<uint32_t>& lens, void** reads) override
+  {
+    lens.resize(sel.size());
+    for (size_t i = 0; i < sel.size(); ++i) {
+      lens[i] = (uint32_t)b.rec[sel[i]].seq_len;
+    }
+    return run_.vt.fastq_pack(run_.ctx, fq_, sel.data(), (uint32_t)sel.size(), reads);
+  }
+  bool failed() const { return failed_; }
+
+private:
+  void release()
+  {
+    if (fq_) {
+      run_.vt.fastq_free(fq_);
+      fq_ = nullptr;
+    }
+  }
+  PathRun& run_;
+  FILE* fp_ = nullptr;
+  std::vector<char> buf_;
+  size_t tail_off_ = 0, tail_len_ = 0;
+  bool eof_ = false, done_ = false, failed_ = false;
+  void* fq_ = nullptr;
+  std::vector<grp_fastq_record> meta_;
+};
+
+std::unique_ptr<RecordSource>
+open_source(PathRun& run)
+{
+  const bool gpu = run.vt.fastq_parse && run.vt.fastq_records && run.vt.fastq_pack && run.vt.fastq_free && !getenv("GRP_HOST_INGEST");
+  if (gpu) {
+    return std::unique_ptr<RecordSource>(new GpuSource(run));
+  }
+  return std::unique_ptr<RecordSource>(new HostSource(run));
+}
 
 // goldrush_path.cpp:79-107.  Deterministic form of the OpenMP loop: the first
 // 50000 eligible reads in file order fill the sample; every one of the `jobs`
@@ -115,24 +340,13 @@ calc_min_phred_threshold(PathRun& run)
   std::cerr << "Calculating minimum phred score via median" << std::endl;
   std::vector<uint32_t> scores(MEDIAN_SAMPLES_NEEDED, 0);
   size_t taken = 0, over = 0;
-  FastqStream fq(opt.input);
-  RecordBatch rb;
+  auto src = open_source(run);
+  Batch b;
   bool done = false;
-  while (!done && fq.ok() && fq.next_batch(rb, BATCH_RECORDS, BATCH_BASES)) {
-    // phred of the eligible records of this batch, in parallel, then consumed in order
-    std::vector<uint32_t> avg(rb.rec.size(), 0);
-#if defined(_OPENMP)
-#pragma omp parallel for schedule(dynamic, 8)
-#endif
-    for (size_t i = 0; i < rb.rec.size(); ++i) {
-      if (rb.rec[i].seq_len >= opt.min_length) {
-        uint32_t a, d;
-        calc_phred_average(rb.qual(i), rb.rec[i].qual_len, a, d);
-        avg[i] = a;
-      }
-    }
-    for (size_t i = 0; i < rb.rec.size(); ++i) {
-      if (rb.rec[i].seq_len < opt.min_length) {
+  while (!done && src->ok() && src->next(b)) {
+    src->stats(b, opt.min_length, false);
+    for (size_t i = 0; i < b.rec.size(); ++i) {
+      if (b.rec[i].seq_len < opt.min_length) {
         continue;
       }
       if (taken >= MEDIAN_SAMPLES_NEEDED) {
@@ -142,7 +356,7 @@ calc_min_phred_threshold(PathRun& run)
         }
         continue;
       }
-      scores[taken++] = avg[i];
+      scores[taken++] = b.avg[i];
     }
   }
   const size_t n = taken + over;
@@ -164,84 +378,49 @@ fill_bit_vector(PathRun& run)
   const Opts& opt = run.opt;
   std::cerr << "inserting bit vector" << std::endl;
   const double s_time = now_s();
-  FastqStream fq(opt.input);
-  if (!fq.ok() || !fq.is_fastq()) {
+  auto src = open_source(run);
+  if (!src->ok() || !src->is_fastq()) {
     std::cerr << "Gold Path requires fastq format" << std::endl;
     return 1;
   }
   size_t num_reads = 0, num_passed_reads = 0, by_phred = 0, by_delta = 0, by_length = 0, by_bases = 0;
-  RecordBatch rb;
-  PackedBatch pb;
+  Batch b;
   void* prev = nullptr;
-  std::vector<uint8_t> verdict; // 0 pass, 1 short, 2 phred/delta, 3 invalid bases
-  std::vector<uint8_t> why;     // bit0 phred, bit1 delta
-  while (fq.next_batch(rb, BATCH_RECORDS, BATCH_BASES)) {
-    const size_t n = rb.rec.size();
-    verdict.assign(n, 0);
-    why.assign(n, 0);
-#if defined(_OPENMP)
-#pragma omp parallel for schedule(dynamic, 8)
-#endif
-    for (size_t i = 0; i < n; ++i) {
-      const RecordRef& r = rb.rec[i];
-      if (r.seq_len < opt.min_length) {
-        verdict[i] = 1;
-        continue;
-      }
-      uint32_t avg, delta;
-      calc_phred_average(rb.qual(i), r.qual_len, avg, delta);
-      if (avg < opt.phred_min || delta >= opt.phred_delta) {
-        verdict[i] = 2;
-        why[i] = (uint8_t)((avg < opt.phred_min ? 1 : 0) | (delta >= opt.phred_delta ? 2 : 0));
-        continue;
-      }
-      // seq is already upper-cased; find_first_not_of("ACGTacgt")
-      const char* s = rb.seq(i);
-      bool ok = true;
-      for (size_t j = 0; j < r.seq_len; ++j) {
-        const char c = s[j];
-        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') {
-          ok = false;
-          break;
-        }
-      }
-      if (!ok) {
-        verdict[i] = 3;
-      }
-    }
-    std::vector<uint32_t> sel;
-    for (size_t i = 0; i < n; ++i) {
+  std::vector<uint32_t> sel, lens;
+  while (src->next(b)) {
+    src->stats(b, opt.min_length, true);
+    sel.clear();
+    for (size_t i = 0; i < b.rec.size(); ++i) {
       ++num_reads;
-      switch (verdict[i]) {
-        case 0:
-          ++num_passed_reads;
-          sel.push_back((uint32_t)i);
-          break;
-        case 1:
-          ++by_length;
-          break;
-        case 2:
-          if (opt.verbose) {
-            by_phred += (why[i] & 1) ? 1 : 0;
-            by_delta += (why[i] & 2) ? 1 : 0;
-          }
-          run.filter_out_reads.insert(rb.id_str(i));
-          break;
-        default:
-          ++by_bases;
-          run.filter_out_reads.insert(rb.id_str(i));
-          break;
+      if (b.rec[i].seq_len < opt.min_length) { // :261-265
+        ++by_length;
+        continue;
       }
+      const bool low = b.avg[i] < opt.phred_min, hairpin = b.delta[i] >= opt.phred_delta;
+      if (low || hairpin) { // :275-292
+        if (opt.verbose) {
+          by_phred += low ? 1 : 0;
+          by_delta += hairpin ? 1 : 0;
+        }
+        run.filter_out_reads.insert(b.id_str(i));
+        continue;
+      }
+      if (b.non_acgt[i]) { // :293-301
+        ++by_bases;
+        run.filter_out_reads.insert(b.id_str(i));
+        continue;
+      }
+      ++num_passed_reads;
+      sel.push_back((uint32_t)i);
     }
     if (!sel.empty()) {
-      pack_selected(rb, sel, pb);
+      void* h = nullptr;
+      if (src->upload(b, sel, lens, &h) != GRP_OK) {
+        return run.fail_engine("uploading reads");
+      }
       if (prev) {
         run.vt.reads_free(prev); // waits for the previous batch's kernel
         prev = nullptr;
-      }
-      void* h = nullptr;
-      if (run.vt.reads_upload(run.ctx, pb.packed.data(), pb.word_off.data(), pb.len.data(), (uint32_t)sel.size(), &h) != GRP_OK) {
-        return run.fail_engine("uploading reads");
       }
       // multiLensfrHashIterator itr(record.seq, seeds); miBFCS.insertBV(itr)  (:304-305)
       if (run.vt.bv_insert(run.ctx, h, 0, (uint32_t)sel.size()) != GRP_OK) {
@@ -277,20 +456,28 @@ fill_bit_vector(PathRun& run)
   return -1;
 }
 
-// writes one committed read (goldrush_path.cpp:996-1002, 1055-1070)
+// classification sink: writes one committed read (goldrush_path.cpp:996-1002, 1055-1070)
+struct SinkState
+{
+  PathRun* run = nullptr;
+  const Batch* batch = nullptr;
+  const std::vector<uint32_t>* sel = nullptr;
+  std::string upper;
+};
+
 double
 commit_sink(void* user, const gr_commit* c)
 {
-  PathRun& run = *static_cast<PathRun*>(user);
+  SinkState& st = *static_cast<SinkState*>(user);
+  PathRun& run = *st.run;
   if (c->dec.kind != DEC_INSERT_WHOLE && c->dec.kind != DEC_INSERT_TRIMMED) {
     return 0.0;
   }
-  const RecordBatch& rb = *run.cur_batch;
-  const size_t i = run.cur_packed->src[c->read];
-  const RecordRef& r = rb.rec[i];
+  const Batch& b = *st.batch;
+  const Rec& r = b.rec[(*st.sel)[c->read]];
   const char first = run.opt.silver_path ? '@' : '>';
-  const char* seq = rb.seq(i);
-  const char* qual = rb.qual(i);
+  const char* seq = b.text + r.seq_off;
+  const char* qual = b.text + r.qual_off;
   size_t off = 0, n_seq = r.seq_len, n_qual = r.qual_len;
   const char* suffix = "_untrimmed\n";
   if (c->dec.kind == DEC_INSERT_TRIMMED) {
@@ -303,9 +490,20 @@ commit_sink(void* user, const gr_commit* c)
   }
   std::ofstream& o = run.out;
   o.put(first);
-  o.write(rb.id(i), (std::streamsize)r.id_len);
+  o.write(b.text + r.id_off, (std::streamsize)r.id_len);
   o << suffix;
-  o.write(seq + off, (std::streamsize)n_seq);
+  if (b.seq_is_upper) {
+    o.write(seq + off, (std::streamsize)n_seq);
+  } else {
+    // SeqReader folds the case of what the reference later writes
+    st.upper.assign(seq + off, n_seq);
+    for (char& ch : st.upper) {
+      if (ch >= 'a' && ch <= 'z') {
+        ch = (char)(ch - 32);
+      }
+    }
+    o.write(st.upper.data(), (std::streamsize)n_seq);
+  }
   o << std::endl;
   const size_t qoff = std::min(off, r.qual_len);
   if (run.opt.silver_path) {
@@ -320,7 +518,7 @@ void
 rollover_sink(void* user, uint64_t new_path)
 {
   // golden_path_vec.pop_back(); emplace_back(ofstream(prefix + "_" + path + ".fq"))  (:182-184)
-  PathRun& run = *static_cast<PathRun*>(user);
+  PathRun& run = *static_cast<SinkState*>(user)->run;
   run.out.close();
   run.out.open(run.opt.prefix_file + "_" + std::to_string(new_path) + ".fq");
 }
@@ -353,6 +551,37 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     opt.hash_universe = hash_universe(opt.weight, opt.genome_size, opt.hash_num);
   }
   const std::string what = opt.silver_path ? std::to_string(opt.max_paths) + " silver path(s)" : std::string("the golden path");
+  // the engine is set up before the first pass over the input (the Phred median
+  // pass already uses the GPU ingest); the reference's messages keep their order
+  const uint64_t filter_size = calc_optimal_size(opt.hash_universe, 1, opt.occupancy);
+  {
+    std::vector<const char*> sp;
+    for (const auto& s : run.seeds) {
+      sp.push_back(s.c_str());
+    }
+    grp_params gp{};
+    gp.struct_size = sizeof(gp);
+    gp.k = (uint32_t)opt.kmer_size;
+    gp.h = (uint32_t)opt.hash_num;
+    gp.tile = (uint32_t)opt.tile_length;
+    gp.m = filter_size;
+    gp.seeds = sp.data();
+    gp.device = -1;
+    if (run.vt.create(&gp, &run.ctx) != GRP_OK) {
+      std::cerr << "goldrush-path: cannot set up the MI355X engine: " << (run.vt.last_error ? run.vt.last_error(nullptr) : "") << std::endl;
+      return 1;
+    }
+  }
+  struct CtxGuard
+  {
+    PathRun& r;
+    ~CtxGuard()
+    {
+      if (r.ctx) {
+        r.vt.destroy(r.ctx);
+      }
+    }
+  } guard{ run };
   ec = calc_min_phred_threshold(run);
   if (ec >= 0) {
     return ec;
@@ -382,36 +611,7 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   run.out.open(opt.silver_path ? opt.prefix_file + "_1.fq" : opt.prefix_file + ".fa");
   double s_time = now_s();
   std::cerr << "allocating bit vector" << std::endl;
-  const uint64_t filter_size = calc_optimal_size(opt.hash_universe, 1, opt.occupancy);
   std::cerr << "m_filterSize: " << filter_size << std::endl;
-  {
-    std::vector<const char*> sp;
-    for (const auto& s : run.seeds) {
-      sp.push_back(s.c_str());
-    }
-    grp_params gp{};
-    gp.struct_size = sizeof(gp);
-    gp.k = (uint32_t)opt.kmer_size;
-    gp.h = (uint32_t)opt.hash_num;
-    gp.tile = (uint32_t)opt.tile_length;
-    gp.m = filter_size;
-    gp.seeds = sp.data();
-    gp.device = -1;
-    if (run.vt.create(&gp, &run.ctx) != GRP_OK) {
-      std::cerr << "goldrush-path: cannot set up the MI355X engine: " << (run.vt.last_error ? run.vt.last_error(nullptr) : "") << std::endl;
-      return 1;
-    }
-  }
-  struct CtxGuard
-  {
-    PathRun& r;
-    ~CtxGuard()
-    {
-      if (r.ctx) {
-        r.vt.destroy(r.ctx);
-      }
-    }
-  } guard{ run };
   std::cerr << "finished allocating bit vector" << std::endl;
   std::cerr << "in " << std::setprecision(4) << std::fixed << now_s() - s_time << "\n";
   std::cerr << "opening: " << opt.input << std::endl;
@@ -443,21 +643,24 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   cp.world = 1;
   cp.rank = 0;
   Classifier cls(cp, run.vt, run.ctx);
-  cls.set_callbacks(commit_sink, rollover_sink, nullptr, &run);
+  SinkState sink;
+  sink.run = &run;
+  cls.set_callbacks(commit_sink, rollover_sink, nullptr, &sink);
 
   {
-    FastqStream fq(opt.input);
-    RecordBatch rb;
-    PackedBatch pb;
+    auto src = open_source(run);
+    Batch b;
+    std::vector<uint32_t> sel, skipped_before, lens;
     bool finished = false;
-    while (!finished && fq.ok() && fq.next_batch(rb, BATCH_RECORDS, BATCH_BASES)) {
+    while (!finished && src->ok() && src->next(b)) {
       // read_hashing.cpp:35-42 / goldrush_path.cpp:907-932: a read is classified
       // iff it is long enough and not in filter_out_reads
-      std::vector<uint32_t> sel, skipped_before;
+      sel.clear();
+      skipped_before.clear();
       uint32_t skipped = 0;
-      for (size_t i = 0; i < rb.rec.size(); ++i) {
-        bool eligible = rb.rec[i].seq_len >= opt.min_length;
-        if (eligible && !run.filter_out_reads.empty() && run.filter_out_reads.count(rb.id_str(i))) {
+      for (size_t i = 0; i < b.rec.size(); ++i) {
+        bool eligible = b.rec[i].seq_len >= opt.min_length;
+        if (eligible && !run.filter_out_reads.empty() && run.filter_out_reads.count(b.id_str(i))) {
           eligible = false;
         }
         if (eligible) {
@@ -468,14 +671,13 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
           ++skipped;
         }
       }
-      pack_selected(rb, sel, pb);
       void* h = nullptr;
-      if (run.vt.reads_upload(run.ctx, pb.packed.data(), pb.word_off.data(), pb.len.data(), (uint32_t)sel.size(), &h) != GRP_OK) {
+      if (src->upload(b, sel, lens, &h) != GRP_OK) {
         return run.fail_engine("uploading reads");
       }
-      run.cur_batch = &rb;
-      run.cur_packed = &pb;
-      const int rc = cls.run(h, pb.len.data(), 0, (uint32_t)sel.size(), skipped_before.data(), skipped, finished);
+      sink.batch = &b;
+      sink.sel = &sel;
+      const int rc = cls.run(h, lens.data(), 0, (uint32_t)sel.size(), skipped_before.data(), skipped, finished);
       run.vt.reads_free(h);
       if (rc != GRP_OK) {
         std::cerr << "goldrush-path: " << cls.error() << std::endl;

@@ -56,6 +56,10 @@ VT_TYPES = [
     ("sync", C.CFUNCTYPE(C.c_int, _vp)),
     ("classify_reads", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp)),
     ("insert_read", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)),
+    ("fastq_parse", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64, C.c_int, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int))),
+    ("fastq_records", C.CFUNCTYPE(C.c_int, _vp, _vp)),
+    ("fastq_pack", C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_uint32, C.POINTER(_vp))),
+    ("fastq_free", C.CFUNCTYPE(None, _vp)),
 ]
 
 

@@ -114,6 +114,17 @@ SIGNATURES.update({
     "grp_synth_last_error": (C.c_char_p, []),
 })
 
+fastq_record_dtype = np.dtype([("id_off", "<u8"), ("seq_off", "<u8"), ("qual_off", "<u8"), ("id_len", "<u4"), ("seq_len", "<u4"),
+                              ("qual_len", "<u4"), ("flags", "<u4"), ("phred_sum", "<f8"), ("phred_first", "<f8")])
+
+# include/grpath_ingest.h
+SIGNATURES.update({
+    "grp_fastq_parse": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "grp_fastq_records": (C.c_int, [_vp, _vp]),
+    "grp_fastq_pack": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(_vp)]),
+    "grp_fastq_free": (None, [_vp]),
+})
+
 _lib = None
 
 
@@ -263,6 +274,27 @@ class Engine:
         out = C.c_void_p()
         self._check(self.lib.grp_reads_wrap_device(self._h, C.c_void_p(d_ptr), _ptr(word_off), _ptr(lens), len(lens), C.byref(out)))
         return ReadBatch(self, out, len(lens), lens, keep=keep)
+
+    # -- FASTQ ingest on the device (include/grpath_ingest.h)
+    def fastq_parse(self, text: bytes, final_chunk: bool = True):
+        """Returns (handle, records[fastq_record_dtype], bytes_consumed, stopped)."""
+        buf = np.frombuffer(text, dtype=np.uint8) if len(text) else np.zeros(1, dtype=np.uint8)
+        out = C.c_void_p()
+        n_rec, used, stopped = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._check(self.lib.grp_fastq_parse(self._h, _ptr(buf), len(text), 1 if final_chunk else 0, C.byref(out), C.byref(n_rec), C.byref(used), C.byref(stopped)))
+        rec = np.zeros(n_rec.value, dtype=fastq_record_dtype)
+        if n_rec.value:
+            self._check(self.lib.grp_fastq_records(out, _ptr(rec)))
+        return out, rec, used.value, bool(stopped.value)
+
+    def fastq_pack(self, fq_handle, sel, lens) -> "ReadBatch":
+        sel = np.ascontiguousarray(sel, dtype=np.uint32)
+        out = C.c_void_p()
+        self._check(self.lib.grp_fastq_pack(self._h, fq_handle, _ptr(sel), sel.size, C.byref(out)))
+        return ReadBatch(self, out, sel.size, np.ascontiguousarray(lens, dtype=np.uint32))
+
+    def fastq_free(self, fq_handle):
+        self.lib.grp_fastq_free(fq_handle)
 
     # -- phase 1
     def bv_insert(self, batch: ReadBatch, first: int = 0, count: int | None = None):

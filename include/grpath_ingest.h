@@ -1,0 +1,66 @@
+/*
+ * grpath_ingest.h — FASTQ ingest on the GPU: record
+ * splitting, read filters' inputs and 2-bit packing for goldrush-path's three
+ * passes over the input (phred median goldrush_path.cpp:79-107, bit-vector fill
+ * :235-339, classification :1229-1256).  Exported by libgrpath_hip.so.
+ *
+ * The reference gets its records from btllib::SeqReader (external): id = header
+ * up to the first whitespace, 4-line records, sequence case-folded to upper case.
+ * Here a chunk of raw FASTQ text is uploaded once and parsed on the device; the
+ * host keeps the text for the output files and only receives 56 bytes per record.
+ *
+ * Exactness of the Phred filter: calc_phred_average (calc_phred_average.cpp:8-43)
+ * sums 10^(-Q/10) left to right in double precision and truncates
+ * -10*log10(sum/n).  The device performs the SAME left-to-right double sums from
+ * a 256-entry table of the host's pow() values (IEEE additions, no reassociation),
+ * so the sums are bit-identical; log10 and the truncation stay on the host.
+ */
+#ifndef GRPATH_INGEST_H
+#define GRPATH_INGEST_H
+
+#include "grpath.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct grp_fastq grp_fastq; /* a parsed chunk of FASTQ text resident in HBM */
+
+typedef struct
+{
+  uint64_t id_off;    /* byte offset of the id (after '@') inside the chunk */
+  uint64_t seq_off;
+  uint64_t qual_off;
+  uint32_t id_len;    /* up to the first whitespace of the header */
+  uint32_t seq_len;   /* trailing CR / blanks trimmed */
+  uint32_t qual_len;
+  uint32_t flags;     /* GRP_FQ_NON_ACGT: find_first_not_of("ACGTacgt") != npos (goldrush_path.cpp:293) */
+  double phred_sum;   /* sum_{i<qual_len} 10^(-(q_i-33)/10), left to right */
+  double phred_first; /* the same sum after i = qual_len/2 - 1 (0 when never reached) */
+} grp_fastq_record;
+
+#define GRP_FQ_NON_ACGT 1u
+
+/*
+ * Upload and parse `n_bytes` of FASTQ text (host memory; pinned memory is faster).
+ * final_chunk != 0: the text ends the file (a last line without newline is a line).
+ * Returns the number of complete records and how many bytes they span; the caller
+ * re-submits the unconsumed tail at the start of its next chunk.  *stopped is set
+ * when a record's header does not start with '@' (records before it are returned;
+ * the reader ends there, like a reader at end of input).
+ */
+int grp_fastq_parse(grp_ctx* ctx, const char* text, uint64_t n_bytes, int final_chunk, grp_fastq** out, uint64_t* n_records, uint64_t* bytes_consumed, int* stopped);
+/* copy the record table (n_records entries) to the host */
+int grp_fastq_records(grp_fastq* fq, grp_fastq_record* out);
+/*
+ * 2-bit pack the selected records (ascending indices; they must be pure ACGT) into a
+ * read batch that lives on the device — no host packing, no second upload.  The
+ * batch is independent of `fq` afterwards.
+ */
+int grp_fastq_pack(grp_ctx* ctx, grp_fastq* fq, const uint32_t* sel, uint32_t n_sel, grp_reads** out);
+void grp_fastq_free(grp_fastq* fq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -131,14 +131,30 @@ def test_cli_error_paths(oracle, host, tmp_path):
     assert rp.returncode == ro.returncode == 1
 
 
-@pytest.mark.parametrize("batch", ["1", "7", "64"])
-def test_batch_boundaries(oracle, host, tmp_path, batch):
-    """Tiny host batches: the filter set, the skipped-read counter, the classifier
-    state and the silver-path rollover all have to carry across grp_reads uploads."""
+@pytest.mark.parametrize("env", [{"GRP_HOST_INGEST": "1", "GRP_BATCH_RECORDS": "1"}, {"GRP_HOST_INGEST": "1", "GRP_BATCH_RECORDS": "7"},
+                                 {"GRP_HOST_INGEST": "1", "GRP_BATCH_RECORDS": "64"}, {"GRP_INGEST_CHUNK": "9000"}, {"GRP_INGEST_CHUNK": "70001"},
+                                 {"GRP_INGEST_CHUNK": "1000000"}, {}])
+def test_batch_boundaries(oracle, host, tmp_path, env):
+    """Tiny host batches / tiny GPU-ingest chunks (smaller than one record: the buffer
+    has to grow): the filter set, the skipped-read counter, the classifier state and
+    the silver-path rollover all have to carry across uploads; host reader and GPU
+    ingest must give the same files as the oracle."""
     fq = str(tmp_path / "reads.fq")
     _mk_fastq(fq, 200_000, 420, 6000, 4000, seed=15, lower=True, with_n=17, short=9)
     args = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j4", "-d5", "-x10", "-s1011011110110111101101", "-g200000", "-b4", "-H3000000",
             "-P0", "-r0.9", "--silver_path", "-M2", "-m3500", "-i", fq, "--verbose"]
-    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "b" + batch, env={"GRP_BATCH_RECORDS": batch})
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "b", env=env)
     assert len(files) == 2
     assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+
+
+def test_crlf_and_missing_final_newline(oracle, host, tmp_path):
+    fq = tmp_path / "reads.fq"
+    _mk_fastq(str(fq), 150_000, 150, 6000, 4000, seed=25)
+    data = fq.read_bytes().replace(b"\n", b"\r\n")[:-2]
+    fq.write_bytes(data)
+    args = ["-k22", "-w16", "-t500", "-u5", "-a1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g150000", "-b4", "-H3000000",
+            "-P0", "-r0.9", "--silver_path", "-M2", "-m3500", "-i", str(fq), "--verbose"]
+    for env in ({}, {"GRP_HOST_INGEST": "1"}):
+        ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "crlf" + str(len(env)), env=env)
+        assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)

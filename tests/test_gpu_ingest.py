@@ -1,0 +1,118 @@
+"""GPU FASTQ ingest (include/grpath_ingest.h) against the host implementations:
+record extents, id, ACGT flag, bit-identical Phred sums, 2-bit packing."""
+import struct
+
+import numpy as np
+import pytest
+
+from helpers import default_seeds, random_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_parse(text: bytes, final=True):
+    """The host reader's semantics (gr_fastq.cpp): 4-line records, rtrim of CR / blank / tab,
+    id up to the first whitespace; stops at a header that does not start with '@'."""
+    lines, pos = [], 0
+    while True:
+        nl = text.find(b"\n", pos)
+        if nl < 0:
+            if final and pos < len(text):
+                lines.append((pos, len(text)))
+            break
+        lines.append((pos, nl))
+        pos = nl + 1
+    recs = []
+    for r in range(len(lines) // 4):
+        ext = []
+        for s, e in lines[4 * r: 4 * r + 4]:
+            while e > s and text[e - 1:e] in (b"\r", b" ", b"\t"):
+                e -= 1
+            ext.append((s, e))
+        (hs, he), (ss, se), _, (qs, qe) = ext
+        if he == hs or text[hs:hs + 1] != b"@":
+            return recs, True
+        ie = hs + 1
+        while ie < he and not text[ie:ie + 1].isspace():
+            ie += 1
+        recs.append((hs + 1, ie - hs - 1, ss, se - ss, qs, qe - qs))
+    return recs, False
+
+
+def _mk_text(seed, n=40, crlf=False, lower=False, with_n=False, no_final_nl=False):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i, s in enumerate(random_reads(n, 30, 3000, seed=seed)):
+        if lower and i % 3 == 0:
+            s = s.lower()
+        if with_n and i % 5 == 2:
+            s = s[:7] + b"N" + s[8:]
+        q = bytes((rng.integers(0, 60, size=len(s)) + 33).astype(np.uint8))
+        if i % 7 == 0:
+            q = b"@" + q[1:]  # a quality line may start with '@'
+        hdr = b"@read%d" % i + (b" extra\tcomment" if i % 4 == 0 else b"")
+        eol = b"\r\n" if crlf else b"\n"
+        out.append(hdr + eol + s + eol + b"+" + eol + q + eol)
+    text = b"".join(out)
+    if no_final_nl:
+        text = text[:-(2 if crlf else 1)]
+    return text
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(crlf=True), dict(lower=True, with_n=True), dict(no_final_nl=True)])
+def test_parse_matches_host(native, kw):
+    from goldrush_amd import host
+
+    hl = host.load()
+    eng = native.Engine(22, 3, 1000, 1 << 20, default_seeds(3))
+    text = _mk_text(5, **kw)
+    fq, rec, used, stopped = eng.fastq_parse(text)
+    exp, _ = _host_parse(text)
+    assert not stopped and used == len(text) and len(rec) == len(exp)
+    for r, e in zip(rec, exp):
+        assert (int(r["id_off"]), int(r["id_len"]), int(r["seq_off"]), int(r["seq_len"]), int(r["qual_off"]), int(r["qual_len"])) == e
+        seq = text[e[2]: e[2] + e[3]]
+        assert bool(r["flags"] & 1) == any(ch not in b"ACGTacgt" for ch in seq)
+        qual = text[e[4]: e[4] + e[5]]
+        # bit-identical left-to-right double sums (calc_phred_average.cpp:15-30)
+        assert struct.pack("<d", float(r["phred_sum"])) == struct.pack("<d", hl.gr_sum_phred(qual, len(qual)))
+        half = qual[: len(qual) // 2]
+        exp_first = hl.gr_sum_phred(half, len(half)) if len(qual) >= 2 else 0.0
+        assert struct.pack("<d", float(r["phred_first"])) == struct.pack("<d", exp_first)
+    # packing of the ACGT records == host packing
+    sel = [i for i, r in enumerate(rec) if not (r["flags"] & 1)]
+    batch = eng.fastq_pack(fq, sel, rec["seq_len"][sel])
+    seqs = [text[exp[i][2]: exp[i][2] + exp[i][3]] for i in sel]
+    ref = eng.upload(seqs)
+    for j in range(len(sel)):
+        for t in range(len(seqs[j]) // 1000):
+            assert np.array_equal(eng.tile_hashes(batch, j, t), eng.tile_hashes(ref, j, t))
+    with pytest.raises(native.GrpError):
+        eng.fastq_pack(fq, [i for i, r in enumerate(rec) if r["flags"] & 1][:1] or [10**6], [1])
+    eng.fastq_free(fq)
+
+
+def test_chunked_and_malformed(native):
+    eng = native.Engine(22, 3, 1000, 1 << 20, default_seeds(3))
+    text = _mk_text(9, n=25)
+    exp, _ = _host_parse(text)
+    # a chunk that ends in the middle of a record: only complete records are consumed
+    cut = exp[10][4] + 5  # inside the quality line of record 10
+    fq, rec, used, stopped = eng.fastq_parse(text[:cut], final_chunk=False)
+    assert len(rec) == 10 and used == exp[10][0] - 1 and not stopped
+    eng.fastq_free(fq)
+    fq, rec2, used2, _ = eng.fastq_parse(text[used:], final_chunk=True)
+    assert len(rec2) == 15 and used2 == len(text) - used
+    eng.fastq_free(fq)
+    # header not starting with '@' -> reader stops there
+    bad = text[: exp[5][0] - 1] + b"X" + text[exp[5][0]:]
+    fq, rec3, used3, stopped = eng.fastq_parse(bad)
+    assert stopped and len(rec3) == 5
+    eng.fastq_free(fq)
+    # empty input, fewer than four lines
+    fq, rec4, used4, stopped = eng.fastq_parse(b"")
+    assert len(rec4) == 0 and used4 == 0
+    eng.fastq_free(fq)
+    fq, rec5, used5, _ = eng.fastq_parse(b"@a\nACGT\n+\n", final_chunk=True)
+    assert len(rec5) == 0
+    eng.fastq_free(fq)
