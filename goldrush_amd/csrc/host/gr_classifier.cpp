@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 #if defined(_OPENMP)
@@ -99,9 +100,47 @@ Classifier::skip_reads(uint32_t n)
 uint32_t
 Classifier::window_size() const
 {
-  // P(no insert within the window) ~ exp(-0.7) ~ 0.5
-  double s = 0.7 / std::max(p_insert_, 1e-6);
-  uint32_t w = (uint32_t)std::min<double>(std::max(s, 1.0), (double)p_.max_window);
+  // Choose the speculation window S that maximises committed reads per second
+  // under a simple cost model of one round:
+  //   time(S)      = t_fixed(S) + S * (t_read / world + t_host)
+  //   committed(S) = (1 - (1-p)^S) / p        (reads up to and including the first insert)
+  // p = insert probability per read, estimated on two time scales (a burst of
+  // inserts shrinks the window at once; the long average keeps it from growing
+  // to the cap between rare inserts, where every insert would discard half a
+  // huge window).
+  static const double factor = [] {
+    const char* e = getenv("GRP_SPEC_FACTOR");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 1.0;
+  }();
+  const double p = std::min(1.0, std::max(std::max(p_insert_, p_insert_slow_), 1e-7));
+  const double world = (double)p_.world;
+  // measured on MI355X (bench.py --trace): a round costs ~70 us when it takes the
+  // latency path (host decision, < 16 reads), ~170 us with the decision kernel,
+  // plus ~0.15 us of ordered host commit per read; multi-rank rounds add the
+  // all-gather
+  const double t_small = 70e-6, t_large = 170e-6 + (p_.world > 1 ? 200e-6 : 0.0);
+  const double t_host = 0.15e-6;
+  const double t_read = std::max(1e-9, avg_probes_per_read_ / 46e9); // query kernel ~46 G probes/s
+  double best_rate = 0.0;
+  uint32_t best = 1;
+  const double lq = std::log1p(-std::min(p, 0.999999));
+  for (uint32_t S = 1;; S = (S < 8) ? S + 1 : S + S / 4) {
+    if (S > p_.max_window) {
+      S = p_.max_window;
+    }
+    const double committed = (1.0 - std::exp(lq * S)) / p;
+    const double time = (S < 16 ? t_small : t_large) + S * (t_read / world + t_host);
+    const double rate = committed / time;
+    if (rate > best_rate) {
+      best_rate = rate;
+      best = S;
+    }
+    if (S == p_.max_window) {
+      break;
+    }
+  }
+  uint32_t w = (uint32_t)std::min<double>(std::max(best * factor, 1.0), (double)p_.max_window);
   if (p_.world > 1) {
     w = ((w + p_.world - 1) / p_.world) * p_.world;
   }
@@ -361,6 +400,10 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
   for (uint32_t i = 0; i < n; ++i) {
     tile0_[i + 1] = tile0_[i] + lens[i] / p_.tile_length;
   }
+  if (n) {
+    // frames x seeds per read of this range (every tile has ~tile_length frames)
+    avg_probes_per_read_ = (double)tile0_[n] * p_.tile_length * p_.hash_num / n;
+  }
   uint32_t pos = 0;
   int rc = GRP_OK;
   while (pos < n && !finished_) {
@@ -380,6 +423,7 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
       }
       ++n_committed_;
       p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
+      p_insert_slow_ += (1.0 / 8192.0) * ((ins ? 1.0 : 0.0) - p_insert_slow_);
       ++j;
       if (ins) {
         ++n_inserts_;
