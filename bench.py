@@ -265,7 +265,7 @@ def main():
                     "wall_s": dt},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dr, 96, m, seeds, k, tile)
+            out["cpu_baseline"] = cpu_baseline(dr, 1024, m, seeds, k, tile)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
