@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--max-window", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace", action="store_true", help="per-step timing / speculation statistics on stderr")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="developer: no HIP events around the launches (roofline fields become meaningless)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for single-GPU plumbing tests)")
     ap.add_argument("--share-gpu", action="store_true", help="developer: all ranks use GPU 0 (plumbing test on a 1-GPU box, use with --backend gloo)")
     a = ap.parse_args()
@@ -201,6 +202,8 @@ def main():
             sys.stderr.write("step %d: %.1f ms windows=%d queried=%d inserts=%d\n" % (
                 i, (time.perf_counter() - ts) * 1e3, s1["windows"] - s0["windows"], s1["reads_queried"] - s0["reads_queried"], s1["inserts"] - s0["inserts"]))
 
+    if a.no_kernel_timing:
+        eng.set_timing(False)
     for i in range(a.warmup):
         step(i)
     eng.sync()
@@ -260,8 +263,9 @@ def main():
                          "probes_per_launch": probes_per_launch, "bytes_per_probe": 128},
             "aux": {"fill_reads_per_s": a.reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill,
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors all-gathered and OR-merged" % world, "synth_s": t_synth,
-                    "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts")},
-                    "query_kernel_s": kq["ms"] * 1e-3, "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
+                    "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit")},
+                    "query_kernel_s": kq["ms"] * 1e-3, "decide_kernel_s": ks["decide"]["ms"] * 1e-3, "decide_launches": ks["decide"]["launches"],
+                    "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
                     "wall_s": dt},
         }
         if world == 1 and not a.no_cpu_baseline:

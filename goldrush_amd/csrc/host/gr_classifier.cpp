@@ -4,6 +4,7 @@
 #include "gr_params.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +61,8 @@ Classifier::get_state(gr_classifier_state& s) const
   s.reads_queried = n_queried_;
   s.reads_committed = n_committed_;
   s.inserts = n_inserts_;
+  s.seconds_windows = t_windows_;
+  s.seconds_commit = t_commit_;
 }
 
 void
@@ -408,10 +411,13 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
   int rc = GRP_OK;
   while (pos < n && !finished_) {
     const uint32_t S = std::min<uint32_t>(window_size(), n - pos);
+    const auto t0 = std::chrono::steady_clock::now();
     rc = query_window(reads, lens, pos, S);
     if (rc != GRP_OK) {
       return rc;
     }
+    const auto t1 = std::chrono::steady_clock::now();
+    t_windows_ += std::chrono::duration<double>(t1 - t0).count();
     uint32_t j = 0;
     while (j < S) {
       if (skipped_before) {
@@ -434,6 +440,7 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
       }
     }
     pos += j;
+    t_commit_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   }
   if (!finished_) {
     skip_reads(skipped_after);

@@ -62,6 +62,7 @@ private:
   double p_insert_slow_ = 0.0;   // EMA over ~8192 reads
   double avg_probes_per_read_ = 75000.0;
   uint64_t n_windows_ = 0, n_queried_ = 0, n_committed_ = 0, n_inserts_ = 0;
+  double t_windows_ = 0, t_commit_ = 0;
 
   // scratch
   std::vector<uint64_t> tile0_; // tile prefix of the current range, relative to base_

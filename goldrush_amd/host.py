@@ -38,7 +38,8 @@ class gr_classifier_params(C.Structure):
 class gr_classifier_state(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("valid_reads", "total_tiles", "assigned_tiles", "unassigned_tiles", "queries", "hits", "misses", "num_reads_in_path")] + \
                [("phred_sum_in_path", C.c_double), ("inserted_bases", C.c_uint64), ("curr_path", C.c_uint64), ("id", C.c_uint32), ("ids_inserted", C.c_uint32)] + \
-               [(n, C.c_uint64) for n in ("windows", "reads_queried", "reads_committed", "inserts")]
+               [(n, C.c_uint64) for n in ("windows", "reads_queried", "reads_committed", "inserts")] + \
+               [("seconds_windows", C.c_double), ("seconds_commit", C.c_double)]
 
 
 # engine function table: members typed exactly like include/grpath.h

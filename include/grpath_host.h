@@ -135,6 +135,8 @@ typedef struct
   uint32_t id, ids_inserted;
   /* speculation statistics */
   uint64_t windows, reads_queried, reads_committed, inserts;
+  /* wall-clock split of gr_classifier_run: engine calls for the windows vs ordered commit */
+  double seconds_windows, seconds_commit;
 } gr_classifier_state;
 void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
 

@@ -101,7 +101,7 @@ def test_full_size_properties(native):
 def test_device_decisions_match_host_and_oracle(oracle, native):
     """grp_classify_reads (decision kernel) == host decide on grp_query_tiles output
     == oracle smoothing/decision, on the same miBF state; includes reads longer than
-    the kernel's LDS scratch (global-scratch path) and very short reads."""
+    the kernel LDS scratch (global-scratch path) and very short reads."""
     from goldrush_amd import host, synth
 
     tile, k, h = 250, 22, 3
