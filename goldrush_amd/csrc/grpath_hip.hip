@@ -40,10 +40,45 @@ struct EventPair
 
 } // namespace
 
+
+// per-window device / pinned buffers of the query + decision kernels
+struct QuerySlot
+{
+  grp_tile_summary* d_tiles = nullptr;
+  uint64_t d_tiles_cap = 0;
+  grp_id_count* d_lists = nullptr;
+  uint64_t d_lists_cap = 0;
+  uint64_t* d_qctr = nullptr; // [3] list arena cursor, [4] flagged tiles (kept zero between calls)
+  uint64_t* h_qctr = nullptr; // pinned
+  uint32_t* d_flag_idx = nullptr;
+  uint64_t d_flag_cap = 0;
+  // decide scratch
+  uint32_t* d_dec_ids = nullptr;
+  uint8_t* d_dec_asg = nullptr;
+  uint64_t* d_dec_scratch = nullptr;
+  uint64_t d_dec_cap = 0;
+  grp_read_decision* d_dec = nullptr;
+  grp_read_decision* h_dec = nullptr; // pinned
+  uint64_t dec_cap = 0;
+  // a window in flight (grp_classify_reads_begin)
+  hipEvent_t done = nullptr;   // decisions of the window are in h_dec
+  hipEvent_t qdone = nullptr;  // the window's query kernel has finished (decide stream waits on it)
+  bool side_used = false;      // `done` was last recorded on the decide stream
+  bool busy = false;
+  const grp_reads* reads = nullptr;
+  uint32_t first = 0, count = 0;
+  grp_decide_params dp{};
+  uint64_t list_cap = 0;
+  uint64_t t0 = 0, nt = 0, probes = 0;
+};
+
 struct grp_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  // decision kernel + copy-back of a pipelined window run here, next to the following
+  // window's query kernel on `stream`
+  hipStream_t stream2 = nullptr;
   grp_params params{};
   std::vector<std::string> seeds;
   DevSeeds h_seeds{};
@@ -53,28 +88,15 @@ struct grp_ctx
   uint64_t n_bv_words = 0;
   uint64_t n_ovf = 0;    // IDs living in the overflow table
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
-  uint32_t* d_flag_idx = nullptr;
-  uint64_t d_flag_cap = 0;
-  std::vector<uint32_t> h_flagged;
-  // decide scratch
-  uint32_t* d_dec_ids = nullptr;
-  uint8_t* d_dec_asg = nullptr;
-  uint64_t* d_dec_scratch = nullptr;
-  uint64_t d_dec_cap = 0;
-  grp_read_decision* d_dec = nullptr;
-  grp_read_decision* h_dec = nullptr; // pinned
-  uint64_t dec_cap = 0;
+
   uint64_t n_flagged_tiles = 0; // statistics
   uint64_t n_chunks = 0; // rank-build chunks
   uint64_t* d_super = nullptr;
   bool finalized = false;
-  // query scratch
-  grp_tile_summary* d_tiles = nullptr;
-  uint64_t d_tiles_cap = 0;
-  grp_id_count* d_lists = nullptr;
-  uint64_t d_lists_cap = 0;
-  uint64_t* d_qctr = nullptr; // [3] list arena cursor (kept zero between calls)
-  uint64_t* h_qctr = nullptr; // pinned
+  // query scratch: two slots so that a second window can be in flight while the
+  // host commits the first (grp_classify_reads_begin / _end)
+  QuerySlot slot[2];
+  QuerySlot* q = &slot[0];
   grp_tile_summary* h_tiles = nullptr; // pinned staging
   uint64_t h_tiles_cap = 0;
   grp_id_count* h_lists = nullptr; // pinned staging of the list prefix
@@ -1293,8 +1315,10 @@ struct Timer
   grp_ctx* c;
   EventPair ep{};
   bool on = false;
-  Timer(grp_ctx* ctx, int kind, uint64_t units)
+  hipStream_t st;
+  Timer(grp_ctx* ctx, int kind, uint64_t units, hipStream_t on_stream = nullptr)
     : c(ctx)
+    , st(on_stream ? on_stream : ctx->stream)
   {
     c->kstat[kind].launches += 1;
     c->kstat[kind].units += units;
@@ -1311,28 +1335,35 @@ struct Timer
     }
     ep.kind = kind;
     on = true;
-    (void)hipEventRecord(ep.a, c->stream);
+    (void)hipEventRecord(ep.a, st);
   }
   ~Timer()
   {
     if (on) {
-      (void)hipEventRecord(ep.b, c->stream);
+      (void)hipEventRecord(ep.b, st);
       c->pending.push_back(ep);
     }
   }
 };
 
+// accumulate the durations of the launches that have completed; launches still in
+// flight (a pipelined next window) stay pending
 void
 drain_events(grp_ctx* c)
 {
+  std::vector<EventPair> keep;
   for (auto& ep : c->pending) {
+    if (hipEventQuery(ep.b) != hipSuccess) {
+      keep.push_back(ep);
+      continue;
+    }
     float ms = 0.f;
-    if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+    if (hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
       c->kstat[ep.kind].ms += (double)ms;
     }
     c->free_events.push_back(ep);
   }
-  c->pending.clear();
+  c->pending.swap(keep);
 }
 
 uint64_t
@@ -1425,15 +1456,15 @@ int
 launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, const uint32_t* d_tile_idx, const QueryGeom& g, uint64_t list_cap, grp_tile_summary* out_tiles = nullptr, grp_id_count* out_lists = nullptr, uint32_t direct_stride = 0)
 {
   if (!out_tiles) {
-    out_tiles = c->d_tiles;
-    out_lists = c->d_lists;
+    out_tiles = c->q->d_tiles;
+    out_lists = c->q->d_lists;
   }
   auto go = [&](auto kern) -> int {
     int rc = ensure_lds(c, kern, g.lds);
     if (rc != GRP_OK) {
       return rc;
     }
-    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->d_qctr), d_tile_idx ? nullptr : c->d_flag_idx, (uint32_t)c->d_flag_cap, direct_stride);
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), d_tile_idx ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride);
     return GRP_OK;
   };
   // 2 frames per lane and pass: 2*H*4 quad reads in flight per lane (measured best on MI355X)
@@ -1571,6 +1602,7 @@ grp_create(const grp_params* p, grp_ctx** out)
     }                                                                                                                  \
   } while (0)
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc(&c->d_seeds, sizeof(DevSeeds)));
   CREATE_TRY(hipMemcpyAsync(c->d_seeds, &c->h_seeds, sizeof(DevSeeds), hipMemcpyHostToDevice, c->stream));
   c->f.m = p->m;
@@ -1579,14 +1611,18 @@ grp_create(const grp_params* p, grp_ctx** out)
   c->n_bv_words = (p->m + 31) / 32;
   CREATE_TRY(hipMalloc(&c->f.bv, (c->n_bv_words + 3) * sizeof(uint32_t)));
   CREATE_TRY(hipMemsetAsync(c->f.bv, 0, (c->n_bv_words + 3) * sizeof(uint32_t), c->stream));
-  CREATE_TRY(hipMalloc(&c->d_qctr, 8 * sizeof(uint64_t)));
-  CREATE_TRY(hipHostMalloc(&c->h_qctr, 8 * sizeof(uint64_t), hipHostMallocDefault));
+  for (QuerySlot& sl : c->slot) {
+    CREATE_TRY(hipMalloc(&sl.d_qctr, 8 * sizeof(uint64_t)));
+    CREATE_TRY(hipHostMalloc(&sl.h_qctr, 8 * sizeof(uint64_t), hipHostMallocDefault));
+    CREATE_TRY(hipMemsetAsync(sl.d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
+    CREATE_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&sl.qdone, hipEventDisableTiming));
+  }
   CREATE_TRY(hipHostMalloc(&c->h_lists, LIST_PREFIX * sizeof(grp_id_count), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&c->h_small_tiles, SMALL_TILES * sizeof(grp_tile_summary), hipHostMallocMapped));
   CREATE_TRY(hipHostMalloc(&c->h_small_lists, (size_t)SMALL_TILES * SMALL_STRIDE * sizeof(grp_id_count), hipHostMallocMapped));
   CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->dmap_small_tiles), c->h_small_tiles, 0));
   CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->dmap_small_lists), c->h_small_lists, 0));
-  CREATE_TRY(hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
   *out = c;
@@ -1599,6 +1635,9 @@ grp_destroy(grp_ctx* c)
   if (!c) {
     return;
   }
+  if (c->stream2) {
+    (void)hipStreamSynchronize(c->stream2);
+  }
   if (c->stream) {
     (void)hipStreamSynchronize(c->stream);
   }
@@ -1607,6 +1646,28 @@ grp_destroy(grp_ctx* c)
     (void)hipEventDestroy(ep.a);
     (void)hipEventDestroy(ep.b);
   }
+  for (QuerySlot& sl : c->slot) {
+    (void)hipFree(sl.d_tiles);
+    (void)hipFree(sl.d_lists);
+    (void)hipFree(sl.d_qctr);
+    if (sl.h_qctr) {
+      (void)hipHostFree(sl.h_qctr);
+    }
+    (void)hipFree(sl.d_flag_idx);
+    (void)hipFree(sl.d_dec_ids);
+    (void)hipFree(sl.d_dec_asg);
+    (void)hipFree(sl.d_dec_scratch);
+    (void)hipFree(sl.d_dec);
+    if (sl.h_dec) {
+      (void)hipHostFree(sl.h_dec);
+    }
+    if (sl.done) {
+      (void)hipEventDestroy(sl.done);
+    }
+    if (sl.qdone) {
+      (void)hipEventDestroy(sl.qdone);
+    }
+  }
   (void)hipFree(c->d_seeds);
   (void)hipFree(c->f.bv);
   (void)hipFree(c->f.buckets);
@@ -1614,12 +1675,6 @@ grp_destroy(grp_ctx* c)
   (void)hipFree(c->f.counts);
   (void)hipFree(c->f.ovf_keys);
   (void)hipFree(c->f.ovf_ids);
-  (void)hipFree(c->d_tiles);
-  (void)hipFree(c->d_lists);
-  (void)hipFree(c->d_qctr);
-  if (c->h_qctr) {
-    (void)hipHostFree(c->h_qctr);
-  }
   if (c->h_tiles) {
     (void)hipHostFree(c->h_tiles);
   }
@@ -1639,13 +1694,8 @@ grp_destroy(grp_ctx* c)
   (void)hipFree(c->d_ir_locs);
   (void)hipFree(c->d_ir_slots);
   (void)hipFree(c->d_ir_counter);
-  (void)hipFree(c->d_flag_idx);
-  (void)hipFree(c->d_dec_ids);
-  (void)hipFree(c->d_dec_asg);
-  (void)hipFree(c->d_dec_scratch);
-  (void)hipFree(c->d_dec);
-  if (c->h_dec) {
-    (void)hipHostFree(c->h_dec);
+  if (c->stream2) {
+    (void)hipStreamDestroy(c->stream2);
   }
   if (c->stream) {
     (void)hipStreamDestroy(c->stream);
@@ -2007,23 +2057,28 @@ count_probes(const grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t coun
   return probes;
 }
 
-// Enqueue the query kernel for the window (results stay in c->d_tiles /
-// c->d_lists).  No synchronisation.
+// Enqueue the query kernel for the window (results stay in c->q->d_tiles /
+// c->q->d_lists).  No synchronisation.
 int
 enqueue_query(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, uint64_t list_cap, QueryRun& q)
 {
   q.t0 = r->tile0[first];
   q.nt = r->tile0[first + count] - q.t0;
   q.probes = count_probes(c, r, first, count);
-  int rc = ensure_dev(c, c->d_tiles, c->d_tiles_cap, q.nt);
+  int rc = ensure_dev(c, c->q->d_tiles, c->q->d_tiles_cap, q.nt);
   if (rc == GRP_OK) {
-    rc = ensure_dev(c, c->d_lists, c->d_lists_cap, std::max<uint64_t>(list_cap, 1));
+    rc = ensure_dev(c, c->q->d_lists, c->q->d_lists_cap, std::max<uint64_t>(list_cap, 1));
   }
   if (rc == GRP_OK) {
-    rc = ensure_dev(c, c->d_flag_idx, c->d_flag_cap, q.nt);
+    rc = ensure_dev(c, c->q->d_flag_idx, c->q->d_flag_cap, q.nt);
   }
   if (rc != GRP_OK) {
     return rc;
+  }
+  if (c->q->side_used) {
+    // the slot's previous window may still be in its decision kernel on the other stream
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->q->done, 0));
+    c->q->side_used = false;
   }
   const QueryGeom g = query_geom(c, false);
   Timer t(c, GRP_K_QUERY, q.probes);
@@ -2042,15 +2097,15 @@ enqueue_query(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, ui
 int
 enqueue_redo_flagged(grp_ctx* c, const grp_reads* r, uint64_t list_cap, QueryRun& q)
 {
-  q.flagged = c->h_qctr[4];
+  q.flagged = c->q->h_qctr[4];
   c->n_flagged_tiles += q.flagged;
   // continue the list arena where the first launch stopped
-  uint64_t cursor[8] = { 0, 0, 0, c->h_qctr[3], 0, 0, 0, 0 };
-  HIP_TRY(c, hipMemcpyAsync(c->d_qctr, cursor, sizeof(cursor), hipMemcpyHostToDevice, c->stream));
+  uint64_t cursor[8] = { 0, 0, 0, c->q->h_qctr[3], 0, 0, 0, 0 };
+  HIP_TRY(c, hipMemcpyAsync(c->q->d_qctr, cursor, sizeof(cursor), hipMemcpyHostToDevice, c->stream));
   const QueryGeom g = query_geom(c, true);
   Timer t(c, GRP_K_QUERY, 0);
   int lrc = GRP_OK;
-  DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, q.flagged, q.t0, c->d_flag_idx, g, list_cap));
+  DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, q.flagged, q.t0, c->q->d_flag_idx, g, list_cap));
   if (lrc != GRP_OK) {
     return lrc;
   }
@@ -2079,7 +2134,15 @@ grp_query_tiles(grp_ctx* c,
   if (!c->finalized) {
     return set_err(c, GRP_ERR_STATE, "grp_query_tiles before grp_finalize");
   }
+  if (c->slot[0].busy) {
+    return set_err(c, GRP_ERR_STATE, "grp_query_tiles while an asynchronous window is in flight in slot 0");
+  }
+  c->q = &c->slot[0];
   HIP_TRY(c, hipSetDevice(c->device));
+  if (c->q->side_used) {
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->q->done, 0));
+    c->q->side_used = false;
+  }
   const uint64_t nt = r->tile0[first + count] - r->tile0[first];
   if (list_used) {
     *list_used = 0;
@@ -2172,12 +2235,12 @@ grp_query_tiles(grp_ctx* c,
   // one round trip: counters, tile summaries and the first LIST_PREFIX list
   // entries come back together; the counters are re-zeroed for the next call
   auto fetch = [&]() -> int {
-    HIP_TRY(c, hipMemcpyAsync(c->h_qctr, c->d_qctr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_tiles, c->d_tiles, nt * sizeof(grp_tile_summary), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->q->h_qctr, c->q->d_qctr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_tiles, c->q->d_tiles, nt * sizeof(grp_tile_summary), hipMemcpyDeviceToHost, c->stream));
     if (prefix) {
-      HIP_TRY(c, hipMemcpyAsync(c->h_lists, c->d_lists, prefix * sizeof(grp_id_count), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_lists, c->q->d_lists, prefix * sizeof(grp_id_count), hipMemcpyDeviceToHost, c->stream));
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->q->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return GRP_OK;
   };
@@ -2185,7 +2248,7 @@ grp_query_tiles(grp_ctx* c,
   if (rc != GRP_OK) {
     return rc;
   }
-  if (c->h_qctr[4]) {
+  if (c->q->h_qctr[4]) {
     rc = enqueue_redo_flagged(c, r, list_cap, q);
     if (rc == GRP_OK) {
       rc = fetch();
@@ -2196,7 +2259,7 @@ grp_query_tiles(grp_ctx* c,
   }
   drain_events(c);
   memcpy(tiles_out, c->h_tiles, nt * sizeof(grp_tile_summary));
-  const uint64_t used = c->h_qctr[3];
+  const uint64_t used = c->q->h_qctr[3];
   if (list_used) {
     *list_used = used;
   }
@@ -2217,7 +2280,7 @@ grp_query_tiles(grp_ctx* c,
     if (used <= prefix) {
       memcpy(lists_out, c->h_lists, used * sizeof(grp_id_count));
     } else {
-      HIP_TRY(c, hipMemcpy(lists_out, c->d_lists, used * sizeof(grp_id_count), hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy(lists_out, c->q->d_lists, used * sizeof(grp_id_count), hipMemcpyDeviceToHost));
     }
     // canonical order inside each tile's list: count descending, id ascending
     for (uint64_t i = 0; i < nt; ++i) {
@@ -2232,107 +2295,198 @@ grp_query_tiles(grp_ctx* c,
   return GRP_OK;
 }
 
+} // extern "C"
+
+namespace {
+
 int
-grp_classify_reads(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, grp_read_decision* out)
+classify_enqueue_decide(grp_ctx* c, QuerySlot& sl, hipStream_t st)
 {
-  if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads || !dp || (!out && count)) {
-    return set_err(c, GRP_ERR_INVALID, "grp_classify_reads: bad argument");
+  Timer t(c, GRP_K_DECIDE, sl.count, st);
+  k_decide<<<dim3(sl.count), dim3(DECIDE_THREADS), 0, st>>>(sl.reads->dev, sl.first, sl.count, sl.dp, sl.d_tiles, sl.d_lists, sl.list_cap, sl.d_dec_ids, sl.d_dec_asg, sl.d_dec_scratch, sl.d_dec);
+  HIP_TRY(c, hipGetLastError());
+  return GRP_OK;
+}
+
+// counters + decisions to pinned memory, counters re-zeroed, completion event
+int
+classify_enqueue_fetch(grp_ctx* c, QuerySlot& sl, hipStream_t st)
+{
+  HIP_TRY(c, hipMemcpyAsync(sl.h_qctr, sl.d_qctr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemcpyAsync(sl.h_dec, sl.d_dec, (size_t)sl.count * sizeof(grp_read_decision), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipMemsetAsync(sl.d_qctr, 0, 8 * sizeof(uint64_t), st));
+  HIP_TRY(c, hipEventRecord(sl.done, st));
+  sl.side_used = (st != c->stream);
+  return GRP_OK;
+}
+
+// query + decide + fetch of the slot's window, all asynchronous
+int
+classify_enqueue(grp_ctx* c, QuerySlot& sl, bool side)
+{
+  c->q = &sl;
+  QueryRun q;
+  if (sl.nt) {
+    int rc = enqueue_query(c, sl.reads, sl.first, sl.count, sl.list_cap, q);
+    if (rc != GRP_OK) {
+      return rc;
+    }
+  }
+  sl.t0 = q.t0;
+  // optimistic: decide right behind the query, one round trip in the common case.
+  // `side`: decision + copy-back go to the second stream, so that the next window's
+  // query kernel (already queued on the main stream) starts at once.
+  hipStream_t st = c->stream;
+  if (side) {
+    HIP_TRY(c, hipEventRecord(sl.qdone, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream2, sl.qdone, 0));
+    st = c->stream2;
+  }
+  int rc = classify_enqueue_decide(c, sl, st);
+  if (rc == GRP_OK) {
+    rc = classify_enqueue_fetch(c, sl, st);
+  }
+  return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+static int
+classify_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, bool side)
+{
+  if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads || !dp || slot > 1) {
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_reads_begin: bad argument");
   }
   if (!c->finalized) {
     return set_err(c, GRP_ERR_STATE, "grp_classify_reads before grp_finalize");
   }
-  if (count == 0) {
-    return GRP_OK;
+  QuerySlot& sl = c->slot[slot];
+  if (sl.busy) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_reads_begin: slot %u still has a window in flight", slot);
   }
   HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t nt = r->tile0[first + count] - r->tile0[first];
   if (nt > (1u << 30)) {
     return set_err(c, GRP_ERR_INVALID, "grp_classify_reads: %llu tiles in one call (limit 2^30)", (unsigned long long)nt);
   }
+  sl.reads = r;
+  sl.first = first;
+  sl.count = count;
+  sl.dp = *dp;
+  sl.nt = nt;
+  sl.busy = true;
+  if (count == 0) {
+    return GRP_OK;
+  }
+  c->q = &sl;
   // decision buffers + scratch for reads too long for the LDS path
-  if (count > c->dec_cap) {
-    (void)hipFree(c->d_dec);
-    c->d_dec = nullptr;
-    if (c->h_dec) {
-      (void)hipHostFree(c->h_dec);
-      c->h_dec = nullptr;
+  if (count > sl.dec_cap) {
+    (void)hipFree(sl.d_dec);
+    sl.d_dec = nullptr;
+    if (sl.h_dec) {
+      (void)hipHostFree(sl.h_dec);
+      sl.h_dec = nullptr;
     }
-    c->dec_cap = 0;
+    sl.dec_cap = 0;
     const uint64_t cap = std::max<uint64_t>((uint64_t)count + count / 4, 1024);
-    HIP_TRY(c, hipMalloc(&c->d_dec, cap * sizeof(grp_read_decision)));
-    HIP_TRY(c, hipHostMalloc(&c->h_dec, cap * sizeof(grp_read_decision), hipHostMallocDefault));
-    c->dec_cap = cap;
+    HIP_TRY(c, hipMalloc(&sl.d_dec, cap * sizeof(grp_read_decision)));
+    HIP_TRY(c, hipHostMalloc(&sl.h_dec, cap * sizeof(grp_read_decision), hipHostMallocDefault));
+    sl.dec_cap = cap;
   }
-  if (nt + 1 > c->d_dec_cap) {
-    (void)hipFree(c->d_dec_ids);
-    (void)hipFree(c->d_dec_asg);
-    (void)hipFree(c->d_dec_scratch);
-    c->d_dec_ids = nullptr;
-    c->d_dec_asg = nullptr;
-    c->d_dec_scratch = nullptr;
-    c->d_dec_cap = 0;
+  if (nt + 1 > sl.d_dec_cap) {
+    (void)hipFree(sl.d_dec_ids);
+    (void)hipFree(sl.d_dec_asg);
+    (void)hipFree(sl.d_dec_scratch);
+    sl.d_dec_ids = nullptr;
+    sl.d_dec_asg = nullptr;
+    sl.d_dec_scratch = nullptr;
+    sl.d_dec_cap = 0;
     const uint64_t cap = nt + nt / 4 + 64;
-    HIP_TRY(c, hipMalloc(&c->d_dec_ids, cap * 4));
-    HIP_TRY(c, hipMalloc(&c->d_dec_asg, cap));
-    HIP_TRY(c, hipMalloc(&c->d_dec_scratch, cap * 8));
-    c->d_dec_cap = cap;
+    HIP_TRY(c, hipMalloc(&sl.d_dec_ids, cap * 4));
+    HIP_TRY(c, hipMalloc(&sl.d_dec_asg, cap));
+    HIP_TRY(c, hipMalloc(&sl.d_dec_scratch, cap * 8));
+    sl.d_dec_cap = cap;
   }
-  uint64_t list_cap = std::max<uint64_t>(c->d_lists_cap, 4 * nt + 4096);
-  for (int attempt = 0; attempt < 3; ++attempt) {
-    QueryRun q;
-    if (nt) {
-      int rc = enqueue_query(c, r, first, count, list_cap, q);
+  sl.list_cap = std::max<uint64_t>(sl.d_lists_cap, 4 * nt + 4096);
+  return classify_enqueue(c, sl, side);
+}
+
+int
+grp_classify_reads_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot)
+{
+  return classify_begin(c, r, first, count, dp, slot, true);
+}
+
+
+int
+grp_classify_reads_end(grp_ctx* c, uint32_t slot, grp_read_decision* out)
+{
+  if (!c || slot > 1 || !c->slot[slot].busy) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_reads_end: no window in flight in this slot");
+  }
+  QuerySlot& sl = c->slot[slot];
+  sl.busy = false;
+  if (sl.count == 0) {
+    return GRP_OK;
+  }
+  if (!out) {
+    // abandoned window: nothing to wait for, the slot's next use is ordered behind it
+    return GRP_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->q = &sl;
+  HIP_TRY(c, hipEventSynchronize(sl.done));
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (sl.h_qctr[3] > sl.list_cap) { // list arena too small: grow and redo the window
+      sl.list_cap = sl.h_qctr[3] + sl.h_qctr[3] / 4 + 4096;
+      int rc = classify_enqueue(c, sl, false);
       if (rc != GRP_OK) {
         return rc;
       }
-    }
-    auto enqueue_decide = [&]() -> int {
-      Timer t(c, GRP_K_DECIDE, count);
-      k_decide<<<dim3(count), dim3(DECIDE_THREADS), 0, c->stream>>>(
-        r->dev, first, count, *dp, c->d_tiles, c->d_lists, list_cap, c->d_dec_ids, c->d_dec_asg, c->d_dec_scratch, c->d_dec);
-      HIP_TRY(c, hipGetLastError());
-      return GRP_OK;
-    };
-    auto fetch = [&]() -> int {
-      HIP_TRY(c, hipMemcpyAsync(c->h_qctr, c->d_qctr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(c->h_dec, c->d_dec, (size_t)count * sizeof(grp_read_decision), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipMemsetAsync(c->d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      return GRP_OK;
-    };
-    // optimistic: decide right behind the query, one round trip in the common case
-    int rc = enqueue_decide();
-    if (rc == GRP_OK) {
-      rc = fetch();
-    }
-    if (rc != GRP_OK) {
-      return rc;
-    }
-    if (c->h_qctr[3] > list_cap) { // list arena too small: grow and redo the window
-      list_cap = c->h_qctr[3] + c->h_qctr[3] / 4 + 4096;
+      HIP_TRY(c, hipEventSynchronize(sl.done));
       continue;
     }
-    if (c->h_qctr[4]) { // some tiles needed the worst-case table: redo them, decide again
-      rc = enqueue_redo_flagged(c, r, list_cap, q);
+    if (sl.h_qctr[4]) { // some tiles needed the worst-case table: redo them, decide again
+      QueryRun q;
+      q.t0 = sl.t0;
+      int rc = enqueue_redo_flagged(c, sl.reads, sl.list_cap, q);
       if (rc == GRP_OK) {
-        rc = enqueue_decide();
+        rc = classify_enqueue_decide(c, sl, c->stream);
       }
       if (rc == GRP_OK) {
-        rc = fetch();
+        rc = classify_enqueue_fetch(c, sl, c->stream);
       }
       if (rc != GRP_OK) {
         return rc;
       }
-      if (c->h_qctr[3] > list_cap) {
-        list_cap = c->h_qctr[3] + c->h_qctr[3] / 4 + 4096;
-        continue;
-      }
+      HIP_TRY(c, hipEventSynchronize(sl.done));
+      continue;
     }
-    drain_events(c);
-    memcpy(out, c->h_dec, (size_t)count * sizeof(grp_read_decision));
+    if (c->pending.size() > 64) {
+      drain_events(c);
+    }
+    memcpy(out, sl.h_dec, (size_t)sl.count * sizeof(grp_read_decision));
     return GRP_OK;
   }
   return set_err(c, GRP_ERR_NOMEM, "grp_classify_reads: list arena kept overflowing");
+}
+
+int
+grp_classify_reads(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, grp_read_decision* out)
+{
+  if (!out && count) {
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_reads: out is NULL");
+  }
+  int rc = classify_begin(c, r, first, count, dp, 0, false);
+  if (rc != GRP_OK) {
+    if (c && r && r->ctx == c) {
+      c->slot[0].busy = false;
+    }
+    return rc;
+  }
+  return grp_classify_reads_end(c, 0, out);
 }
 
 // ---- insert -------------------------------------------------------------------------
@@ -2469,6 +2623,7 @@ grp_sync(grp_ctx* c)
   if (!c) {
     return GRP_ERR_INVALID;
   }
+  HIP_TRY(c, hipStreamSynchronize(c->stream2));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return GRP_OK;
 }
@@ -2626,12 +2781,12 @@ grp_debug_tile_hashes(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_
 int
 grp_debug_tile_states(grp_ctx* c, uint64_t n_tiles, uint32_t* ids, uint8_t* assigned)
 {
-  if (!c || !ids || !assigned || n_tiles > c->d_dec_cap) {
+  if (!c || !ids || !assigned || n_tiles > c->q->d_dec_cap) { // c->q: the slot of the last window
     return set_err(c, GRP_ERR_INVALID, "grp_debug_tile_states: no such window");
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemcpy(ids, c->d_dec_ids, n_tiles * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(assigned, c->d_dec_asg, n_tiles, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(ids, c->q->d_dec_ids, n_tiles * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(assigned, c->q->d_dec_asg, n_tiles, hipMemcpyDeviceToHost));
   return GRP_OK;
 }
 
@@ -2656,6 +2811,7 @@ grp_get_kernel_stats(grp_ctx* c, grp_kernel_stat out[GRP_K_COUNT])
   if (!c || !out) {
     return GRP_ERR_INVALID;
   }
+  HIP_TRY(c, hipStreamSynchronize(c->stream2));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_events(c);
   memcpy(out, c->kstat, sizeof(c->kstat));
@@ -2668,6 +2824,7 @@ grp_reset_kernel_stats(grp_ctx* c)
   if (!c) {
     return GRP_ERR_INVALID;
   }
+  HIP_TRY(c, hipStreamSynchronize(c->stream2));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   drain_events(c);
   memset(c->kstat, 0, sizeof(c->kstat));

@@ -100,44 +100,67 @@ Classifier::skip_reads(uint32_t n)
   }
 }
 
-uint32_t
-Classifier::window_size() const
+Classifier::Plan
+Classifier::window_plan() const
 {
   // Choose the speculation window S that maximises committed reads per second
-  // under a simple cost model of one round:
-  //   time(S)      = t_fixed(S) + S * (t_read / world + t_host)
-  //   committed(S) = (1 - (1-p)^S) / p        (reads up to and including the first insert)
-  // p = insert probability per read, estimated on two time scales (a burst of
-  // inserts shrinks the window at once; the long average keeps it from growing
-  // to the cap between rare inserts, where every insert would discard half a
-  // huge window).
+  // under a cost model of one round.  p = insert probability per read, estimated
+  // on two time scales (a burst of inserts shrinks the window at once; the long
+  // average keeps it from growing to the cap between rare inserts, where every
+  // insert would discard half a huge window).
+  //   committed(S) = (1 - (1-p)^S) / p        reads up to and including the first insert
+  // synchronous round (query, decide, fetch, commit one after the other):
+  //   time(S) = t_fixed(S) + S * (t_read / world + t_host)
+  // pipelined rounds (the next window runs on the GPU during decide + commit): the
+  // slower of GPU and host per window, plus the abandoned next window whenever the
+  // current one holds an insert:
+  //   time(S) = max(g_fix + S * t_read / world, h_fix + S * t_host) * (1 + P_ins(S))
   static const double factor = [] {
     const char* e = getenv("GRP_SPEC_FACTOR");
     const double v = e ? atof(e) : 0.0;
     return v > 0.0 ? v : 1.0;
   }();
+  // GRP_PIPELINE=off: synchronous rounds only; =force: pipelined whenever the window
+  // cap allows (tests)
+  const char* pipe_env = getenv("GRP_PIPELINE");
+  const bool no_pipeline = pipe_env && !strcmp(pipe_env, "off");
+  const bool force_pipeline = pipe_env && !strcmp(pipe_env, "force");
   const double p = std::min(1.0, std::max(std::max(p_insert_, p_insert_slow_), 1e-7));
   const double world = (double)p_.world;
-  // measured on MI355X (bench.py --trace): a round costs ~70 us when it takes the
-  // latency path (host decision, < 16 reads), ~170 us with the decision kernel,
-  // plus ~0.15 us of ordered host commit per read; multi-rank rounds add the
-  // all-gather
-  const double t_small = 70e-6, t_large = 170e-6 + (p_.world > 1 ? 200e-6 : 0.0);
+  // measured on MI355X (bench.py --trace): a synchronous round costs ~70 us when it
+  // takes the latency path (host decision, < 16 reads), ~170 us with the decision
+  // kernel, plus ~0.15 us of ordered host commit per read; multi-rank rounds add the
+  // all-gather.  Pipelined: ~40 us of ramp-up / tail per query launch on the GPU,
+  // ~60 us of launches and waits per window on the host.
+  const double t_gather = p_.world > 1 ? 200e-6 : 0.0;
+  const double t_small = 70e-6, t_large = 170e-6 + t_gather;
+  const double g_fix = 40e-6, h_fix = 60e-6 + t_gather;
   const double t_host = 0.15e-6;
   const double t_read = std::max(1e-9, avg_probes_per_read_ / 46e9); // query kernel ~46 G probes/s
+  const bool can_pipe = vt_.classify_begin && vt_.classify_end && !no_pipeline;
   double best_rate = 0.0;
   uint32_t best = 1;
+  bool best_pipe = false;
   const double lq = std::log1p(-std::min(p, 0.999999));
   for (uint32_t S = 1;; S = (S < 8) ? S + 1 : S + S / 4) {
     if (S > p_.max_window) {
       S = p_.max_window;
     }
-    const double committed = (1.0 - std::exp(lq * S)) / p;
-    const double time = (S < 16 ? t_small : t_large) + S * (t_read / world + t_host);
-    const double rate = committed / time;
-    if (rate > best_rate) {
-      best_rate = rate;
+    const double p_ins = 1.0 - std::exp(lq * S);
+    const double committed = p_ins / p;
+    const double t_sync = (S < 16 * p_.world ? t_small : t_large) + S * (t_read / world + t_host);
+    if (committed / t_sync > best_rate && !(force_pipeline && best_pipe)) {
+      best_rate = committed / t_sync;
       best = S;
+      best_pipe = false;
+    }
+    if (can_pipe && S >= (force_pipeline ? 1 : 16) * p_.world) {
+      const double t_pipe = std::max(g_fix + S * t_read / world, h_fix + S * t_host) * (1.0 + p_ins);
+      if (committed / t_pipe > best_rate || (force_pipeline && !best_pipe)) {
+        best_rate = committed / t_pipe;
+        best = S;
+        best_pipe = true;
+      }
     }
     if (S == p_.max_window) {
       break;
@@ -147,7 +170,75 @@ Classifier::window_size() const
   if (p_.world > 1) {
     w = ((w + p_.world - 1) / p_.world) * p_.world;
   }
-  return w;
+  return Plan{ w, best_pipe };
+}
+
+int
+Classifier::gather_decisions(uint32_t q)
+{
+  const uint32_t world = p_.world;
+  if (world > 1) {
+    dec_all_.resize((size_t)q * world);
+    if (!allgather_cb_) {
+      err_ = "world > 1 but no allgather callback";
+      return GRP_ERR_INVALID;
+    }
+    int rc = allgather_cb_(user_, dec_.data(), (uint64_t)q * sizeof(gr_read_decision), dec_all_.data());
+    if (rc != 0) {
+      err_ = "allgather callback failed";
+      return GRP_ERR_INVALID;
+    }
+  } else {
+    dec_all_.swap(dec_);
+  }
+  ++n_windows_;
+  return GRP_OK;
+}
+
+// enqueue this rank's slice of the window [pos, pos+S) in an engine slot
+int
+Classifier::launch_window(void* reads, uint32_t pos, uint32_t S, uint32_t slot, Flight& f)
+{
+  const uint32_t world = p_.world;
+  const uint32_t q = (S + world - 1) / world;
+  const uint32_t my_first = std::min<uint64_t>((uint64_t)pos + (uint64_t)p_.rank * q, (uint64_t)pos + S);
+  const uint32_t my_count = std::min<uint32_t>(q, pos + S - my_first);
+  const grp_decide_params dp{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
+  int rc = vt_.classify_begin(ctx_, reads, base_ + my_first, my_count, &dp, slot);
+  if (rc != GRP_OK) {
+    err_ = std::string("classify_begin: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+    return rc;
+  }
+  n_queried_ += my_count;
+  f.active = true;
+  f.pos = pos;
+  f.S = S;
+  f.slot = slot;
+  f.q = q;
+  f.my_count = my_count;
+  return GRP_OK;
+}
+
+int
+Classifier::finish_window(Flight& f)
+{
+  f.active = false;
+  dec_.assign(f.q, gr_read_decision{});
+  int rc = vt_.classify_end(ctx_, f.slot, dec_.data());
+  if (rc != GRP_OK) {
+    err_ = std::string("classify_end: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+    return rc;
+  }
+  return gather_decisions(f.q);
+}
+
+void
+Classifier::abandon_window(Flight& f)
+{
+  if (f.active) {
+    (void)vt_.classify_end(ctx_, f.slot, nullptr); // results are stale: do not wait for them
+    f.active = false;
+  }
 }
 
 int
@@ -218,22 +309,7 @@ Classifier::query_window(void* reads, const uint32_t* lens, uint32_t first, uint
       std::memcpy(&dec_[j], &rd, sizeof(rd));
     }
   }
-  if (world > 1) {
-    dec_all_.resize((size_t)q * world);
-    if (!allgather_cb_) {
-      err_ = "world > 1 but no allgather callback";
-      return GRP_ERR_INVALID;
-    }
-    int rc = allgather_cb_(user_, dec_.data(), (uint64_t)q * sizeof(gr_read_decision), dec_all_.data());
-    if (rc != 0) {
-      err_ = "allgather callback failed";
-      return GRP_ERR_INVALID;
-    }
-  } else {
-    dec_all_.swap(dec_);
-  }
-  ++n_windows_;
-  return GRP_OK;
+  return gather_decisions(q);
 }
 
 void
@@ -409,22 +485,54 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
   }
   uint32_t pos = 0;
   int rc = GRP_OK;
+  Flight next; // the window after the current one, already on the GPU
   while (pos < n && !finished_) {
-    const uint32_t S = std::min<uint32_t>(window_size(), n - pos);
     const auto t0 = std::chrono::steady_clock::now();
-    rc = query_window(reads, lens, pos, S);
-    if (rc != GRP_OK) {
-      return rc;
+    Flight cur;
+    uint32_t S;
+    if (next.active) {
+      cur = next; // starts at pos: an insert would have abandoned it
+      next.active = false;
+      S = cur.S;
+    } else {
+      const Plan plan = window_plan();
+      S = std::min<uint32_t>(plan.S, n - pos);
+      if (plan.pipelined) {
+        rc = launch_window(reads, pos, S, 0, cur);
+      } else {
+        rc = query_window(reads, lens, pos, S);
+      }
+      if (rc != GRP_OK) {
+        return rc;
+      }
+    }
+    if (cur.active) {
+      if (pos + S < n) {
+        const Plan plan = window_plan();
+        const uint32_t S2 = std::min<uint32_t>(plan.S, n - pos - S);
+        if (plan.pipelined && (S2 >= 16 * p_.world || S2 == plan.S)) {
+          rc = launch_window(reads, pos + S, S2, cur.slot ^ 1u, next);
+        }
+      }
+      if (rc == GRP_OK) {
+        rc = finish_window(cur);
+      }
+      if (rc != GRP_OK) {
+        abandon_window(next);
+        return rc;
+      }
     }
     const auto t1 = std::chrono::steady_clock::now();
     t_windows_ += std::chrono::duration<double>(t1 - t0).count();
     uint32_t j = 0;
+    bool stale = false;
     while (j < S) {
       if (skipped_before) {
         skip_reads(skipped_before[pos + j]);
       }
       const bool ins = commit(reads, lens, pos + j, dec_all_[j], rc);
       if (rc != GRP_OK) {
+        abandon_window(next);
         return rc;
       }
       ++n_committed_;
@@ -433,15 +541,20 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
       ++j;
       if (ins) {
         ++n_inserts_;
-        break; // the miBF changed: later speculative results are stale
+        stale = true; // the miBF changed: later speculative results are stale
+        break;
       }
       if (finished_) {
         break;
       }
     }
+    if (stale || finished_) {
+      abandon_window(next);
+    }
     pos += j;
     t_commit_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   }
+  abandon_window(next);
   if (!finished_) {
     skip_reads(skipped_after);
   }

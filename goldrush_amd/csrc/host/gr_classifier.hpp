@@ -7,7 +7,9 @@
 // order, and as soon as one read inserts (which changes the miBF) the rest of
 // the window is discarded and queried again.  The window size adapts to the
 // observed insert rate, so the result is identical to the serial loop while
-// the insert-free stretches run as large GPU batches.
+// the insert-free stretches run as large GPU batches.  With an engine that has
+// classify_begin / classify_end the window after the current one is already on
+// the GPU while the host commits (two slots); an insert abandons it.
 #pragma once
 #include "../../../include/grpath_host.h"
 #include "gr_tiles.hpp"
@@ -37,7 +39,21 @@ private:
   void silver_path_check(int& rc);
   void skip_reads(uint32_t n);
   void bump_id();
-  uint32_t window_size() const;
+  struct Plan
+  {
+    uint32_t S;     // reads in the next window
+    bool pipelined; // worth keeping a second window in flight
+  };
+  Plan window_plan() const;
+  struct Flight
+  {
+    bool active = false;
+    uint32_t pos = 0, S = 0, slot = 0, q = 0, my_count = 0;
+  };
+  int launch_window(void* reads, uint32_t pos, uint32_t S, uint32_t slot, Flight& f);
+  int finish_window(Flight& f);
+  void abandon_window(Flight& f);
+  int gather_decisions(uint32_t q);
 
   gr_classifier_params p_;
   grp_engine_vt vt_;

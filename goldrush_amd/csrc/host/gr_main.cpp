@@ -30,6 +30,10 @@ hip_engine()
   vt.insert_read = [](void* c, const void* r, uint32_t ri, uint32_t ts, uint32_t te, uint32_t block, uint32_t first_id, uint32_t off) {
     return grp_insert_read(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), ri, ts, te, block, first_id, off);
   };
+  vt.classify_begin = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot) {
+    return grp_classify_reads_begin(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, slot);
+  };
+  vt.classify_end = [](void* c, uint32_t slot, grp_read_decision* out) { return grp_classify_reads_end(static_cast<grp_ctx*>(c), slot, out); };
   vt.fastq_parse = [](void* c, const char* text, uint64_t n, int fin, void** out, uint64_t* nrec, uint64_t* used, int* stopped) {
     return grp_fastq_parse(static_cast<grp_ctx*>(c), text, n, fin, reinterpret_cast<grp_fastq**>(out), nrec, used, stopped);
   };

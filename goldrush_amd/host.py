@@ -57,6 +57,8 @@ VT_TYPES = [
     ("sync", C.CFUNCTYPE(C.c_int, _vp)),
     ("classify_reads", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp)),
     ("insert_read", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)),
+    ("classify_begin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32)),
+    ("classify_end", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, _vp)),
     ("fastq_parse", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64, C.c_int, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int))),
     ("fastq_records", C.CFUNCTYPE(C.c_int, _vp, _vp)),
     ("fastq_pack", C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_uint32, C.POINTER(_vp))),
@@ -186,8 +188,9 @@ def hip_engine_vt() -> grp_engine_vt:
     """Function table filled with the grp_* symbols of libgrpath_hip.so."""
     lib = native.load()
     vt = grp_engine_vt()
+    alias = {"classify_begin": "classify_reads_begin", "classify_end": "classify_reads_end"}
     for name, ftype in VT_TYPES:
-        sym = getattr(lib, "grp_" + name)
+        sym = getattr(lib, "grp_" + alias.get(name, name))
         setattr(vt, name, C.cast(sym, ftype))
     return vt
 

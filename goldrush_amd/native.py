@@ -81,6 +81,8 @@ SIGNATURES = {
     "grp_finalize": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "grp_query_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(grp_query_stats)]),
     "grp_classify_reads": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp]),
+    "grp_classify_reads_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32]),
+    "grp_classify_reads_end": (C.c_int, [_vp, C.c_uint32, _vp]),
     "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_insert_read": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_reset_ids": (C.c_int, [_vp]),
@@ -346,6 +348,25 @@ class Engine:
         out = np.zeros(count, dtype=decision_dtype)
         dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
         self._check(self.lib.grp_classify_reads(self._h, batch._h, first, count, C.byref(dp), _ptr(out)))
+        return out
+
+    def classify_begin(self, batch: ReadBatch, first: int, count: int, slot: int, threshold=10, unassigned_min=5, assigned_max=1):
+        """Enqueue query + decision of a window in slot 0 / 1 (asynchronous)."""
+        if first < 0 or count < 0 or first + count > batch.n_reads:
+            raise GrpError(GRP_ERR_INVALID, f"reads [{first}, {first + count}) outside the batch of {batch.n_reads}")
+        dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
+        self._check(self.lib.grp_classify_reads_begin(self._h, batch._h, first, count, C.byref(dp), slot))
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[slot] = count
+
+    def classify_end(self, slot: int, abandon: bool = False):
+        """Wait for the slot's window and return its decisions (None when abandoned)."""
+        count = getattr(self, "_inflight", {}).pop(slot, 0)
+        if abandon:
+            self._check(self.lib.grp_classify_reads_end(self._h, slot, None))
+            return None
+        out = np.zeros(count, dtype=decision_dtype)
+        self._check(self.lib.grp_classify_reads_end(self._h, slot, _ptr(out)))
         return out
 
     def tile_states(self, n_tiles: int):

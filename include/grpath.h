@@ -240,6 +240,16 @@ int grp_classify_reads(grp_ctx* ctx,
                        const grp_decide_params* params,
                        grp_read_decision* decisions_out);
 
+/*
+ * The same in two halves, so that a second window can run on the GPU while the host
+ * commits the first: _begin enqueues query + decision + copy-back of the window into
+ * one of two slots (0 / 1) and returns at once; _end waits for that slot and delivers
+ * the decisions.  Windows execute in the order of their _begin calls, stream-ordered
+ * with grp_insert_tiles / grp_insert_read like every other call.
+ */
+int grp_classify_reads_begin(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot);
+int grp_classify_reads_end(grp_ctx* ctx, uint32_t slot, grp_read_decision* decisions_out);
+
 /* ---- phase 2: ID insert ---------------------------------------------------- */
 /*
  * Replaces: miBFCS.insertMIBF(*miBF, hashed_values, tile_start, tile_end, id)

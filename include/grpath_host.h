@@ -35,6 +35,9 @@ typedef struct
   int (*classify_reads)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, grp_read_decision* out);
   /* optional (may be NULL): all ID blocks of one read at once, grp_insert_read */
   int (*insert_read)(void* ctx, const void* reads, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset);
+  /* optional (both or none): pipelined windows, grp_classify_reads_begin / _end */
+  int (*classify_begin)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot);
+  int (*classify_end)(void* ctx, uint32_t slot, grp_read_decision* out);
   /* optional (all four or none): FASTQ ingest on the device, grpath_ingest.h */
   int (*fastq_parse)(void* ctx, const char* text, uint64_t n_bytes, int final_chunk, void** fq_out, uint64_t* n_records, uint64_t* bytes_consumed, int* stopped);
   int (*fastq_records)(void* fq, grp_fastq_record* out);

@@ -9,13 +9,16 @@ from goldrush_amd import host, native
 
 
 class OracleEngine:
-    def __init__(self, orc, m, seeds, tile, k, reads):
+    def __init__(self, orc, m, seeds, tile, k, reads, pipelined=False):
+        self.pipelined = pipelined
         self.orc = orc
         self.oseeds = orc.Seeds(seeds)
         self.mf = orc.MiBF(m, self.oseeds, tile, k)
         self.tile, self.k = tile, k
         self.reads = reads
         self.n_queries = 0
+        self.n_begun = 0
+        self.n_abandoned = 0
         for s in reads:
             self.mf.bv_insert_read(s)
         self.mf.finalize()
@@ -47,6 +50,39 @@ class OracleEngine:
                 off += len(lst)
             return 0
 
+        # pipelined windows: the decisions are taken at _begin (the GPU engine runs the
+        # window in stream order, i.e. before any insert issued later) and handed out
+        # at _end; a NULL `out` abandons the window
+        slots = {}
+
+        def classify_begin(ctx, reads, first, count, dp_p, slot):
+            assert slot in (0, 1) and slot not in slots, "slot busy"
+            dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
+            self.n_queries += count
+            self.n_begun += 1
+            out = []
+            for r in range(first, first + count):
+                res = self.mf.query_read(self.reads[r])
+                lists = [sorted(((int(a), int(b)) for a, b in x[2]), key=lambda t: (-t[1], t[0])) for x in res]
+                tiles, flat = host.tiles_from([x[0] for x in res], lists)
+                d = host.decide_read(tiles, flat, len(res), dp.threshold, dp.unassigned_min, dp.assigned_max)
+                d.hits = sum(int(x[3][1]) for x in res)
+                d.misses = sum(int(x[3][2]) for x in res)
+                out.append(d)
+            slots[slot] = out
+            return 0
+
+        def classify_end(ctx, slot, out_p):
+            assert slot in slots, "no window in flight"
+            decs = slots.pop(slot)
+            if not out_p:
+                self.n_abandoned += 1
+                return 0
+            arr = C.cast(out_p, C.POINTER(host.gr_read_decision))
+            for i, d in enumerate(decs):
+                arr[i] = d
+            return 0
+
         def insert_tiles(ctx, reads, ri, ts, te, id_):
             self.mf.insert_read_tiles(self.reads[ri], ts, te, id_)
             return 0
@@ -61,7 +97,10 @@ class OracleEngine:
         def last_error(ctx):
             return b"oracle engine"
 
-        impl = {"query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync, "last_error": last_error}
+        impl = {}
+        if self.pipelined:
+            impl.update({"classify_begin": classify_begin, "classify_end": classify_end})
+        impl.update({"query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync, "last_error": last_error})
         for name, ftype in host.VT_TYPES:
             if name in impl:
                 cb = ftype(impl[name])

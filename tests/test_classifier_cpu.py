@@ -50,6 +50,30 @@ def test_classifier_matches_serial_loop(oracle, native, max_window):
         assert st["reads_queried"] == len(exp)  # no speculation, no waste
 
 
+@pytest.mark.parametrize("max_window", [16, 40, 4096])
+def test_pipelined_windows_match_serial_loop(oracle, native, max_window, monkeypatch):
+    """Two windows in flight (classify_begin / classify_end): a window begun before an
+    insert must never be committed after it."""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine, serial_reference
+
+    monkeypatch.setenv("GRP_PIPELINE", "force")
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    reads = _workload()
+    m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=90_000, max_paths=2)
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads, pipelined=True)
+    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, target_bases=90_000, max_paths=2, silver_path=True, max_window=max_window)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    finished = cls.run(None, lens, skipped_before=np.zeros(len(reads), dtype=np.uint32))
+    assert _strip(cls.commits) == exp
+    assert cls.rollovers == [2] and finished
+    assert np.array_equal(eng.mf.ids(), mf_ref.ids()) and np.array_equal(eng.mf.counts(), mf_ref.counts())
+    assert eng.n_begun >= 2 and eng.n_abandoned >= 1  # the path was exercised, stale windows were dropped
+    assert cls.state()["reads_committed"] == len(exp)
+
+
 def test_skipped_reads_advance_counter(oracle, native):
     from goldrush_amd import host
     from oracle_engine import OracleEngine
@@ -85,7 +109,8 @@ tile, k, h, block = 500, 22, 3, 4
 seeds = default_seeds(h)
 reads = _workload()
 m = orc.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
-eng = OracleEngine(orc, m, seeds, tile, k, reads)   # every rank holds a full replica
+PIPE = os.environ.get("GRP_PIPELINE") == "force"
+eng = OracleEngine(orc, m, seeds, tile, k, reads, pipelined=PIPE)   # every rank holds a full replica
 
 
 def allgather(user, send, nbytes, recv):
@@ -98,7 +123,7 @@ def allgather(user, send, nbytes, recv):
     return 0
 
 
-cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, target_bases=90_000, max_paths=2, silver_path=True, max_window=16,
+cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, target_bases=90_000, max_paths=2, silver_path=True, max_window=8 if PIPE else 16,
                       world=world, rank=rank, allgather=allgather)
 lens = np.array([len(r) for r in reads], dtype=np.uint32)
 cls.run(None, lens)
@@ -110,13 +135,15 @@ tot = torch.tensor([eng.n_queries], dtype=torch.int64)
 mine = int(tot.item())
 dist.all_reduce(tot)
 assert mine < int(tot.item())
+assert not PIPE or (eng.n_begun >= 2 and eng.n_abandoned >= 1)
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, "ok", mine, int(tot.item()))
+print("rank", rank, "ok", mine, int(tot.item()), eng.n_begun, eng.n_abandoned)
 """
 
 
-def test_two_ranks_gloo(oracle, native, tmp_path):
+@pytest.mark.parametrize("pipeline", ["off", "force"])
+def test_two_ranks_gloo(oracle, native, tmp_path, pipeline):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=root))
@@ -125,7 +152,7 @@ def test_two_ranks_gloo(oracle, native, tmp_path):
         port = s.getsockname()[1]
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", GRP_PIPELINE=pipeline)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):

@@ -143,6 +143,31 @@ def test_device_decisions_match_host_and_oracle(oracle, native):
     # sub-window
     sub = eng.classify_reads(b, 10, 7)
     assert np.array_equal(sub, dec[10:17])
+    # two windows in flight (grp_classify_reads_begin / _end): same decisions; an insert
+    # issued after a _begin is ordered behind that window; an abandoned slot is reusable
+    n = len(reads)
+    eng.classify_begin(b, 0, 30, 0)
+    eng.classify_begin(b, 30, n - 30, 1)
+    with pytest.raises(native.GrpError):
+        eng.classify_begin(b, 0, 1, 1)  # slot busy
+    ri = 41
+    eng.insert_tiles(b, ri, 0, len(reads[ri]) // tile, 7777)  # changes read 41's own decision afterwards
+    w0 = eng.classify_end(0)
+    w1 = eng.classify_end(1)
+    assert np.array_equal(w0, dec[:30]) and np.array_equal(w1, dec[30:])
+    with pytest.raises(native.GrpError):
+        eng.classify_end(1)  # nothing in flight
+    eng.classify_begin(b, 0, n, 0)
+    eng.classify_end(0, abandon=True)
+    eng.classify_begin(b, 5, 3, 1)
+    eng.classify_begin(b, 0, n, 0)
+    after = eng.classify_end(0)
+    assert np.array_equal(eng.classify_end(1), after[5:8])
+    assert np.array_equal(after, eng.classify_reads(b))
+    assert int(after[ri]["num_assigned"]) == int(after[ri]["num_tiles"]) > int(dec[ri]["num_assigned"])
+    # empty window
+    eng.classify_begin(b, 3, 0, 0)
+    assert len(eng.classify_end(0)) == 0
 
 
 def test_hip_classifier_h5_designed_seed(oracle, native):

@@ -36,6 +36,17 @@ def test_tile_hashes_match_oracle(oracle, native, h):
             assert np.array_equal(got, exp), (ri, t)
 
 
+def test_nthash_known_answers_btllib(native):
+    """The HIP hash kernel against the known answers of btllib's own test-suite
+    (tests/nthash.cpp, ACATGCATGCA, k = 5; see tests/test_oracle.py)."""
+    eng = native.Engine(5, 1, 7, 1 << 16, ["11111"])
+    b = eng.upload([b"ACATGCATGCA"])
+    got = eng.tile_hashes(b, 0, 0)  # tile 0 = substr(0, 7 + 5 - 1): all 7 frames
+    assert [int(x) for x in got[:3]] == [0xF59ECB45F0E22B9C, 0x38CC00F940AEBDAE, 0x603A48C5A11C794A]
+    assert len(got) == 7
+    eng.close()
+
+
 def test_fill_bits_pop_rank(oracle, native):
     eng, oseeds, omf, m = _mk(oracle, native)
     reads = random_reads(12, 1500, 9000, seed=21) + [b"ACGT" * 6, b"A" * 25, b"ACGTTGCA" * 40]

@@ -116,6 +116,22 @@ def test_hash_properties(oracle):
         assert (f + r) & 0xFFFFFFFFFFFFFFFF == int(h[p]), p
 
 
+# Known answers of btllib's own test-suite (tests/nthash.cpp, "k-mer hash values":
+# seq ACATGCATGCA, k = 5, first hash of the first three k-mers).  btllib is not vendored
+# in /root/reference, so the vectors are quoted from its published source; a contiguous
+# spaced seed has the same base hash as the k-mer ntHash (fwd + rev).
+BTLLIB_KAT_SEQ = b"ACATGCATGCA"
+BTLLIB_KAT = [0xF59ECB45F0E22B9C, 0x38CC00F940AEBDAE, 0x603A48C5A11C794A]
+
+
+def test_nthash_known_answers_btllib(oracle):
+    h = oracle.Seeds(["11111"]).multi_hash(BTLLIB_KAT_SEQ)
+    assert [int(x) for x in h[:3]] == BTLLIB_KAT
+    # canonical: the reverse complement walks the same values backwards
+    rc = _revcomp(BTLLIB_KAT_SEQ)
+    assert [int(x) for x in oracle.Seeds(["11111"]).multi_hash(rc)][::-1] == [int(x) for x in h]
+
+
 def test_mibf_semantics(oracle):
     sd = oracle.Seeds(default_seeds(3))
     m = 1 << 16
