@@ -93,6 +93,13 @@ struct grp_ctx
   uint64_t n_chunks = 0; // rank-build chunks
   uint64_t* d_super = nullptr;
   bool finalized = false;
+  // --ntcard pass (grp_ntcard.inc)
+  uint32_t* d_ntc = nullptr;
+  uint32_t ntc_sbits = 0;
+  uint2* d_ntc_chunks = nullptr;
+  uint64_t ntc_chunks_cap = 0;
+  uint32_t* d_ntc_extra = nullptr;
+  uint64_t ntc_extra_cap = 0;
   // query scratch: two slots so that a second window can be in flight while the
   // host commits the first (grp_classify_reads_begin / _end)
   QuerySlot slot[2];
@@ -1553,7 +1560,9 @@ grp_create(const grp_params* p, grp_ctx** out)
   if (p->tile < p->k + p->h - 1) {
     return set_err(nullptr, GRP_ERR_INVALID, "tile length %u shorter than the longest seed span %u", p->tile, p->k + p->h - 1);
   }
-  if (p->m < 64 || p->m >= (1ULL << 50)) {
+  // m = 0: the size is not known yet (--ntcard estimates it from the reads);
+  // grp_set_filter_size() must follow before the first grp_bv_insert
+  if (p->m != 0 && (p->m < 64 || p->m >= (1ULL << 50))) {
     return set_err(nullptr, GRP_ERR_INVALID, "filter size m=%llu unsupported", (unsigned long long)p->m);
   }
   int ndev = 0;
@@ -1605,12 +1614,14 @@ grp_create(const grp_params* p, grp_ctx** out)
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc(&c->d_seeds, sizeof(DevSeeds)));
   CREATE_TRY(hipMemcpyAsync(c->d_seeds, &c->h_seeds, sizeof(DevSeeds), hipMemcpyHostToDevice, c->stream));
-  c->f.m = p->m;
-  c->f.m_inv = ~0ULL / p->m;
-  // phase 1: plain bit vector (+3 zero pad words for the bucket builder)
-  c->n_bv_words = (p->m + 31) / 32;
-  CREATE_TRY(hipMalloc(&c->f.bv, (c->n_bv_words + 3) * sizeof(uint32_t)));
-  CREATE_TRY(hipMemsetAsync(c->f.bv, 0, (c->n_bv_words + 3) * sizeof(uint32_t), c->stream));
+  if (p->m != 0) {
+    c->f.m = p->m;
+    c->f.m_inv = ~0ULL / p->m;
+    // phase 1: plain bit vector (+3 zero pad words for the bucket builder)
+    c->n_bv_words = (p->m + 31) / 32;
+    CREATE_TRY(hipMalloc(&c->f.bv, (c->n_bv_words + 3) * sizeof(uint32_t)));
+    CREATE_TRY(hipMemsetAsync(c->f.bv, 0, (c->n_bv_words + 3) * sizeof(uint32_t), c->stream));
+  }
   for (QuerySlot& sl : c->slot) {
     CREATE_TRY(hipMalloc(&sl.d_qctr, 8 * sizeof(uint64_t)));
     CREATE_TRY(hipHostMalloc(&sl.h_qctr, 8 * sizeof(uint64_t), hipHostMallocDefault));
@@ -1668,6 +1679,9 @@ grp_destroy(grp_ctx* c)
       (void)hipEventDestroy(sl.qdone);
     }
   }
+  (void)hipFree(c->d_ntc);
+  (void)hipFree(c->d_ntc_chunks);
+  (void)hipFree(c->d_ntc_extra);
   (void)hipFree(c->d_seeds);
   (void)hipFree(c->f.bv);
   (void)hipFree(c->f.buckets);
@@ -1842,6 +1856,26 @@ grp_reads_tile0(const grp_reads* r)
 // ---- fill ---------------------------------------------------------------------------
 
 int
+grp_set_filter_size(grp_ctx* c, uint64_t m)
+{
+  if (!c || m < 64 || m >= (1ULL << 50)) {
+    return set_err(c, GRP_ERR_INVALID, "grp_set_filter_size: filter size m=%llu unsupported", (unsigned long long)m);
+  }
+  if (c->f.m != 0) {
+    return set_err(c, GRP_ERR_STATE, "grp_set_filter_size: the filter already has m=%llu bits", (unsigned long long)c->f.m);
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t words = (m + 31) / 32;
+  HIP_TRY(c, hipMalloc(&c->f.bv, (words + 3) * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemsetAsync(c->f.bv, 0, (words + 3) * sizeof(uint32_t), c->stream));
+  c->params.m = m;
+  c->f.m = m;
+  c->f.m_inv = ~0ULL / m;
+  c->n_bv_words = words;
+  return GRP_OK;
+}
+
+int
 grp_bv_insert(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count)
 {
   if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads) {
@@ -1849,6 +1883,9 @@ grp_bv_insert(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count)
   }
   if (c->finalized) {
     return set_err(c, GRP_ERR_STATE, "grp_bv_insert after grp_finalize: the bit vector is immutable");
+  }
+  if (c->f.m == 0) {
+    return set_err(c, GRP_ERR_STATE, "grp_bv_insert: the filter size is not set (grp_set_filter_size)");
   }
   HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t ch0 = r->chunk0[first], ch1 = r->chunk0[first + count];
@@ -1895,6 +1932,9 @@ grp_bv_export_device(grp_ctx* c, void* d_dst)
   if (c->finalized) {
     return set_err(c, GRP_ERR_STATE, "grp_bv_export_device after grp_finalize");
   }
+  if (c->f.m == 0) {
+    return set_err(c, GRP_ERR_STATE, "grp_bv_export_device: the filter size is not set (grp_set_filter_size)");
+  }
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemcpyAsync(d_dst, c->f.bv, c->n_bv_words * 4, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1930,6 +1970,9 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
   }
   if (c->finalized) {
     return set_err(c, GRP_ERR_STATE, "grp_finalize called twice");
+  }
+  if (c->f.m == 0) {
+    return set_err(c, GRP_ERR_STATE, "grp_finalize: the filter size is not set (grp_set_filter_size)");
   }
   HIP_TRY(c, hipSetDevice(c->device));
   unsigned long long* d_scalars = nullptr; // [0] pop (popcount), [1] pop (scan), [2] overflow entries
@@ -2840,3 +2883,4 @@ grp_stream(grp_ctx* c)
 } // extern "C"
 
 #include "grp_ingest.inc"
+#include "grp_ntcard.inc"

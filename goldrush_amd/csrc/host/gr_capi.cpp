@@ -50,6 +50,34 @@ gr_sum_phred(const char* qual, size_t n)
 }
 
 unsigned
+gr_ntcard_sbits(uint64_t input_bytes)
+{
+  return gr::ntcard_sbits(input_bytes);
+}
+
+uint64_t
+gr_ntcard_f0(uint64_t zero0, uint64_t zero1, unsigned sbits)
+{
+  return gr::ntcard_f0(zero0, zero1, sbits);
+}
+
+size_t
+gr_ntcard_split(const char* seq, size_t n, unsigned k, unsigned h, uint64_t* run_off, uint64_t* run_len, uint32_t* extra, size_t cap)
+{
+  std::vector<std::pair<size_t, size_t>> runs;
+  std::vector<uint32_t> ex;
+  gr::ntcard_split(seq, n, k, h, runs, ex);
+  for (size_t r = 0; r < runs.size() && r < cap; ++r) {
+    run_off[r] = runs[r].first;
+    run_len[r] = runs[r].second;
+    for (unsigned s = 0; s < h; ++s) {
+      extra[r * h + s] = ex[r * h + s];
+    }
+  }
+  return runs.size();
+}
+
+unsigned
 gr_effective_cpus(void)
 {
   return gr::effective_cpus();

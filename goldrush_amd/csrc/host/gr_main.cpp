@@ -34,6 +34,12 @@ hip_engine()
     return grp_classify_reads_begin(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, slot);
   };
   vt.classify_end = [](void* c, uint32_t slot, grp_read_decision* out) { return grp_classify_reads_end(static_cast<grp_ctx*>(c), slot, out); };
+  vt.ntcard_begin = [](void* c, uint32_t sbits) { return grp_ntcard_begin(static_cast<grp_ctx*>(c), sbits); };
+  vt.ntcard_add = [](void* c, const void* r, uint32_t first, uint32_t count, const uint32_t* extra) {
+    return grp_ntcard_add(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, extra);
+  };
+  vt.ntcard_finish = [](void* c, uint64_t* z) { return grp_ntcard_finish(static_cast<grp_ctx*>(c), z); };
+  vt.set_filter_size = [](void* c, uint64_t m) { return grp_set_filter_size(static_cast<grp_ctx*>(c), m); };
   vt.fastq_parse = [](void* c, const char* text, uint64_t n, int fin, void** out, uint64_t* nrec, uint64_t* used, int* stopped) {
     return grp_fastq_parse(static_cast<grp_ctx*>(c), text, n, fin, reinterpret_cast<grp_fastq**>(out), nrec, used, stopped);
   };

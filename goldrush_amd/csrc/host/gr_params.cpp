@@ -166,6 +166,60 @@ pack_2bit(const char* seq, size_t n, uint32_t* out)
 }
 
 unsigned
+ntcard_sbits(uint64_t input_bytes)
+{
+  return input_bytes < 50000000000ULL ? 7u : 11u;
+}
+
+uint64_t
+ntcard_f0(uint64_t zero0, uint64_t zero1, unsigned sbits)
+{
+  const unsigned r_bits = 27; // nts::rBits
+  const size_t n_samp = 2;    // nts::nSamp
+  // pMean[0] = (p[0][0] + p[1][0]) / (1.0 * nSamp), p[][] unsigned
+  double p_mean0 = 0.0;
+  p_mean0 += (unsigned)zero0;
+  p_mean0 += (unsigned)zero1;
+  p_mean0 /= 1.0 * n_samp;
+  const double f0_mean = (ssize_t)((r_bits * log(2) - log(p_mean0)) * 1.0 * ((size_t)1 << (sbits + r_bits)));
+  return (size_t)f0_mean;
+}
+
+void
+ntcard_split(const char* seq, size_t n, unsigned k, unsigned h, std::vector<std::pair<size_t, size_t>>& runs, std::vector<uint32_t>& extra)
+{
+  runs.clear();
+  extra.clear();
+  size_t start = 0;
+  for (size_t i = 0; i <= n; ++i) {
+    const bool clean = i < n && (kCode.t[(unsigned char)seq[i]] & 4u) == 0;
+    if (!clean) {
+      if (i - start >= k) {
+        runs.emplace_back(start, i - start);
+      }
+      start = i + 1;
+    }
+  }
+  extra.assign(runs.size() * h, 0);
+  std::vector<uint64_t> V(h, 0);
+  std::vector<size_t> last(h, (size_t)-1);
+  for (size_t r = 0; r < runs.size(); ++r) {
+    for (unsigned s = 0; s < h; ++s) {
+      if (runs[r].second >= k + s) {
+        V[s] += runs[r].second - (k + s) + 1;
+        last[s] = r;
+      }
+    }
+  }
+  const uint64_t F = h ? V[0] : 0; // the shortest span has the most windows
+  for (unsigned s = 0; s < h; ++s) {
+    if (V[s]) {
+      extra[last[s] * h + s] = (uint32_t)(F - V[s]);
+    }
+  }
+}
+
+unsigned
 effective_cpus()
 {
   unsigned n = 1;

@@ -4,6 +4,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace gr {
@@ -25,5 +26,18 @@ bool pack_2bit(const char* seq, size_t n, uint32_t* out);
 
 // CPUs this process may actually use: min(affinity mask, cgroup v2 cpu.max quota)
 unsigned effective_cpus();
+
+// ---- --ntcard (goldrush_path/ntcard.hpp) ----------------------------------------
+// nts::sBits for an input of this many bytes (:35, :177-178)
+unsigned ntcard_sbits(uint64_t input_bytes);
+// compEst's F0Mean as getHist stores it (:124-136, :232), from the zero buckets of
+// the two sample tables of one seed
+uint64_t ntcard_f0(uint64_t zero0, uint64_t zero1, unsigned sbits);
+// A record with non-ACGT characters as the engine wants it (grp_ntcard_add): its
+// maximal ACGT runs of at least k bases (offset, length), and per run and seed the
+// number of extra counts of the run's last window — the stale repeats of
+// multiLensfrHashIterator (seed s of span k+s visits its V_s clean windows, the
+// iterator runs max_s V_s frames; multiLensfrHashIterator.hpp:49-68).
+void ntcard_split(const char* seq, size_t n, unsigned k, unsigned h, std::vector<std::pair<size_t, size_t>>& runs, std::vector<uint32_t>& extra);
 
 } // namespace gr

@@ -324,6 +324,104 @@ open_source(PathRun& run)
   return std::unique_ptr<RecordSource>(new HostSource(run));
 }
 
+// goldrush_path.cpp:1109-1112 -> calc_ntcard_genome_size (ntcard.hpp:248-275): the
+// hash stream of EVERY record (no read filter) sampled on the device; the host only
+// turns the zero-bucket counts into F0.  Returns -1 to continue.
+int
+calc_ntcard_genome_size(PathRun& run, uint64_t& genome_size)
+{
+  const Opts& opt = run.opt;
+  const unsigned k = (unsigned)opt.kmer_size, h = (unsigned)opt.hash_num;
+  std::cerr << "Calculating expected entries" << std::endl;
+  const double s_time = now_s();
+  uint64_t input_bytes = 0;
+  {
+    std::ifstream in(opt.input, std::ifstream::ate | std::ifstream::binary); // getInf (:44-49)
+    if (in) {
+      input_bytes = (uint64_t)in.tellg();
+    }
+  }
+  const unsigned sbits = ntcard_sbits(input_bytes);
+  if (run.vt.ntcard_begin(run.ctx, sbits) != GRP_OK) {
+    return run.fail_engine("ntcard tables");
+  }
+  auto src = open_source(run);
+  Batch b;
+  std::vector<uint32_t> sel, lens, extra, run_extra, packed;
+  std::vector<uint64_t> word_off;
+  std::vector<std::pair<size_t, size_t>> runs;
+  // (another format fails in fill_bit_vector, as in the reference; nothing is counted here)
+  const bool readable = src->ok() && src->is_fastq();
+  while (readable && src->next(b)) {
+    src->stats(b, 0, true);
+    sel.clear();
+    // records with other characters go in as their ACGT runs (rare: host packing)
+    lens.clear();
+    extra.clear();
+    word_off.assign(1, 0);
+    packed.clear();
+    for (size_t i = 0; i < b.rec.size(); ++i) {
+      if (!b.non_acgt[i]) {
+        if (b.rec[i].seq_len >= k) {
+          sel.push_back((uint32_t)i);
+        }
+        continue;
+      }
+      const char* seq = b.text + b.rec[i].seq_off;
+      ntcard_split(seq, b.rec[i].seq_len, k, h, runs, run_extra);
+      for (size_t r = 0; r < runs.size(); ++r) {
+        const size_t w0 = packed.size();
+        packed.resize(w0 + (runs[r].second + 15) / 16);
+        pack_2bit(seq + runs[r].first, runs[r].second, packed.data() + w0);
+        lens.push_back((uint32_t)runs[r].second);
+        word_off.push_back(packed.size());
+      }
+      extra.insert(extra.end(), run_extra.begin(), run_extra.end());
+    }
+    if (!lens.empty()) {
+      void* hr = nullptr;
+      if (packed.empty()) {
+        packed.push_back(0);
+      }
+      if (run.vt.reads_upload(run.ctx, packed.data(), word_off.data(), lens.data(), (uint32_t)lens.size(), &hr) != GRP_OK) {
+        return run.fail_engine("uploading reads");
+      }
+      const int rc = run.vt.ntcard_add(run.ctx, hr, 0, (uint32_t)lens.size(), extra.data());
+      run.vt.reads_free(hr);
+      if (rc != GRP_OK) {
+        return run.fail_engine("ntcard");
+      }
+    }
+    if (!sel.empty()) {
+      void* hr = nullptr;
+      if (src->upload(b, sel, lens, &hr) != GRP_OK) {
+        return run.fail_engine("uploading reads");
+      }
+      // stRead (:96-112): multiLensfrHashIterator over the whole sequence, ntComp per seed
+      const int rc = run.vt.ntcard_add(run.ctx, hr, 0, (uint32_t)sel.size(), nullptr);
+      run.vt.reads_free(hr);
+      if (rc != GRP_OK) {
+        return run.fail_engine("ntcard");
+      }
+    }
+  }
+  std::vector<uint64_t> zeros((size_t)h * 2, 0);
+  if (run.vt.ntcard_finish(run.ctx, zeros.data()) != GRP_OK) {
+    return run.fail_engine("ntcard");
+  }
+  std::cerr << "Reapeat profile estimated using ntCard in (sec): " << std::setprecision(4) << std::fixed << now_s() - s_time << "\n";
+  // (setprecision(4) << fixed stay set on std::cerr, as in the reference: the banner
+  // below prints "occupancy: 0.1000" after an ntcard pass)
+  genome_size = 0;
+  for (unsigned i = 0; i < h; ++i) {
+    const uint64_t f0 = ntcard_f0(zeros[2 * i], zeros[2 * i + 1], sbits);
+    std::cerr << "Expected entries for seed pattern " << run.seeds[i] << " : " << f0 << std::endl;
+    genome_size += f0;
+  }
+  std::cerr << "Total expected entries for seed patterns: " << genome_size << std::endl;
+  return -1;
+}
+
 // goldrush_path.cpp:79-107.  Deterministic form of the OpenMP loop: the first
 // 50000 eligible reads in file order fill the sample; every one of the `jobs`
 // threads performs one more fetch_add before it breaks, which only moves the
@@ -543,17 +641,19 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   omp_set_num_threads((int)std::max<size_t>(1, std::min<size_t>(opt.jobs, (size_t)effective_cpus())));
 #endif
   run.seeds = make_seed_pattern(opt.seed_preset, (unsigned)opt.kmer_size, (unsigned)opt.weight, (unsigned)opt.hash_num, true);
-  if (opt.hash_universe == 0) {
-    if (opt.ntcard) {
-      std::cerr << "goldrush-path: --ntcard is not available in this build (it is never passed by bin/goldrush)" << std::endl;
-      return 1;
-    }
+  const bool use_ntcard = opt.hash_universe == 0 && opt.ntcard;
+  if (use_ntcard && !(run.vt.ntcard_begin && run.vt.ntcard_add && run.vt.ntcard_finish && run.vt.set_filter_size)) {
+    std::cerr << "goldrush-path: --ntcard needs an engine with the ntcard entry points" << std::endl;
+    return 1;
+  }
+  if (opt.hash_universe == 0 && !use_ntcard) {
     opt.hash_universe = hash_universe(opt.weight, opt.genome_size, opt.hash_num);
   }
   const std::string what = opt.silver_path ? std::to_string(opt.max_paths) + " silver path(s)" : std::string("the golden path");
   // the engine is set up before the first pass over the input (the Phred median
-  // pass already uses the GPU ingest); the reference's messages keep their order
-  const uint64_t filter_size = calc_optimal_size(opt.hash_universe, 1, opt.occupancy);
+  // pass already uses the GPU ingest); the reference's messages keep their order.
+  // With --ntcard the filter size is only known after the ntcard pass.
+  uint64_t filter_size = use_ntcard ? 0 : calc_optimal_size(opt.hash_universe, 1, opt.occupancy);
   {
     std::vector<const char*> sp;
     for (const auto& s : run.seeds) {
@@ -582,6 +682,18 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
       }
     }
   } guard{ run };
+  if (use_ntcard) {
+    uint64_t genome_size = 0;
+    ec = calc_ntcard_genome_size(run, genome_size);
+    if (ec >= 0) {
+      return ec;
+    }
+    opt.hash_universe = genome_size;
+    filter_size = calc_optimal_size(opt.hash_universe, 1, opt.occupancy);
+    if (run.vt.set_filter_size(run.ctx, filter_size) != GRP_OK) {
+      return run.fail_engine("allocating the bit vector");
+    }
+  }
   ec = calc_min_phred_threshold(run);
   if (ec >= 0) {
     return ec;

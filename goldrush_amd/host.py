@@ -59,6 +59,10 @@ VT_TYPES = [
     ("insert_read", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)),
     ("classify_begin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32)),
     ("classify_end", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, _vp)),
+    ("ntcard_begin", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
+    ("ntcard_add", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp)),
+    ("ntcard_finish", C.CFUNCTYPE(C.c_int, _vp, _vp)),
+    ("set_filter_size", C.CFUNCTYPE(C.c_int, _vp, C.c_uint64)),
     ("fastq_parse", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64, C.c_int, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int))),
     ("fastq_records", C.CFUNCTYPE(C.c_int, _vp, _vp)),
     ("fastq_pack", C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_uint32, C.POINTER(_vp))),
@@ -82,6 +86,9 @@ SIGNATURES = {
     "gr_sum_phred": (C.c_double, [C.c_char_p, C.c_size_t]),
     "gr_pack_2bit": (C.c_int, [C.c_char_p, C.c_size_t, _vp]),
     "gr_effective_cpus": (C.c_uint, []),
+    "gr_ntcard_sbits": (C.c_uint, [C.c_uint64]),
+    "gr_ntcard_f0": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint]),
+    "gr_ntcard_split": (C.c_size_t, [C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, _vp, _vp, _vp, C.c_size_t]),
     "gr_decide_read": (None, [C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _vp, _vp, C.POINTER(gr_read_decision)]),
     "gr_smooth_tiles": (C.c_size_t, [C.c_size_t, _vp, _vp, C.c_size_t, _vp, _vp]),
     "gr_find_longest_stretch": (None, [_vp, C.c_size_t, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
@@ -137,6 +144,16 @@ def pack_2bit(seq: bytes):
     out = np.zeros((len(seq) + 15) // 16 or 1, dtype=np.uint32)
     rc = load().gr_pack_2bit(seq, len(seq), _p(out))
     return rc, out[: (len(seq) + 15) // 16]
+
+
+def ntcard_split(seq: bytes, k: int, h: int):
+    """ACGT runs (offset, length) of a record and the stale repeats [runs, h]."""
+    cap = len(seq) // max(k, 1) + 2
+    off = np.zeros(cap, dtype=np.uint64)
+    ln = np.zeros(cap, dtype=np.uint64)
+    ex = np.zeros(cap * h, dtype=np.uint32)
+    n = load().gr_ntcard_split(seq, len(seq), k, h, _p(off), _p(ln), _p(ex), cap)
+    return [(int(off[i]), int(ln[i])) for i in range(n)], ex[: n * h].reshape(n, h)
 
 
 def tiles_from(ids, lists):

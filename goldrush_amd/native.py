@@ -21,8 +21,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libgrpath_hip.so")
 
 GRP_OK = 0
 GRP_ERR_INVALID, GRP_ERR_NO_DEVICE, GRP_ERR_HIP, GRP_ERR_STATE, GRP_ERR_NOMEM = -1, -2, -3, -4, -5
-GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_COUNT = 0, 1, 2, 3, 4, 5
-KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide")
+GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6
+KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard")
 
 
 class GrpError(RuntimeError):
@@ -74,6 +74,10 @@ SIGNATURES = {
     "grp_reads_wrap_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(_vp)]),
     "grp_reads_free": (None, [_vp]),
     "grp_reads_tile0": (C.POINTER(C.c_uint64), [_vp]),
+    "grp_ntcard_begin": (C.c_int, [_vp, C.c_uint32]),
+    "grp_ntcard_add": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp]),
+    "grp_ntcard_finish": (C.c_int, [_vp, _vp]),
+    "grp_set_filter_size": (C.c_int, [_vp, C.c_uint64]),
     "grp_bv_insert": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32]),
     "grp_bv_words": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "grp_bv_export_device": (C.c_int, [_vp, _vp]),
@@ -297,6 +301,28 @@ class Engine:
 
     def fastq_free(self, fq_handle):
         self.lib.grp_fastq_free(fq_handle)
+
+    # -- phase 0 (--ntcard)
+    def ntcard_begin(self, sbits: int = 7):
+        self._check(self.lib.grp_ntcard_begin(self._h, sbits))
+
+    def ntcard_add(self, batch: ReadBatch, first: int = 0, count: int | None = None, stale_extra=None):
+        count = batch.n_reads - first if count is None else count
+        ex = None
+        if stale_extra is not None:
+            ex = np.ascontiguousarray(stale_extra, dtype=np.uint32)
+            assert ex.size == count * self.h
+        self._check(self.lib.grp_ntcard_add(self._h, batch._h, first, count, _ptr(ex) if ex is not None else None))
+
+    def ntcard_finish(self) -> np.ndarray:
+        """Zero buckets [h, 2] (seed, sample table)."""
+        z = np.zeros(self.h * 2, dtype=np.uint64)
+        self._check(self.lib.grp_ntcard_finish(self._h, _ptr(z)))
+        return z.reshape(self.h, 2)
+
+    def set_filter_size(self, m: int):
+        self._check(self.lib.grp_set_filter_size(self._h, m))
+        self.m = m
 
     # -- phase 1
     def bv_insert(self, batch: ReadBatch, first: int = 0, count: int | None = None):

@@ -67,7 +67,8 @@ typedef struct
   uint32_t tile;        /* tile length (-t) */
   uint64_t m;           /* filter size in bits, computed by the host with
                            MIBloomFilter::calcOptimalSize
-                           (MIBloomFilter.hpp:94-101, goldrush_path.cpp:1183) */
+                           (MIBloomFilter.hpp:94-101, goldrush_path.cpp:1183);
+                           0 = not known yet, grp_set_filter_size follows (--ntcard) */
   const char* const* seeds; /* h strings of '0'/'1'; seed i has span k+i
                                (make_seed_pattern, spaced_seeds.cpp:63-66) */
   int32_t device;       /* HIP device ordinal; -1 = current device */
@@ -113,6 +114,35 @@ void grp_reads_free(grp_reads* reads);
  * tile0[i] = index of its first tile in the batch-wide tile numbering;
  * tile0 has n_reads+1 entries. Pointer valid until grp_reads_free. */
 const uint64_t* grp_reads_tile0(const grp_reads* reads);
+
+/* ---- phase 0 (only with --ntcard): expected entries from the reads ---------- */
+/*
+ * Replaces calc_ntcard_genome_size -> getHist -> stRead -> ntComp
+ * (ntcard.hpp:248-275, :156-246, :96-112, :81-94; called at goldrush_path.cpp:1109-1112):
+ * the multiLensfrHashIterator stream of EVERY record (no read filter) is sampled into
+ * two tables of 2^27 counters per seed; the caller turns the number of zero buckets
+ * into F0 with compEst's arithmetic (ntcard.hpp:124-136) — the only value the
+ * reference consumes.  The filter size depends on the result, so the context is
+ * created with grp_params.m = 0 and sized afterwards with grp_set_filter_size.
+ *
+ *   grp_ntcard_begin   sbits = nts::sBits (7 below 50e9 input bytes, else 11; :177-178)
+ *   grp_ntcard_add     reads [first, first+count) of a batch; every entry is a run of
+ *                      ACGT bases.  Each seed counts all its windows once and its last
+ *                      window stale_extra[(i-first)*h + s] more times (the iterator
+ *                      repeats a seed that can no longer roll); stale_extra == NULL
+ *                      means the plain-read rule: span_s - k repeats.  A record with
+ *                      non-ACGT characters is passed as its maximal ACGT runs, the
+ *                      record's repeats attached to the run holding the seed's last
+ *                      window.  Synchronous.
+ *   grp_ntcard_finish  zero_buckets[s*2 + t] = buckets of sample table t of seed s
+ *                      whose count is 0 mod 2^16 (the reference counts in uint16_t);
+ *                      frees the tables.
+ */
+int grp_ntcard_begin(grp_ctx* ctx, uint32_t sbits);
+int grp_ntcard_add(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const uint32_t* stale_extra);
+int grp_ntcard_finish(grp_ctx* ctx, uint64_t* zero_buckets);
+/* size the filter of a context created with m = 0 (once, before grp_bv_insert) */
+int grp_set_filter_size(grp_ctx* ctx, uint64_t m);
 
 /* ---- phase 1: bit-vector fill -------------------------------------------- */
 /*
@@ -336,7 +366,8 @@ enum
   GRP_K_QUERY = 2,    /* fused hash + probe + tile histogram kernel */
   GRP_K_INSERT = 3,   /* ID insert kernel */
   GRP_K_DECIDE = 4,   /* read decision kernel */
-  GRP_K_COUNT = 5
+  GRP_K_NTCARD = 5,   /* --ntcard sampling kernel (units = hashes) */
+  GRP_K_COUNT = 6
 };
 
 typedef struct

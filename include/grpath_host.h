@@ -38,6 +38,11 @@ typedef struct
   /* optional (both or none): pipelined windows, grp_classify_reads_begin / _end */
   int (*classify_begin)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot);
   int (*classify_end)(void* ctx, uint32_t slot, grp_read_decision* out);
+  /* optional (all four or none): --ntcard on the device, grp_ntcard_* / grp_set_filter_size */
+  int (*ntcard_begin)(void* ctx, uint32_t sbits);
+  int (*ntcard_add)(void* ctx, const void* reads, uint32_t first, uint32_t count, const uint32_t* stale_extra);
+  int (*ntcard_finish)(void* ctx, uint64_t* zero_buckets);
+  int (*set_filter_size)(void* ctx, uint64_t m);
   /* optional (all four or none): FASTQ ingest on the device, grpath_ingest.h */
   int (*fastq_parse)(void* ctx, const char* text, uint64_t n_bytes, int final_chunk, void** fq_out, uint64_t* n_records, uint64_t* bytes_consumed, int* stopped);
   int (*fastq_records)(void* fq, grp_fastq_record* out);
@@ -59,6 +64,14 @@ double gr_sum_phred(const char* qual, size_t n);
 /* 2-bit packing of one read into ceil(n/16) words; returns 0, or -1 if the read
  * holds a non-ACGT character */
 int gr_pack_2bit(const char* seq, size_t n, uint32_t* out_words);
+/* --ntcard host arithmetic (goldrush_path/ntcard.hpp): nts::sBits for the input size
+ * (:177-178); compEst's F0 from the zero buckets of the two sample tables (:124-136,
+ * :232); and a record with non-ACGT characters cut into the ACGT runs (>= k bases)
+ * grp_ntcard_add takes, with the iterator's stale repeats per run and seed
+ * (extra[run*h + s]).  gr_ntcard_split returns the number of runs (writes at most cap). */
+unsigned gr_ntcard_sbits(uint64_t input_bytes);
+uint64_t gr_ntcard_f0(uint64_t zero0, uint64_t zero1, unsigned sbits);
+size_t gr_ntcard_split(const char* seq, size_t n, unsigned k, unsigned h, uint64_t* run_off, uint64_t* run_len, uint32_t* extra, size_t cap);
 /* CPUs this process may use: min(affinity mask, cgroup cpu.max quota) */
 unsigned gr_effective_cpus(void);
 

@@ -88,6 +88,10 @@ def load():
         "orc_multi_hash": (sz, [vp, C.c_uint, C.c_char_p, sz, vp, sz]),
         "orcpy_tile_hashes": (sz, [vp, C.c_uint, C.c_char_p, sz, sz, sz, sz, vp, sz]),
         "orc_calc_optimal_size": (u64, [u64, C.c_uint, C.c_double]),
+        "orc_ntcard_new": (vp, [C.c_uint, u64]), "orc_ntcard_free": (None, [vp]),
+        "orc_ntcard_add_read": (None, [vp, vp, C.c_char_p, sz]),
+        "orc_ntcard_zero_buckets": (u64, [vp, C.c_uint, C.c_uint]), "orc_ntcard_f0": (u64, [vp, C.c_uint]),
+        "orcpy_ntcard_counters": (vp, [vp]),
         "orc_mibf_create": (vp, [u64, C.c_uint]), "orc_mibf_destroy": (None, [vp]),
         "orc_mibf_insert_bv": (None, [vp, vp, sz]), "orc_mibf_finalize": (None, [vp]),
         "orc_mibf_bit": (C.c_int, [vp, u64]), "orc_mibf_rank": (u64, [vp, u64]),
@@ -165,6 +169,41 @@ class Seeds:
     def __del__(self):
         try:
             self.lib.orcpy_seeds_free(self._h)
+        except Exception:
+            pass
+
+
+class NtCard:
+    """orc_ntcard wrapper (--ntcard restatement, goldrush_path/ntcard.hpp)."""
+
+    def __init__(self, seeds: Seeds, input_bytes: int = 0):
+        self.lib = load()
+        self.seeds = seeds
+        self._h = self.lib.orc_ntcard_new(seeds.h, input_bytes)
+
+    def add_read(self, seq: bytes):
+        self.lib.orc_ntcard_add_read(self._h, self.seeds._h, seq, len(seq))
+
+    def zero_buckets(self) -> np.ndarray:
+        return np.array([[self.lib.orc_ntcard_zero_buckets(self._h, s, t) for t in range(2)] for s in range(self.seeds.h)], dtype=np.uint64)
+
+    def f0(self, seed: int) -> int:
+        return int(self.lib.orc_ntcard_f0(self._h, seed))
+
+    def counters(self) -> np.ndarray:
+        """[h, 2, 2^27] uint16 view of the sample tables."""
+        n = self.seeds.h * 2 * (1 << 27)
+        a = np.ctypeslib.as_array(C.cast(self.lib.orcpy_ntcard_counters(self._h), C.POINTER(C.c_uint16)), shape=(n,))
+        return a.reshape(self.seeds.h, 2, 1 << 27)
+
+    def close(self):
+        if self._h:
+            self.lib.orc_ntcard_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 

@@ -7,6 +7,7 @@
  */
 #define _GNU_SOURCE
 #include "orc_path.h"
+#include "orc_ntcard.h"
 
 #include <ctype.h>
 #include <getopt.h>
@@ -1428,12 +1429,33 @@ orc_path_open(const orc_opts* o, const orc_reads* reads, FILE* log, int* exit_co
   /* :1109-1123 */
   if (p->opt.hash_universe == 0) {
     if (p->opt.ntcard) {
-      LOGF(p, "oracle: --ntcard is outside the restated path (SURVEY.md §2: OUT OF SCOPE)\n");
-      *exit_code = 1;
-      free(p);
-      return NULL;
+      /* calc_ntcard_genome_size (ntcard.hpp:248-275) over every record of the input */
+      const double nt_s = now_s();
+      uint64_t input_bytes = 0;
+      FILE* fsz = fopen(o->input, "rb");
+      if (fsz) {
+        fseek(fsz, 0, SEEK_END);
+        input_bytes = (uint64_t)ftell(fsz); /* getInf (:44-49) */
+        fclose(fsz);
+      }
+      LOGF(p, "Calculating expected entries\n");
+      orc_ntcard* nc = orc_ntcard_new(p->h, input_bytes);
+      for (size_t i = 0; i < reads->n; ++i) {
+        orc_ntcard_add_read(nc, p->seeds, reads->rec[i].seq, reads->rec[i].len);
+      }
+      LOGF(p, "Reapeat profile estimated using ntCard in (sec): %.4f\n", now_s() - nt_s);
+      uint64_t genome_size = 0;
+      for (unsigned i = 0; i < p->h; ++i) {
+        const uint64_t f0 = orc_ntcard_f0(nc, i);
+        LOGF(p, "Expected entries for seed pattern %s : %llu\n", p->seeds_str[i], (unsigned long long)f0);
+        genome_size += f0;
+      }
+      LOGF(p, "Total expected entries for seed patterns: %llu\n", (unsigned long long)genome_size);
+      orc_ntcard_free(nc);
+      p->opt.hash_universe = genome_size;
+    } else {
+      p->opt.hash_universe = orc_hash_universe(o->weight, o->genome_size, o->hash_num);
     }
-    p->opt.hash_universe = orc_hash_universe(o->weight, o->genome_size, o->hash_num);
   }
   char num_and_type_path_log[64];
   if (o->silver_path) {
@@ -1442,11 +1464,14 @@ orc_path_open(const orc_opts* o, const orc_reads* reads, FILE* log, int* exit_co
     snprintf(num_and_type_path_log, sizeof(num_and_type_path_log), "the golden path");
   }
   calc_min_phred_threshold(p); /* :1131 */
+  /* getHist leaves std::cerr in setprecision(4) << fixed (ntcard.hpp:240-241) */
+  char occupancy_str[64];
+  snprintf(occupancy_str, sizeof(occupancy_str), (o->hash_universe == 0 && o->ntcard) ? "%.4f" : "%g", p->opt.occupancy);
   LOGF(p,
        "Calculating %s\nUsing:\n\ttile length: %zu\n\tblock size: %zu\n\tseed patterns: %zu\n\tthreshold: %zu\n"
        "\tbase seed pattern: %s\n\tminimum unassigned tiles: %zu\n\tmaximum assigned tiles: %zu\n"
        "\texpected hash space: %llu\n\tminimum average phred quality score: %u\n"
-       "\tmaximum average phred delta between first and second half of read: %u\n\toccupancy: %g\n\tjobs: %zu\n",
+       "\tmaximum average phred delta between first and second half of read: %u\n\toccupancy: %s\n\tjobs: %zu\n",
        num_and_type_path_log,
        p->opt.tile_length,
        p->opt.block_size,
@@ -1458,7 +1483,7 @@ orc_path_open(const orc_opts* o, const orc_reads* reads, FILE* log, int* exit_co
        (unsigned long long)p->opt.hash_universe,
        p->opt.phred_min,
        p->opt.phred_delta,
-       p->opt.occupancy,
+       occupancy_str,
        p->opt.jobs);
   /* :1161-1171 */
   if (o->filter_file[0] != '\0') {

@@ -69,3 +69,10 @@ uint32_t* orcpy_mibf_counts(orc_mibf* f) { return f->counts; }
 uint64_t orcpy_mibf_m(const orc_mibf* f) { return f->m; }
 size_t orcpy_sizeof_opts(void) { return sizeof(orc_opts); }
 size_t orcpy_sizeof_decision(void) { return sizeof(orc_decision); }
+
+#include "orc_ntcard.h"
+uint16_t*
+orcpy_ntcard_counters(orc_ntcard* nc)
+{
+  return nc->counters;
+}

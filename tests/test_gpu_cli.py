@@ -102,6 +102,37 @@ def test_designed_seed_h5_noisy_quals(oracle, host, tmp_path):
     assert ("WARNING: Expected" in rp.stderr) == ("WARNING: Expected" in ro.stderr)
 
 
+def _ntcard_lines(stderr):
+    keep = ("Calculating expected entries", "Expected entries for seed pattern", "Total expected entries", "m_filterSize", "\texpected hash space",
+            "\toccupancy")
+    return [l for l in stderr.splitlines() if l.startswith(keep)]
+
+
+@pytest.mark.parametrize("host_ingest", [False, True])
+def test_ntcard_sizes_the_filter(oracle, host, tmp_path, host_ingest):
+    """--ntcard (goldrush_path.cpp:1109-1112, ntcard.hpp): expected entries per seed from
+    the reads themselves, incl. records with N, lower case and records shorter than the
+    spans; the estimate sizes the filter, the rest of the run is unchanged."""
+    fq = str(tmp_path / "reads.fq")
+    recs = _mk_fastq(fq, 200_000, 400, 5000, 3000, seed=21, lower=True, with_n=9, short=40)
+    with open(fq, "ab") as f:
+        for i, seq in enumerate([b"ACGT" * 5 + b"AC", b"ACGT" * 5 + b"ACG", b"N" * 40, b"acgtnACGTACGTACGTACGTACGTACGTAC", b"ACGTAC" * 10 + b"RY" + b"TTGCA" * 9]):
+            f.write(b"@extra%d\n%s\n+\n%s\n" % (i, seq, b"5" * len(seq)))
+    args = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j4", "-d5", "-x10", "-s1011011110110111101101", "-g200000", "-b4", "-P10", "-m0",
+            "--ntcard", "-i", fq, "--verbose"]
+    env = {"GRP_HOST_INGEST": "1"} if host_ingest else {"GRP_INGEST_CHUNK": "300000"}
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "ntc", env=env)
+    assert files == ["out.fa"] and os.path.getsize(d_p / "out.fa") > 0
+    lo, lp = _ntcard_lines(ro.stderr), _ntcard_lines(rp.stderr)
+    assert lo == lp and len(lo) == 8, (lo, lp)
+    assert "\toccupancy: 0.1000" in lp  # the reference's setprecision(4) << fixed stays on std::cerr
+    assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+    # -H given: --ntcard is ignored (goldrush_path.cpp:1109)
+    ro, rp, _, _, _ = _run_both(oracle, host, tmp_path, args + ["-H2000000"], "ntc_H", env=env)
+    assert "Calculating expected entries" not in rp.stderr and "Calculating expected entries" not in ro.stderr
+    assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+
+
 def test_cli_error_paths(oracle, host, tmp_path):
     fa = tmp_path / "x.fa"
     fa.write_text(">r1\nACGT\n")

@@ -378,3 +378,63 @@ def test_sharded_fill_or_merge(oracle, native):
     assert np.array_equal(a.export_bits(), omf.bits())
     with pytest.raises(native.GrpError):
         a.bv_merge_device(1 << 20)  # after finalize
+
+
+def test_ntcard_tables_match_oracle(oracle, native):
+    """grp_ntcard_* (ntcard.hpp:81-112 on the device) vs the oracle: zero buckets of
+    every sample table, for plain reads (iterator rule), reads shorter than the longest
+    span, reads given as ACGT runs with explicit stale repeats, two calls + two batches;
+    and the deferred filter size (grp_params.m = 0 -> grp_set_filter_size)."""
+    from goldrush_amd import host
+
+    k, h, tile = 22, 3, 500
+    seeds = default_seeds(h)
+    osd = oracle.Seeds(seeds)
+    reads = random_reads(40, 1500, 9000, seed=91) + [b"ACGT" * 5 + b"AC", b"ACGT" * 5 + b"ACG", b"ACGT" * 6, b"ACGT" * 5 + b"A", b"ACG"]
+    dirty = []
+    rng = np.random.default_rng(92)
+    for i, r in enumerate(random_reads(6, 800, 5000, seed=93)):
+        r = bytearray(r)
+        for p in rng.integers(0, len(r), size=2 + i):
+            r[p] = ord("N")
+        dirty.append(bytes(r))
+    eng = native.Engine(k, h, tile, 0, seeds)  # size not known yet
+    b = eng.upload(reads)
+    with pytest.raises(native.GrpError):
+        eng.bv_insert(b)  # no filter yet
+    with pytest.raises(native.GrpError):
+        eng.ntcard_add(b)  # not begun
+    eng.ntcard_begin(7)
+    eng.ntcard_add(b, 0, 17)
+    eng.ntcard_add(b, 17)
+    runs_all, extra_all = [], []
+    for seq in dirty:
+        runs, extra = host.ntcard_split(seq, k, h)
+        runs_all += [seq[o:o + n] for o, n in runs]
+        extra_all.append(extra)
+    b2 = eng.upload(runs_all)
+    eng.ntcard_add(b2, stale_extra=np.concatenate(extra_all).ravel())
+    z = eng.ntcard_finish()
+    nc = oracle.NtCard(osd, 1000)
+    for seq in reads + dirty:
+        nc.add_read(seq)
+    assert np.array_equal(z, nc.zero_buckets())
+    assert int((z < (1 << 27)).sum()) == 2 * h  # every table was hit
+    for s in range(h):
+        assert host.load().gr_ntcard_f0(int(z[s][0]), int(z[s][1]), 7) == nc.f0(s)
+    st = eng.kernel_stats()["ntcard"]
+    assert st["launches"] == 3 and st["units"] > 0
+    # the filter gets its size now; fill works as in a context created with m
+    m = oracle.load().orc_calc_optimal_size(sum(nc.f0(s) for s in range(h)), 1, 0.1)
+    nc.close()
+    eng.set_filter_size(m)
+    with pytest.raises(native.GrpError):
+        eng.set_filter_size(m)
+    eng.bv_insert(b)
+    omf = oracle.MiBF(m, osd, tile, k)
+    for seq in reads:
+        if len(seq) >= k + h - 1:
+            omf.bv_insert_read(seq)
+    assert eng.finalize() == omf.finalize()
+    assert np.array_equal(eng.export_bits(), omf.bits())
+    eng.close()

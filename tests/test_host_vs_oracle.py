@@ -132,3 +132,63 @@ def test_flank_edge_cases(oracle, host):
         assert host.eval_flanks(a, b, ids) == oracle.eval_flanks(a, b, ids), (n, a, b, ids.tolist())
         bools = (rng.random(n) < rng.random()).astype(np.uint8)
         assert host.find_longest_stretch(bools) == oracle.find_longest_stretch(bools), bools.tolist()
+
+
+def test_ntcard_host_arithmetic(oracle, host):
+    """--ntcard host side (gr_ntcard_*) vs the oracle's restatement of ntcard.hpp: sBits,
+    F0 from zero buckets, and the decomposition of a record with non-ACGT characters
+    into ACGT runs + stale repeats (what grp_ntcard_add is fed) reproduces the oracle's
+    sample tables exactly."""
+    from helpers import default_seeds, random_reads
+
+    lib = host.load()
+    assert lib.gr_ntcard_sbits(0) == 7 and lib.gr_ntcard_sbits(49_999_999_999) == 7 and lib.gr_ntcard_sbits(50_000_000_000) == 11
+    k, h = 22, 3
+    seeds = default_seeds(h)
+    sd = oracle.Seeds(seeds)
+    rng = np.random.default_rng(5)
+    reads = random_reads(8, 500, 4000, seed=6)
+    out = []
+    for i, r in enumerate(reads):
+        r = bytearray(r)
+        for p in rng.integers(0, len(r), size=i):  # read 0 stays clean
+            r[p] = ord("N")
+        if i == 3:
+            r[10:60] = r[10:60].lower()
+            r[-23] = ord("n")  # last run holds only the two shorter seeds
+        if i == 4:
+            r[-1] = ord("X")
+        out.append(bytes(r))
+    out += [b"ACGT" * 5 + b"AC", b"ACGT" * 5 + b"ACG", b"N" * 30, b"ACGTACGTAC" * 3 + b"N" + b"ACGTACGTAC" * 3]
+    sbits, rbits = 7, 27
+    nc = oracle.NtCard(sd, 123)
+    exp = {}
+    for seq in out:
+        nc.add_read(seq.upper())
+        runs, extra = host.ntcard_split(seq, k, h)
+        for (off, ln), ex in zip(runs, extra):
+            run = seq[off:off + ln].upper()
+            assert set(run) <= set(b"ACGT") and ln >= k
+            assert (off == 0 or seq[off - 1:off].upper() not in (b"A", b"C", b"G", b"T")) and seq[off + ln:off + ln + 1].upper() not in (b"A", b"C", b"G", b"T")
+            for s, pat in enumerate(seeds):
+                K = len(pat)
+                one = oracle.Seeds([pat])
+                for p in range(ln - K + 1):
+                    hv = int(one.multi_hash(run[p:p + K])[0])
+                    times = 1 + (int(ex[s]) if p + K == ln else 0)
+                    ind = 2
+                    if hv >> (63 - sbits) == 1:
+                        ind = 0
+                    if hv >> (64 - sbits) == (1 << (sbits - 1)) - 1:
+                        ind = 1
+                    if ind < 2:
+                        key = (s, ind, hv & ((1 << rbits) - 1))
+                        exp[key] = exp.get(key, 0) + times
+    cnt = nc.counters()
+    got = {(int(a), int(b), int(c)): int(cnt[a, b, c]) for a, b, c in np.argwhere(cnt)}
+    assert got == exp and len(exp) > 100
+    z = nc.zero_buckets()
+    for s in range(h):
+        assert lib.gr_ntcard_f0(int(z[s][0]), int(z[s][1]), sbits) == nc.f0(s)
+    assert lib.gr_ntcard_f0(1 << 27, 1 << 27, 7) == 0
+    nc.close()

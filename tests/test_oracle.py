@@ -177,3 +177,57 @@ def test_path_equals_python_serial_loop(oracle, tmp_path):
     p.close()
     exp, _ = serial_reference(oracle, m, default_seeds(3), 500, 22, [r[1] for r in reads], block=4, silver=True, target_bases=90_000, max_paths=2)
     assert [(d[0], d[1], d[2], d[3], d[4], d[5], d[6]) for d in got] == [(e[1], e[2], e[3], e[4], e[5], e[6], e[7]) for e in exp]
+
+
+def test_ntcard_restatement(oracle):
+    """ntComp / stRead / compEst (ntcard.hpp:81-154) against a direct Python statement
+    of the same rules: clean windows per seed, stale repeats of the iterator, the two
+    sampled tables, F0 from the zero buckets."""
+    import math
+
+    seeds = default_seeds(3)
+    sd = oracle.Seeds(seeds)
+    rng = np.random.default_rng(77)
+    reads = random_reads(6, 3000, 9000, seed=78)
+    r = bytearray(reads[0])
+    for p in (0, 500, 501, 1200, len(r) - 1):
+        r[p] = ord("N")
+    reads[0] = bytes(r)
+    reads[1] = reads[1][:40].lower() + reads[1][40:]
+    reads += [reads[2][:23], reads[2][:21], b"ACGTNACGT", b""]
+    nc = oracle.NtCard(sd, 1000)
+    sbits, rbits = 7, 27
+    exp = {}
+    for seq in reads:
+        nc.add_read(seq)
+        up = seq.upper()
+        per_seed = []
+        for s, pat in enumerate(seeds):
+            K = len(pat)
+            one = oracle.Seeds([pat])
+            hs = [int(one.multi_hash(up[p:p + K])[0]) for p in range(len(up) - K + 1) if set(up[p:p + K]) <= set(b"ACGT")]
+            per_seed.append(hs)
+        F = max(len(x) for x in per_seed)
+        for s, hs in enumerate(per_seed):
+            if hs:
+                hs = hs + [hs[-1]] * (F - len(hs))
+            for hv in hs:
+                ind = 2
+                if hv >> (63 - sbits) == 1:
+                    ind = 0
+                if hv >> (64 - sbits) == (1 << (sbits - 1)) - 1:
+                    ind = 1
+                if ind < 2:
+                    key = (s, ind, hv & ((1 << rbits) - 1))
+                    exp[key] = exp.get(key, 0) + 1
+    cnt = nc.counters()
+    nz = np.argwhere(cnt)
+    got = {(int(a), int(b), int(c)): int(cnt[a, b, c]) for a, b, c in nz}
+    assert got == exp and len(exp) > 300
+    z = nc.zero_buckets()
+    for s in range(3):
+        assert int(z[s].sum()) == 2 * (1 << rbits) - sum(1 for k_ in exp if k_[0] == s)
+        pmean0 = (float(z[s][0]) + float(z[s][1])) / 2.0
+        f0 = int((rbits * math.log(2) - math.log(pmean0)) * (1 << (sbits + rbits)))
+        assert nc.f0(s) == f0
+    nc.close()
