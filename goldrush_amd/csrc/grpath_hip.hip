@@ -64,6 +64,23 @@ struct QuerySlot
   hipEvent_t done = nullptr;   // decisions of the window are in h_dec
   hipEvent_t qdone = nullptr;  // the window's query kernel has finished (decide stream waits on it)
   bool side_used = false;      // `done` was last recorded on the decide stream
+  // streaming window (grp_classify_stream_*)
+  grp_read_decision* h_sdec = nullptr;    // mapped, coherent: the kernel publishes decisions here
+  grp_read_decision* dmap_sdec = nullptr;
+  uint64_t sdec_cap = 0;
+  // abort flag: the host raises the one in mapped host memory (a plain store); every
+  // 64th workgroup reads that one when it starts and relays it to the flag in DEVICE
+  // memory, which is what all workgroups test (a PCIe round trip in every workgroup
+  // costs the kernel 2.4x, measured; a 4-byte hipMemcpyAsync takes ~1.5 ms to land
+  // beside a full-device kernel, measured)
+  uint32_t* d_abort = nullptr;
+  uint32_t* h_abort = nullptr;            // mapped, coherent
+  uint32_t* dmap_abort = nullptr;
+  uint32_t* d_tiles_done = nullptr;
+  uint64_t tiles_done_cap = 0;
+  unsigned long long* d_executed = nullptr;
+  unsigned long long* h_executed = nullptr; // pinned
+  bool streaming = false;
   bool busy = false;
   const grp_reads* reads = nullptr;
   uint32_t first = 0, count = 0;
@@ -93,6 +110,7 @@ struct grp_ctx
   uint64_t n_chunks = 0; // rank-build chunks
   uint64_t* d_super = nullptr;
   bool finalized = false;
+  int n_cus = 0;
   // --ntcard pass (grp_ntcard.inc)
   uint32_t* d_ntc = nullptr;
   uint32_t ntc_sbits = 0;
@@ -640,7 +658,182 @@ seed_hash_t(const ulonglong2* sTab, const DevSeeds* __restrict__ sd, uint32_t s,
 
 #define GRP_TILE_FLAGGED 0xFFFFFFFFu
 
-template<int H, int FR, int WT>
+// Stores / loads that are coherent across the XCDs' L2s inside one launch (agent scope,
+// "sc1": written through to / read from the memory side).  The streaming window uses
+// them for everything one workgroup hands to another; with them the hand-over needs no
+// device-scope fence (whose L2 write-back + invalidate per workgroup costs the query
+// kernel 5x, measured).
+__device__ inline void
+store_coherent(unsigned long long* p, unsigned long long v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline unsigned long long
+load_coherent(const unsigned long long* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static_assert(sizeof(grp_tile_summary) == 24 && sizeof(grp_id_count) == 8, "coherent copies move these as 64-bit words");
+
+// Streaming window (grp_classify_stream_*): persistent k_query<.., true> workgroups draw
+// the window's tiles in order; the workgroup that finishes the LAST tile of a read takes
+// that read's decision on the spot (first wave, register-resident state: a few
+// microseconds) and publishes it in mapped host memory, so the host commits reads while
+// the same launch is still working on later ones.  An abort (an insert made the rest of
+// the window stale) parks the tile dispenser: the launch ends as soon as the resident
+// tiles are done.
+// (Measured alternatives: a decision by one lane walking LDS arrays keeps a 141-VGPR wave
+// slot for ~100 us per read and costs the query kernel 10 %; resident decision waves in a
+// second kernel do not fit beside 3 query workgroups per CU — they either displace one
+// (-20 %) or starve until the launch ends.)
+struct DevStreamCtl
+{
+  uint32_t first = 0;                    // batch index of the window's first read
+  uint32_t* tiles_done = nullptr;        // [reads of the window] finished tiles, zeroed before the launch
+  uint32_t* abort = nullptr;             // device memory: what every workgroup tests
+  const uint32_t* abort_host = nullptr;  // mapped host memory: raised by the host, relayed by every 64th workgroup
+  grp_read_decision* dec = nullptr;      // mapped host memory [reads]; .pad = 1 once the record is complete
+  uint32_t* next_tile = nullptr;         // tile dispenser of the persistent workgroups; >= n_tiles: stop
+  uint32_t n_tiles = 0;
+  unsigned long long* executed = nullptr; // probes of the tiles that were processed
+  grp_decide_params dp{};
+  uint32_t* g_ids = nullptr;             // per-tile results (inspection) / scratch of long reads
+  uint8_t* g_asg = nullptr;
+  uint64_t* g_scratch = nullptr;
+};
+
+// reads of up to this many tiles are decided inside the streaming launch (37 bytes of the
+// idle count-table area per tile: 9.5 KB of the >= 16 KB the small geometry owns)
+constexpr uint32_t STREAM_LDS_TILES = 256;
+
+// ---- wave-register state for the decision core (csrc/host/gr_tiles_core.hpp) -------
+// Tile i of the read lives in lane i (reads of up to 64 tiles); every access is a
+// v_readlane / v_writelane with a wave-uniform index, so the passes run as scalar code
+// executed by the whole wave in lockstep.
+__device__ inline uint32_t
+lane_get(uint32_t v, size_t i)
+{
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i);
+}
+
+// v_writelane by hand (this compiler has no builtin for it): value and index are
+// wave-uniform, every lane executes — a compare and a select
+__device__ inline uint32_t
+lane_set(uint32_t v, size_t i, uint32_t reg)
+{
+  return (__lane_id() == (uint32_t)i) ? v : reg;
+}
+
+struct LaneState
+{
+  uint32_t v_top_id = 0, v_top_count = 0, v_list_n = 0, v_list_off = 0, v_hits = 0, v_misses = 0;
+  uint32_t v_id = 0, v_asg = 0, v_lo = 0, v_hi = 0;
+  const grp_id_count* lists = nullptr;
+
+  __device__ uint32_t top_id(size_t i) const { return lane_get(v_top_id, i); }
+  __device__ uint32_t top_count(size_t i) const { return lane_get(v_top_count, i); }
+  __device__ uint32_t list_n(size_t i) const { return lane_get(v_list_n, i); }
+  __device__ uint32_t list_off(size_t i) const { return lane_get(v_list_off, i); }
+  __device__ uint32_t hits(size_t i) const { return lane_get(v_hits, i); }
+  __device__ uint32_t misses(size_t i) const { return lane_get(v_misses, i); }
+  __device__ grp_id_count list_entry(size_t k) const { return gr::core::load_list_entry(lists + k); }
+  __device__ uint32_t id(size_t i) const { return lane_get(v_id, i); }
+  __device__ void set_id(size_t i, uint32_t v) { v_id = lane_set(v, i, v_id); }
+  __device__ uint32_t asg(size_t i) const { return lane_get(v_asg, i); }
+  __device__ void set_asg(size_t i, uint32_t v) { v_asg = lane_set(v, i, v_asg); }
+  __device__ uint64_t scr(size_t i) const { return (uint64_t)lane_get(v_lo, i) | ((uint64_t)lane_get(v_hi, i) << 32); }
+  __device__ void set_scr(size_t i, uint64_t v)
+  {
+    v_lo = lane_set((uint32_t)v, i, v_lo);
+    v_hi = lane_set((uint32_t)(v >> 32), i, v_hi);
+  }
+  __device__ void load(const grp_tile_summary& t)
+  {
+    v_top_id = t.top_id;
+    v_top_count = t.top_count;
+    v_list_n = t.list_n;
+    v_list_off = t.list_off;
+    v_hits = t.hits;
+    v_misses = t.misses;
+  }
+};
+constexpr uint32_t LANE_TILES = 64;
+
+// One wave (all 64 lanes), read `rj` of a streaming window complete (tiles [a, a+n) of the
+// window): the decision, published to the host.  Summaries and lists were written by other
+// workgroups during this launch: coherent loads.  `lds` / cap_tiles: work space for reads
+// of more than 64 tiles (the idle count-table area of the workgroup).
+__device__ inline void
+stream_decide(const DevStreamCtl& sc, uint32_t rj, uint64_t a, uint32_t n, const grp_tile_summary* tiles, const grp_id_count* lists, uint64_t lists_cap, uint32_t* lds, uint32_t cap_tiles)
+{
+  const uint32_t lane = threadIdx.x;
+  grp_read_decision d{};
+  auto fetch = [&](uint32_t i) {
+    union
+    {
+      unsigned long long w[3];
+      grp_tile_summary t;
+    } u;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(tiles + a + i);
+    u.w[0] = load_coherent(src);
+    u.w[1] = load_coherent(src + 1);
+    u.w[2] = load_coherent(src + 2);
+    return u.t;
+  };
+  if (n <= LANE_TILES) {
+    LaneState st;
+    st.lists = lists;
+    bool bad = false;
+    if (lane < n) {
+      const grp_tile_summary t = fetch(lane);
+      st.load(t);
+      bad = t.list_n == GRP_TILE_FLAGGED || (uint64_t)t.list_off + t.list_n > lists_cap;
+    }
+    if (__ballot(bad) == 0ull) { // else kind stays 0: the host takes this read through the synchronous path
+      gr::core::decide(sc.dp.threshold, sc.dp.unassigned_min, sc.dp.assigned_max, (size_t)n, st, d);
+      if (lane < n) {
+        sc.g_ids[a + lane] = st.v_id;
+        sc.g_asg[a + lane] = (uint8_t)st.v_asg;
+      }
+    }
+  } else if (n <= cap_tiles) {
+    uint64_t* sScratch = reinterpret_cast<uint64_t*>(lds);
+    grp_tile_summary* sTiles = reinterpret_cast<grp_tile_summary*>(sScratch + cap_tiles);
+    uint32_t* sIds = reinterpret_cast<uint32_t*>(sTiles + cap_tiles);
+    uint8_t* sAsg = reinterpret_cast<uint8_t*>(sIds + cap_tiles);
+    bool bad = false;
+    for (uint32_t i = lane; i < n; i += 64u) {
+      const grp_tile_summary t = fetch(i);
+      sTiles[i] = t;
+      bad = bad || t.list_n == GRP_TILE_FLAGGED || (uint64_t)t.list_off + t.list_n > lists_cap;
+    }
+    const bool redo = __ballot(bad) != 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && !redo) {
+      gr::core::decide(sc.dp.threshold, sc.dp.unassigned_min, sc.dp.assigned_max, (size_t)n, sTiles, lists, sIds, sAsg, sScratch, d);
+      for (uint32_t i = 0; i < n; ++i) {
+        sc.g_ids[a + i] = sIds[i];
+        sc.g_asg[a + i] = sAsg[i];
+      }
+    }
+  } // longer still: synchronous path (kind stays 0)
+  if (lane == 0) {
+    // The record goes to host memory with system-scope stores (no L2 involved); the flag
+    // follows once they are acknowledged.  No fence: a system-scope release would write
+    // back and invalidate the whole L2 once per read.
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(sc.dec + rj);
+    __hip_atomic_store(o, (unsigned long long)d.kind | ((unsigned long long)d.num_tiles << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(o + 1, (unsigned long long)d.num_assigned | ((unsigned long long)d.trim_start << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(o + 2, (unsigned long long)d.trim_end | ((unsigned long long)d.hits << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(o + 3), d.misses, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_s_waitcnt(0);
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(o + 3) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template<int H, int FR, int WT, bool ST>
 __global__ void __launch_bounds__(THREADS)
 k_query(DevFilter f,
         DevReads rd,
@@ -657,8 +850,9 @@ k_query(DevFilter f,
         unsigned long long* __restrict__ ctr,
         uint32_t* __restrict__ flagged_out, // indices of flagged tiles (NULL in the redo launch)
         uint32_t flagged_cap,
-        uint32_t direct_stride) // != 0: tile i owns lists_out[i*stride ..) (no arena, no counters:
+        uint32_t direct_stride, // != 0: tile i owns lists_out[i*stride ..) (no arena, no counters:
                                 // small windows write straight into mapped host memory)
+        DevStreamCtl sc)        // ST only
 {
   extern __shared__ uint4 smem4[];
   ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
@@ -669,8 +863,52 @@ k_query(DevFilter f,
   __shared__ uint32_t sListN, sDistinct, sOverflow, sListOff;
   __shared__ uint32_t sRed[2 * (THREADS / 64)];
   __shared__ uint32_t sBest[2 * (THREADS / 64)];
+  __shared__ uint32_t sTile;
 
-  const uint32_t out_idx = tile_idx ? tile_idx[blockIdx.x] : blockIdx.x;
+  load_tab(sTab, sd);
+  // ST: persistent workgroups (one launch fills the device once) draw tile after tile
+  // from a dispenser, in window order; an abort parks the dispenser beyond the last
+  // tile, so a stale window ends as soon as the resident tiles are done.  The next
+  // index is fetched while the current tile is being processed.
+  constexpr uint32_t STREAM_STOP = 0x40000000u;
+  uint32_t nxt = 0;
+  uint32_t stop = 0; // thread 0: the device abort flag, read while the previous tile was finishing
+  if constexpr (ST) {
+    if (threadIdx.x == 0) {
+      // a window that was aborted before it started (the host read an insert out of the
+      // previous launch) must not begin a single tile: every workgroup asks the host
+      // flag once, here — one PCIe read per workgroup and launch
+      if (__hip_atomic_load(sc.abort_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+        atomicMax(sc.next_tile, STREAM_STOP);
+        __hip_atomic_store(sc.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stop = 1u;
+      }
+      nxt = atomicAdd(sc.next_tile, 1u);
+    }
+  }
+  for (;;) {
+  uint32_t out_idx;
+  if constexpr (ST) {
+    if (threadIdx.x == 0) {
+      sTile = stop ? STREAM_STOP : nxt;
+    }
+    __syncthreads();
+    out_idx = sTile;
+    if (out_idx >= sc.n_tiles) {
+      return;
+    }
+    if (threadIdx.x == 0) {
+      nxt = atomicAdd(sc.next_tile, 1u);
+      if (blockIdx.x < 32u) { // relays of the host's abort flag (a PCIe read: only a few workgroups pay for it)
+        if (__hip_atomic_load(sc.abort_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+          atomicMax(sc.next_tile, STREAM_STOP);
+          __hip_atomic_store(sc.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  } else {
+    out_idx = tile_idx ? tile_idx[blockIdx.x] : blockIdx.x;
+  }
   const uint64_t t = tile_begin + out_idx;
   const uint32_t r = rd.tile_read[t];
   const uint32_t ti = (uint32_t)(t - rd.tile0[r]);
@@ -681,7 +919,6 @@ k_query(DevFilter f,
   const uint32_t Lp = min(tile_len + k - 1u, len - start);
   const uint32_t frames = (Lp >= k) ? (Lp - k + 1u) : 0u;
 
-  load_tab(sTab, sd);
   const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[r], len, start, Lp);
   for (uint32_t i = threadIdx.x; i < hist_cap; i += THREADS) {
     sKeys[i] = 0u;
@@ -693,6 +930,11 @@ k_query(DevFilter f,
     sOverflow = 0;
   }
   __syncthreads();
+  if constexpr (ST) {
+    if (threadIdx.x == 0) {
+      atomicAdd(sc.executed, (unsigned long long)frames * H);
+    }
+  }
 
   const uint32_t hmask = hist_cap - 1u;
   uint32_t n_hit = 0, n_miss = 0;
@@ -861,31 +1103,65 @@ k_query(DevFilter f,
     ts.list_n = flagged ? GRP_TILE_FLAGGED : n;
     ts.hits = hsum;
     ts.misses = msum;
-    tiles_out[out_idx] = ts;
+    if constexpr (ST) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(tiles_out + out_idx);
+      store_coherent(dst, (unsigned long long)ts.top_id | ((unsigned long long)ts.top_count << 32));
+      store_coherent(dst + 1, (unsigned long long)ts.list_off | ((unsigned long long)ts.list_n << 32));
+      store_coherent(dst + 2, (unsigned long long)ts.hits | ((unsigned long long)ts.misses << 32));
+    } else {
+      tiles_out[out_idx] = ts;
+    }
   }
   __syncthreads();
   const uint32_t n = sListN;
   const uint64_t lo = sListOff;
   for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
     if (lo + i < lists_cap) {
-      lists_out[lo + i] = sList[i];
+      if constexpr (ST) {
+        store_coherent(reinterpret_cast<unsigned long long*>(lists_out + lo + i), (unsigned long long)sList[i].id | ((unsigned long long)sList[i].count << 32));
+      } else {
+        lists_out[lo + i] = sList[i];
+      }
     }
   }
+  if constexpr (ST) {
+    // "last block" hand-over without device-scope fences: the summaries and lists went
+    // out as coherent stores; once they are acknowledged (vmcnt = 0 in every wave, then
+    // the barrier) one lane counts the tile with a device-scope atomic.  The workgroup
+    // that sees the read complete reads them back with coherent loads.
+    if (threadIdx.x == 0) { // the prefetched tile index is only used if the window is still live
+      stop = __hip_atomic_load(sc.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    const uint32_t rj = r - sc.first;
+    const uint32_t nt_read = (uint32_t)(rd.tile0[r + 1] - rd.tile0[r]);
+    if (threadIdx.x == 0) {
+      sTile = (atomicAdd(&sc.tiles_done[rj], 1u) + 1u == nt_read) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (sTile != 0u && threadIdx.x < 64u) {
+      stream_decide(sc, rj, rd.tile0[r] - tile_begin, nt_read, tiles_out, lists_out, lists_cap, reinterpret_cast<uint32_t*>(sKeys), min(STREAM_LDS_TILES, hist_cap * 8u / 40u));
+    }
+    // (the barrier at the top of the loop keeps sTile / the count-table area untouched
+    // until the deciding wave is back)
+  } else {
+    return;
+  }
+  } // next tile (ST)
 }
 
 // ---- read decision --------------------------------------------------------------
 
-// One lane per read: threshold + smoothing passes + flank test (the shared
-// host/device core, csrc/host/gr_tiles_core.hpp).  The per-read scratch (ids,
-// flags, 64-bit work array) sits in LDS for reads of up to DECIDE_LDS_TILES tiles
-// and in a global scratch slice otherwise.
+// threshold + smoothing passes + flank test + decision of every read of a window (the
+// shared host/device core, csrc/host/gr_tiles_core.hpp), one WAVE per read.
+//   reads of up to 64 tiles: tile i sits in lane i, the passes run as wave-uniform scalar
+//     code on v_readlane / v_writelane (LaneState) — no LDS, no divergence
+//   longer reads: lane 0 walks a slice of a global scratch area
+// History (profiles/): 64 reads in the lanes of one wave serialised on divergence
+// (~300 us per window), one lane per wave over LDS arrays ~120 us, this form ~10 us.
 constexpr int DECIDE_THREADS = 64;
-constexpr uint32_t DECIDE_LDS_TILES = 64;
 
-// One WAVE per read: the lanes stage the read's tile summaries into LDS with one
-// coalesced load, then lane 0 runs the (inherently sequential, branchy) passes
-// alone — 64 different reads in the lanes of one wave would serialise on
-// divergence (measured: ~300 us per window against ~20 us this way).
 __global__ void __launch_bounds__(DECIDE_THREADS)
 k_decide(DevReads rd,
          uint32_t first,
@@ -899,45 +1175,31 @@ k_decide(DevReads rd,
          uint64_t* __restrict__ g_scratch,
          grp_read_decision* __restrict__ out)
 {
-  __shared__ grp_tile_summary sTiles[DECIDE_LDS_TILES];
-  __shared__ uint64_t sScratch[DECIDE_LDS_TILES];
-  __shared__ uint32_t sIds[DECIDE_LDS_TILES];
-  __shared__ uint8_t sAsg[DECIDE_LDS_TILES];
-  __shared__ uint32_t sRedo;
   const uint32_t lane = threadIdx.x;
   const uint32_t j = blockIdx.x;
   const uint64_t t_base = rd.tile0[first];
   const uint64_t a = rd.tile0[first + j] - t_base;
   const uint64_t n = rd.tile0[first + j + 1] - rd.tile0[first + j];
-  grp_read_decision d;
-  // Two copies of the same code on purpose: with the scratch pointers known to be
-  // LDS (or global) the compiler emits ds_* (or global_*) accesses; a run-time
-  // choice of address space would turn every access into a flat_* one.
-  if (n <= DECIDE_LDS_TILES) {
-    if (lane == 0) {
-      sRedo = 0;
-    }
-    __syncthreads();
+  grp_read_decision d{};
+  if (n <= LANE_TILES) {
+    LaneState st;
+    st.lists = lists;
+    bool bad = false;
     if (lane < n) {
       const grp_tile_summary t = tiles[a + lane];
-      sTiles[lane] = t;
-      if (t.list_n == GRP_TILE_FLAGGED || (uint64_t)t.list_off + t.list_n > lists_cap) {
-        sRedo = 1; // decided again after the flagged tiles have been redone / the list arena enlarged
+      st.load(t);
+      // decided again after the flagged tiles have been redone / the list arena enlarged
+      bad = t.list_n == GRP_TILE_FLAGGED || (uint64_t)t.list_off + t.list_n > lists_cap;
+    }
+    if (__ballot(bad) == 0ull) {
+      gr::core::decide(dp.threshold, dp.unassigned_min, dp.assigned_max, (size_t)n, st, d);
+      if (lane < n) { // keep the per-tile result inspectable (grp_debug_tile_states)
+        g_ids[a + lane] = st.v_id;
+        g_asg[a + lane] = (uint8_t)st.v_asg;
       }
     }
-    __syncthreads();
-    if (lane != 0) {
-      return;
-    }
-    if (sRedo) {
-      out[j] = grp_read_decision{};
-      return;
-    }
-    gr::core::decide(dp.threshold, dp.unassigned_min, dp.assigned_max, (size_t)n, sTiles, lists, sIds, sAsg, sScratch, d);
-    out[j] = d;
-    for (uint32_t i = 0; i < (uint32_t)n; ++i) { // keep the per-tile result inspectable (grp_debug_tile_states)
-      g_ids[a + i] = sIds[i];
-      g_asg[a + i] = sAsg[i];
+    if (lane == 0) {
+      out[j] = d;
     }
   } else {
     if (lane != 0) {
@@ -948,11 +1210,9 @@ k_decide(DevReads rd,
     for (uint64_t i = 0; i < n; ++i) {
       redo = redo || my_tiles[i].list_n == GRP_TILE_FLAGGED || (uint64_t)my_tiles[i].list_off + my_tiles[i].list_n > lists_cap;
     }
-    if (redo) {
-      out[j] = grp_read_decision{};
-      return;
+    if (!redo) {
+      gr::core::decide(dp.threshold, dp.unassigned_min, dp.assigned_max, (size_t)n, my_tiles, lists, g_ids + a, g_asg + a, g_scratch + a, d);
     }
-    gr::core::decide(dp.threshold, dp.unassigned_min, dp.assigned_max, (size_t)n, my_tiles, lists, g_ids + a, g_asg + a, g_scratch + a, d);
     out[j] = d;
   }
 }
@@ -1460,7 +1720,7 @@ query_geom(const grp_ctx* c, bool full)
 
 template<int HH>
 int
-launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, const uint32_t* d_tile_idx, const QueryGeom& g, uint64_t list_cap, grp_tile_summary* out_tiles = nullptr, grp_id_count* out_lists = nullptr, uint32_t direct_stride = 0)
+launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, const uint32_t* d_tile_idx, const QueryGeom& g, uint64_t list_cap, grp_tile_summary* out_tiles = nullptr, grp_id_count* out_lists = nullptr, uint32_t direct_stride = 0, const DevStreamCtl* stream_ctl = nullptr)
 {
   if (!out_tiles) {
     out_tiles = c->q->d_tiles;
@@ -1471,22 +1731,42 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     if (rc != GRP_OK) {
       return rc;
     }
-    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), d_tile_idx ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride);
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), d_tile_idx ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, stream_ctl ? *stream_ctl : DevStreamCtl{});
     return GRP_OK;
   };
+  if (stream_ctl) {
+    // persistent workgroups: exactly what is resident at once
+    auto kern = k_query<HH, 2, 0, true>;
+    int rc = ensure_lds(c, kern, g.lds);
+    if (rc != GRP_OK) {
+      return rc;
+    }
+    int per_cu = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, THREADS, g.lds));
+    static const int cap_per_cu = [] { // developer hook
+      const char* e = getenv("GRP_STREAM_WGS_PER_CU");
+      return e ? atoi(e) : 0;
+    }();
+    if (cap_per_cu > 0) {
+      per_cu = std::min(per_cu, cap_per_cu);
+    }
+    const uint64_t resident = (uint64_t)std::max(per_cu, 1) * (uint64_t)std::max(c->n_cus, 1);
+    n_launch = std::min<uint64_t>(n_launch, resident);
+    return go(kern);
+  }
   // 2 frames per lane and pass: 2*H*4 quad reads in flight per lane (measured best on MI355X)
   if constexpr (HH == 3) {
     // tuning hook (developer only): GRP_QUERY_VARIANT = "<frames per lane>,<unrolled weight>"
     static const char* v = getenv("GRP_QUERY_VARIANT");
     if (v) {
       const std::string sv(v);
-      if (sv == "1,0") return go(k_query<HH, 1, 0>);
-      if (sv == "4,0") return go(k_query<HH, 4, 0>);
-      if (sv == "2,16" && c->uniform_weight == 16) return go(k_query<HH, 2, 16>);
-      if (sv == "1,16" && c->uniform_weight == 16) return go(k_query<HH, 1, 16>);
+      if (sv == "1,0") return go(k_query<HH, 1, 0, false>);
+      if (sv == "4,0") return go(k_query<HH, 4, 0, false>);
+      if (sv == "2,16" && c->uniform_weight == 16) return go(k_query<HH, 2, 16, false>);
+      if (sv == "1,16" && c->uniform_weight == 16) return go(k_query<HH, 1, 16, false>);
     }
   }
-  return go(k_query<HH, 2, 0>);
+  return go(k_query<HH, 2, 0, false>);
 }
 
 int
@@ -1610,6 +1890,11 @@ grp_create(const grp_params* p, grp_ctx** out)
       return fail(e_ == hipErrorOutOfMemory ? GRP_ERR_NOMEM : GRP_ERR_HIP);                                            \
     }                                                                                                                  \
   } while (0)
+  {
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->n_cus = prop.multiProcessorCount;
+  }
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   CREATE_TRY(hipMalloc(&c->d_seeds, sizeof(DevSeeds)));
@@ -1628,6 +1913,13 @@ grp_create(const grp_params* p, grp_ctx** out)
     CREATE_TRY(hipMemsetAsync(sl.d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
     CREATE_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&sl.qdone, hipEventDisableTiming));
+    CREATE_TRY(hipMalloc(&sl.d_abort, 256)); // [0] abort flag, [32] tile dispenser (its own 128-byte line)
+    CREATE_TRY(hipMemsetAsync(sl.d_abort, 0, 256, c->stream));
+    CREATE_TRY(hipHostMalloc(&sl.h_abort, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_abort), sl.h_abort, 0));
+    *sl.h_abort = 0;
+    CREATE_TRY(hipMalloc(&sl.d_executed, sizeof(unsigned long long)));
+    CREATE_TRY(hipHostMalloc(&sl.h_executed, sizeof(unsigned long long), hipHostMallocDefault));
   }
   CREATE_TRY(hipHostMalloc(&c->h_lists, LIST_PREFIX * sizeof(grp_id_count), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&c->h_small_tiles, SMALL_TILES * sizeof(grp_tile_summary), hipHostMallocMapped));
@@ -1678,6 +1970,18 @@ grp_destroy(grp_ctx* c)
     if (sl.qdone) {
       (void)hipEventDestroy(sl.qdone);
     }
+    if (sl.h_sdec) {
+      (void)hipHostFree(sl.h_sdec);
+    }
+    if (sl.h_abort) {
+      (void)hipHostFree(sl.h_abort);
+    }
+    (void)hipFree(sl.d_abort);
+    if (sl.h_executed) {
+      (void)hipHostFree(sl.h_executed);
+    }
+    (void)hipFree(sl.d_tiles_done);
+    (void)hipFree(sl.d_executed);
   }
   (void)hipFree(c->d_ntc);
   (void)hipFree(c->d_ntc_chunks);
@@ -2466,7 +2770,7 @@ grp_classify_reads_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_
 int
 grp_classify_reads_end(grp_ctx* c, uint32_t slot, grp_read_decision* out)
 {
-  if (!c || slot > 1 || !c->slot[slot].busy) {
+  if (!c || slot > 1 || !c->slot[slot].busy || c->slot[slot].streaming) {
     return set_err(c, GRP_ERR_STATE, "grp_classify_reads_end: no window in flight in this slot");
   }
   QuerySlot& sl = c->slot[slot];
@@ -2530,6 +2834,181 @@ grp_classify_reads(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t coun
     return rc;
   }
   return grp_classify_reads_end(c, 0, out);
+}
+
+// ---- streaming window --------------------------------------------------------------
+
+int
+grp_classify_stream_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, const grp_read_decision** decisions)
+{
+  if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads || !dp || slot > 1 || !decisions) {
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_stream_begin: bad argument");
+  }
+  if (!c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_stream_begin before grp_finalize");
+  }
+  QuerySlot& sl = c->slot[slot];
+  if (sl.busy) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_stream_begin: slot %u still has a window in flight", slot);
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t t0 = r->tile0[first];
+  const uint64_t nt = r->tile0[first + count] - t0;
+  if (nt > (1u << 30)) {
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_stream_begin: %llu tiles in one call (limit 2^30)", (unsigned long long)nt);
+  }
+  c->q = &sl;
+  if (count > sl.sdec_cap) {
+    if (sl.h_sdec) {
+      (void)hipHostFree(sl.h_sdec);
+      sl.h_sdec = nullptr;
+    }
+    sl.sdec_cap = 0;
+    const uint64_t cap = std::max<uint64_t>((uint64_t)count + count / 4, 1024);
+    HIP_TRY(c, hipHostMalloc(&sl.h_sdec, cap * sizeof(grp_read_decision), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_sdec), sl.h_sdec, 0));
+    sl.sdec_cap = cap;
+  }
+  int rc = ensure_dev(c, sl.d_tiles_done, sl.tiles_done_cap, std::max<uint64_t>(count, 1));
+  if (rc != GRP_OK) {
+    return rc;
+  }
+  if (nt + 1 > sl.d_dec_cap) {
+    (void)hipFree(sl.d_dec_ids);
+    (void)hipFree(sl.d_dec_asg);
+    (void)hipFree(sl.d_dec_scratch);
+    sl.d_dec_ids = nullptr;
+    sl.d_dec_asg = nullptr;
+    sl.d_dec_scratch = nullptr;
+    sl.d_dec_cap = 0;
+    const uint64_t cap = nt + nt / 4 + 64;
+    HIP_TRY(c, hipMalloc(&sl.d_dec_ids, cap * 4));
+    HIP_TRY(c, hipMalloc(&sl.d_dec_asg, cap));
+    HIP_TRY(c, hipMalloc(&sl.d_dec_scratch, cap * 8));
+    sl.d_dec_cap = cap;
+  }
+  sl.list_cap = std::max<uint64_t>(sl.d_lists_cap, 4 * nt + 4096);
+  rc = ensure_dev(c, sl.d_tiles, sl.d_tiles_cap, std::max<uint64_t>(nt, 1));
+  if (rc == GRP_OK) {
+    rc = ensure_dev(c, sl.d_lists, sl.d_lists_cap, sl.list_cap);
+  }
+  if (rc == GRP_OK) {
+    rc = ensure_dev(c, sl.d_flag_idx, sl.d_flag_cap, std::max<uint64_t>(nt, 1));
+  }
+  if (rc != GRP_OK) {
+    return rc;
+  }
+  // reads without a single tile are never completed by a workgroup: decided here
+  memset(sl.h_sdec, 0, (size_t)count * sizeof(grp_read_decision));
+  for (uint32_t j = 0; j < count; ++j) {
+    if (r->tile0[first + j + 1] == r->tile0[first + j]) {
+      grp_read_decision d{};
+      gr::core::decide(dp->threshold, dp->unassigned_min, dp->assigned_max, 0, nullptr, nullptr, nullptr, nullptr, nullptr, d);
+      d.pad = 1;
+      sl.h_sdec[j] = d;
+    }
+  }
+  __atomic_store_n(sl.h_abort, 0u, __ATOMIC_RELEASE);
+  sl.reads = r;
+  sl.first = first;
+  sl.count = count;
+  sl.dp = *dp;
+  sl.nt = nt;
+  sl.t0 = t0;
+  sl.busy = true;
+  sl.streaming = true;
+  *decisions = sl.h_sdec;
+  if (sl.side_used) {
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.done, 0));
+    sl.side_used = false;
+  }
+  if (nt) {
+    HIP_TRY(c, hipMemsetAsync(sl.d_abort, 0, 256, c->stream));
+    HIP_TRY(c, hipMemsetAsync(sl.d_tiles_done, 0, (size_t)count * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(sl.d_executed, 0, sizeof(unsigned long long), c->stream));
+    DevStreamCtl sc;
+    sc.first = first;
+    sc.tiles_done = sl.d_tiles_done;
+    sc.abort = sl.d_abort;
+    sc.abort_host = sl.dmap_abort;
+    sc.next_tile = sl.d_abort + 32;
+    sc.n_tiles = (uint32_t)nt;
+    sc.dec = sl.dmap_sdec;
+    sc.executed = sl.d_executed;
+    sc.dp = *dp;
+    sc.g_ids = sl.d_dec_ids;
+    sc.g_asg = sl.d_dec_asg;
+    sc.g_scratch = sl.d_dec_scratch;
+    const QueryGeom g = query_geom(c, false);
+    {
+      Timer t(c, GRP_K_QUERY, 0); // the probes actually executed are added at _end
+      int lrc = GRP_OK;
+      DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, nt, t0, nullptr, g, sl.list_cap, nullptr, nullptr, 0, &sc));
+      if (lrc != GRP_OK) {
+        sl.busy = false;
+        sl.streaming = false;
+        return lrc;
+      }
+      HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipMemcpyAsync(sl.h_executed, sl.d_executed, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(sl.d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
+  } else {
+    *sl.h_executed = 0;
+  }
+  HIP_TRY(c, hipEventRecord(sl.done, c->stream));
+  return GRP_OK;
+}
+
+int
+grp_classify_stream_abort(grp_ctx* c, uint32_t slot)
+{
+  if (!c || slot > 1 || !c->slot[slot].busy || !c->slot[slot].streaming) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_stream_abort: no streaming window in this slot");
+  }
+  __atomic_store_n(c->slot[slot].h_abort, 1u, __ATOMIC_RELEASE);
+  return GRP_OK;
+}
+
+int
+grp_classify_stream_poll(grp_ctx* c, uint32_t slot)
+{
+  if (!c || slot > 1 || !c->slot[slot].busy || !c->slot[slot].streaming) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_stream_poll: no streaming window in this slot");
+  }
+  hipError_t e = hipEventQuery(c->slot[slot].done);
+  if (e == hipSuccess) {
+    return 1;
+  }
+  if (e == hipErrorNotReady) {
+    return 0;
+  }
+  return set_err(c, GRP_ERR_HIP, "grp_classify_stream_poll: %s", hipGetErrorString(e));
+}
+
+int
+grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
+{
+  if (!c || slot > 1 || !c->slot[slot].busy || !c->slot[slot].streaming) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_stream_end: no streaming window in this slot");
+  }
+  QuerySlot& sl = c->slot[slot];
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipEventSynchronize(sl.done));
+  sl.busy = false;
+  sl.streaming = false;
+  c->kstat[GRP_K_QUERY].units += *sl.h_executed;
+  if (reads_decided) {
+    uint32_t n = 0;
+    for (uint32_t j = 0; j < sl.count; ++j) {
+      n += sl.h_sdec[j].pad != 0;
+    }
+    *reads_decided = n;
+  }
+  if (c->pending.size() > 64) {
+    drain_events(c);
+  }
+  return GRP_OK;
 }
 
 // ---- insert -------------------------------------------------------------------------

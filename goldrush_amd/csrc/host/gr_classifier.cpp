@@ -125,6 +125,8 @@ Classifier::window_plan() const
   const char* pipe_env = getenv("GRP_PIPELINE");
   const bool no_pipeline = pipe_env && !strcmp(pipe_env, "off");
   const bool force_pipeline = pipe_env && !strcmp(pipe_env, "force");
+  const char* stream_env = getenv("GRP_STREAM");
+  const bool force_stream = stream_env && !strcmp(stream_env, "force");
   const double p = std::min(1.0, std::max(std::max(p_insert_, p_insert_slow_), 1e-7));
   const double world = (double)p_.world;
   // measured on MI355X (bench.py --trace): a synchronous round costs ~70 us when it
@@ -170,7 +172,88 @@ Classifier::window_plan() const
   if (p_.world > 1) {
     w = ((w + p_.world - 1) / p_.world) * p_.world;
   }
-  return Plan{ w, best_pipe };
+  if (can_stream() && p_.max_window >= 32) {
+    // streaming launch: no per-window round trip and a stale window is cut short by the
+    // abort flag, so an insert costs one drain + relaunch (~120 us: resident workgroups
+    // finish, insert kernels, ramp-up) whatever the window size
+    const double t_abort = 120e-6;
+    // the window size does not matter to an abort (only the resident workgroups are lost),
+    // so the launches are as long as allowed
+    const uint32_t S = p_.max_window;
+    const double per_read = t_read + t_host + p * t_abort + g_fix / S;
+    if (force_stream || 1.0 / per_read > best_rate) {
+      return Plan{ S, false, true };
+    }
+  }
+  return Plan{ w, best_pipe, false };
+}
+
+bool
+Classifier::can_stream() const
+{
+  const char* e = getenv("GRP_STREAM");
+  return p_.world == 1 && vt_.stream_begin && vt_.stream_abort && vt_.stream_poll && vt_.stream_end && !(e && !strcmp(e, "off"));
+}
+
+int
+Classifier::launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, StreamFlight& f)
+{
+  const grp_decide_params dp{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
+  const gr_read_decision* dec = nullptr;
+  int rc = vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, &dec);
+  if (rc != GRP_OK) {
+    err_ = std::string("stream_begin: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+    return rc;
+  }
+  f.active = true;
+  f.pos = pos;
+  f.S = S;
+  f.slot = slot;
+  f.dec = dec;
+  ++n_windows_;
+  return GRP_OK;
+}
+
+int
+Classifier::end_stream(StreamFlight& f)
+{
+  if (!f.active) {
+    return GRP_OK;
+  }
+  f.active = false;
+  uint32_t decided = 0;
+  int rc = vt_.stream_end(ctx_, f.slot, &decided);
+  if (rc != GRP_OK) {
+    err_ = std::string("stream_end: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+    return rc;
+  }
+  n_queried_ += decided;
+  return GRP_OK;
+}
+
+// spin until record j of the window is complete
+int
+Classifier::wait_record(const StreamFlight& f, uint32_t j)
+{
+  const uint32_t* flag = &f.dec[j].pad;
+  uint32_t spins = 0;
+  bool finished_seen = false;
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == 0) {
+    __builtin_ia32_pause();
+    if ((++spins & 0x3FFFu) == 0) {
+      if (finished_seen) {
+        err_ = "streaming window finished without deciding one of its reads";
+        return GRP_ERR_STATE;
+      }
+      const int st = vt_.stream_poll(ctx_, f.slot);
+      if (st < 0) {
+        err_ = std::string("stream_poll: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+        return st;
+      }
+      finished_seen = st == 1; // one more round of spinning for the last store to land
+    }
+  }
+  return GRP_OK;
 }
 
 int
@@ -486,8 +569,116 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
   uint32_t pos = 0;
   int rc = GRP_OK;
   Flight next; // the window after the current one, already on the GPU
+  StreamFlight scur, snext;
+  auto drop_streams = [&]() {
+    for (StreamFlight* f : { &scur, &snext }) {
+      if (f->active) {
+        (void)vt_.stream_abort(ctx_, f->slot);
+        (void)end_stream(*f);
+      }
+    }
+  };
   while (pos < n && !finished_) {
     const auto t0 = std::chrono::steady_clock::now();
+    // ---- streaming window: consume the decisions while the launch is running ----
+    if (!next.active && (snext.active || window_plan().streaming)) {
+      if (snext.active) {
+        scur = snext; // starts at pos: an insert would have aborted it
+        snext.active = false;
+      } else {
+        const Plan plan = window_plan();
+        rc = launch_stream(reads, pos, std::min<uint32_t>(plan.S, n - pos), 0, scur);
+        if (rc != GRP_OK) {
+          return rc;
+        }
+      }
+      const uint32_t S = scur.S;
+      uint32_t j = 0;
+      bool stale = false, redo = false;
+      while (j < S) {
+        // the next window goes in shortly before this launch runs out of work: early
+        // enough to start back to back (the GPU is at most ~100 reads ahead of the host),
+        // late enough that an insert rarely has to abort it
+        if (!snext.active && j + 256 >= S && pos + S < n) {
+          const Plan plan = window_plan();
+          if (plan.streaming) { // queued right behind the current launch
+            rc = launch_stream(reads, pos + S, std::min<uint32_t>(plan.S, n - pos - S), scur.slot ^ 1u, snext);
+            if (rc != GRP_OK) {
+              drop_streams();
+              return rc;
+            }
+          }
+        }
+        rc = wait_record(scur, j);
+        if (rc != GRP_OK) {
+          drop_streams();
+          return rc;
+        }
+        gr_read_decision d = scur.dec[j];
+        d.pad = 0;
+        if (d.kind == 0) {
+          redo = true; // needs the worst-case table / a larger arena: synchronous path below
+          break;
+        }
+        if (d.kind == DEC_INSERT_WHOLE || d.kind == DEC_INSERT_TRIMMED) {
+          // everything behind this read is stale: stop the launches before the insert is queued
+          (void)vt_.stream_abort(ctx_, scur.slot);
+          if (snext.active) {
+            (void)vt_.stream_abort(ctx_, snext.slot);
+          }
+          stale = true;
+        }
+        if (skipped_before) {
+          skip_reads(skipped_before[pos + j]);
+        }
+        const bool ins = commit(reads, lens, pos + j, d, rc);
+        if (rc != GRP_OK) {
+          drop_streams();
+          return rc;
+        }
+        ++n_committed_;
+        p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
+        p_insert_slow_ += (1.0 / 8192.0) * ((ins ? 1.0 : 0.0) - p_insert_slow_);
+        ++j;
+        if (ins) {
+          ++n_inserts_;
+        }
+        if (stale || finished_) {
+          break;
+        }
+      }
+      pos += j;
+      if (stale || finished_ || redo) {
+        drop_streams();
+      } else {
+        rc = end_stream(scur); // completed: returns at once
+        if (rc != GRP_OK) {
+          drop_streams();
+          return rc;
+        }
+      }
+      if (redo && !finished_) {
+        // one read through the synchronous path (it redoes flagged tiles / grows the arena)
+        rc = query_window(reads, lens, pos, 1);
+        if (rc != GRP_OK) {
+          return rc;
+        }
+        if (skipped_before) {
+          skip_reads(skipped_before[pos]);
+        }
+        const bool ins = commit(reads, lens, pos, dec_all_[0], rc);
+        if (rc != GRP_OK) {
+          return rc;
+        }
+        ++n_committed_;
+        p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
+        p_insert_slow_ += (1.0 / 8192.0) * ((ins ? 1.0 : 0.0) - p_insert_slow_);
+        n_inserts_ += ins ? 1 : 0;
+        ++pos;
+      }
+      t_windows_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      continue;
+    }
     Flight cur;
     uint32_t S;
     if (next.active) {
@@ -555,6 +746,7 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
     t_commit_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   }
   abandon_window(next);
+  drop_streams();
   if (!finished_) {
     skip_reads(skipped_after);
   }

@@ -43,6 +43,7 @@ private:
   {
     uint32_t S;     // reads in the next window
     bool pipelined; // worth keeping a second window in flight
+    bool streaming; // one long launch, decisions consumed while it runs (single rank)
   };
   Plan window_plan() const;
   struct Flight
@@ -54,6 +55,16 @@ private:
   int finish_window(Flight& f);
   void abandon_window(Flight& f);
   int gather_decisions(uint32_t q);
+  struct StreamFlight
+  {
+    bool active = false;
+    uint32_t pos = 0, S = 0, slot = 0;
+    const gr_read_decision* dec = nullptr;
+  };
+  int launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, StreamFlight& f);
+  int end_stream(StreamFlight& f);
+  int wait_record(const StreamFlight& f, uint32_t j);
+  bool can_stream() const;
 
   gr_classifier_params p_;
   grp_engine_vt vt_;

@@ -8,6 +8,8 @@
 
 #include <cstring>
 
+#include <algorithm>
+
 namespace gr {
 
 static void
@@ -16,7 +18,7 @@ reserve(TileWorkspace& ws, size_t n)
   if (ws.ids.size() < n + 1) {
     ws.ids.resize(n + 1);
     ws.asg.resize(n + 1);
-    ws.scratch.resize(n + 1);
+    ws.scratch.resize(std::max(n + 1, core::GR_MIN_SCRATCH));
   }
 }
 
@@ -24,19 +26,31 @@ size_t
 smooth_tiles(size_t n, const grp_tile_summary* tiles, const grp_id_count* lists, size_t x, TileWorkspace& ws, FILE*)
 {
   reserve(ws, n);
-  return core::smooth(n, tiles, lists, x, ws.ids.data(), ws.asg.data(), ws.scratch.data());
+  core::PtrState s;
+  s.tiles = tiles;
+  s.lists = lists;
+  s.ids = ws.ids.data();
+  s.flags = ws.asg.data();
+  s.scratch = ws.scratch.data();
+  return core::smooth(n, x, s);
 }
 
 void
 find_longest_stretch(const std::vector<uint8_t>& asg, size_t n, long& start, long& end)
 {
-  core::longest_stretch(asg.data(), n, start, end);
+  core::PtrState s;
+  s.flags = const_cast<uint8_t*>(asg.data());
+  core::longest_stretch(n, s, start, end);
 }
 
 bool
 eval_flanks(long ls, long le, const uint32_t* ids, size_t n, size_t& trim_start, size_t& trim_end)
 {
-  return core::flanks(ls, le, ids, n, trim_start, trim_end);
+  uint64_t hist[core::GR_MIN_SCRATCH];
+  core::PtrState s;
+  s.ids = const_cast<uint32_t*>(ids);
+  s.scratch = hist;
+  return core::flanks(ls, le, n, s, trim_start, trim_end);
 }
 
 void

@@ -1,8 +1,15 @@
 // Tile classification core, shared by the host (g++) and the device (hipcc):
 // threshold + the ten smoothing passes of calc_num_assigned_tiles
 // (goldrush_path.cpp:628-889), find_longest_stretch (:195-233), eval_flanks
-// (:341-527) and the read decision (:960-1040).  No allocation, no STL: the
-// caller provides the scratch arrays (host vectors or LDS).
+// (:341-527) and the read decision (:960-1040).  No allocation, no STL.
+//
+// The algorithm is written once against a small "state" interface S (per-tile summaries,
+// the working IDs / flags, a 64-bit scratch array, the count>2 lists):
+//   PtrState   plain arrays — host vectors, LDS or global memory on the device
+//   LaneState  (grpath_hip.hip) tile i lives in lane i of a few VGPRs and every access is
+//              a v_readlane / v_writelane: the whole decision runs as wave-uniform scalar
+//              code without a single LDS round trip (~20x faster than one lane walking
+//              LDS arrays)
 //
 // Integer widths and wrap-around follow the reference expression by expression
 // (uint32_t +-1 in P3/P4/P5/P9, size_t in P8 and in the flank tests).
@@ -30,116 +37,166 @@ enum : uint32_t
   KIND_ASSIGNED = 5
 };
 
+// the 64-bit scratch holds max(n, GR_MIN_SCRATCH) words: the run table of the smoothing
+// passes, later the flank histograms (16 entries of {id, count})
+constexpr size_t GR_MIN_SCRATCH = 32;
+
+// One entry of a tile's count>2 list.  On the device the load is coherent at agent scope:
+// in a streaming window (k_query<.., true>) the entry was written by another workgroup —
+// possibly on another XCD, behind another L2 — during the SAME launch.
+GR_HD inline grp_id_count
+load_list_entry(const grp_id_count* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  grp_id_count e;
+  e.id = (uint32_t)v;
+  e.count = (uint32_t)(v >> 32);
+  return e;
+#else
+  return *p;
+#endif
+}
+
+// state over plain arrays; pointers that a caller does not need may stay null
+struct PtrState
+{
+  const grp_tile_summary* tiles = nullptr;
+  const grp_id_count* lists = nullptr;
+  uint32_t* ids = nullptr;
+  uint8_t* flags = nullptr;
+  uint64_t* scratch = nullptr;
+
+  GR_HD uint32_t top_id(size_t i) const { return tiles[i].top_id; }
+  GR_HD uint32_t top_count(size_t i) const { return tiles[i].top_count; }
+  GR_HD uint32_t list_n(size_t i) const { return tiles[i].list_n; }
+  GR_HD uint32_t list_off(size_t i) const { return tiles[i].list_off; }
+  GR_HD uint32_t hits(size_t i) const { return tiles[i].hits; }
+  GR_HD uint32_t misses(size_t i) const { return tiles[i].misses; }
+  GR_HD grp_id_count list_entry(size_t k) const { return load_list_entry(lists + k); }
+  GR_HD uint32_t id(size_t i) const { return ids[i]; }
+  GR_HD void set_id(size_t i, uint32_t v) { ids[i] = v; }
+  GR_HD uint32_t asg(size_t i) const { return flags[i]; }
+  GR_HD void set_asg(size_t i, uint32_t v) { flags[i] = (uint8_t)v; }
+  GR_HD uint64_t scr(size_t i) const { return scratch[i]; }
+  GR_HD void set_scr(size_t i, uint64_t v) { scratch[i] = v; }
+};
+
 // P1 / P2 (:646-661, :667-682): tile i takes over its neighbour's ID when that
 // ID is in tile i's own count>2 list; its flag becomes (count > x).
+template<class S>
 GR_HD inline void
-adopt_neighbour(size_t i, size_t nb, const grp_tile_summary* tiles, const grp_id_count* lists, size_t x, uint32_t* ids, uint8_t* asg)
+adopt_neighbour(size_t i, size_t nb, size_t x, S& s)
 {
-  const uint32_t want = ids[nb];
-  if (ids[i] == want) {
+  const uint32_t want = s.id(nb);
+  if (s.id(i) == want) {
     return;
   }
-  const grp_id_count* l = lists + tiles[i].list_off;
-  for (uint32_t j = 0; j < tiles[i].list_n; ++j) {
-    if (l[j].id == want) {
-      ids[i] = want;
-      asg[i] = l[j].count > x ? 1 : 0;
+  const size_t off = s.list_off(i);
+  const uint32_t ln = s.list_n(i);
+  for (uint32_t j = 0; j < ln; ++j) {
+    const grp_id_count e = s.list_entry(off + j);
+    if (e.id == want) {
+      s.set_id(i, want);
+      s.set_asg(i, e.count > x ? 1u : 0u);
     }
   }
 }
 
 // P3 / P4 (:688-710, :712-734)
+template<class S>
 GR_HD inline void
-neighbour_fill(size_t i, uint32_t* ids, uint8_t* asg)
+neighbour_fill(size_t i, S& s)
 {
-  if (asg[i]) {
+  if (s.asg(i)) {
     return;
   }
-  const uint32_t cur = ids[i];
-  const uint32_t pid = ids[i - 1], nid = ids[i + 1];
-  const uint8_t pa = asg[i - 1], na = asg[i + 1];
+  const uint32_t cur = s.id(i);
+  const uint32_t pid = s.id(i - 1), nid = s.id(i + 1);
+  const uint32_t pa = s.asg(i - 1), na = s.asg(i + 1);
   if ((cur == pid && pa) || (cur == nid && na)) {
-    asg[i] = 1;
+    s.set_asg(i, 1);
   } else if ((cur == (uint32_t)(pid + 1u) && pa) || (cur == (uint32_t)(nid + 1u) && na)) {
-    asg[i] = 1;
+    s.set_asg(i, 1);
   } else if ((cur == (uint32_t)(pid - 1u) && pa) || (cur == (uint32_t)(nid - 1u) && na)) {
-    asg[i] = 1;
+    s.set_asg(i, 1);
   } else if (pid == nid && pa && na) {
-    asg[i] = pa;
-    ids[i] = pid;
+    s.set_asg(i, pa);
+    s.set_id(i, pid);
   }
 }
 
 // run discovery shared by P5 (:742-753, unassigned runs) and P10 (:859-869,
 // assigned runs): only indices 1..n-2 are scanned, a run's start defaults to 0,
-// a run still open at the end of the scan is dropped.  runs[r] = start<<32 | end.
-template<bool kAssigned>
+// a run still open at the end of the scan is dropped.  scratch[r] = start<<32 | end.
+template<bool kAssigned, class S>
 GR_HD inline size_t
-collect_runs(const uint8_t* asg, size_t n, uint64_t* runs)
+collect_runs(size_t n, S& s)
 {
   size_t nr = 0;
   size_t start = 0;
   for (size_t i = 1; i + 1 < n; ++i) {
-    const bool c = asg[i] != 0, p = asg[i - 1] != 0;
+    const bool c = s.asg(i) != 0, p = s.asg(i - 1) != 0;
     if (c == kAssigned && p != kAssigned) {
       start = i;
     } else if (c != kAssigned && p == kAssigned) {
-      runs[nr++] = ((uint64_t)start << 32) | (uint64_t)(i - 1);
+      s.set_scr(nr++, ((uint64_t)start << 32) | (uint64_t)(i - 1));
     }
   }
   return nr;
 }
 
-// ids / asg: outputs, n entries; scratch: n uint64 entries.
-// Returns the number of assigned tiles.
+// Fills the working IDs / flags of the n tiles; returns the number of assigned tiles.
+template<class S>
 GR_HD inline size_t
-smooth(size_t n, const grp_tile_summary* tiles, const grp_id_count* lists, size_t x, uint32_t* ids, uint8_t* asg, uint64_t* scratch)
+smooth(size_t n, size_t x, S& s)
 {
   for (size_t i = 0; i < n; ++i) {
-    ids[i] = tiles[i].top_id;
+    s.set_id(i, s.top_id(i));
     // :628-634 — the list is non-empty iff some count is > 2, and then its largest
     // count (list[0] after the reference's sort) is the tile's top count; the
     // device-side lists are unsorted, so top_count is used
-    asg[i] = (tiles[i].list_n != 0 && tiles[i].top_count > x) ? 1 : 0;
+    s.set_asg(i, (s.list_n(i) != 0 && s.top_count(i) > x) ? 1u : 0u);
   }
   if (n >= 3) {
     for (size_t i = 1; i < n; ++i) { // P1
-      adopt_neighbour(i, i - 1, tiles, lists, x, ids, asg);
+      adopt_neighbour(i, i - 1, x, s);
     }
     for (size_t i = n - 1; i-- > 0;) { // P2: i = n-2 .. 0
-      adopt_neighbour(i, i + 1, tiles, lists, x, ids, asg);
+      adopt_neighbour(i, i + 1, x, s);
     }
     for (size_t i = 1; i + 1 < n; ++i) { // P3
-      neighbour_fill(i, ids, asg);
+      neighbour_fill(i, s);
     }
     for (size_t i = n - 2; i >= 1; --i) { // P4
-      neighbour_fill(i, ids, asg);
+      neighbour_fill(i, s);
     }
     // P5 (:739-766): interior unassigned runs whose flanking IDs differ by <= 1
-    size_t nr = collect_runs<false>(asg, n, scratch);
+    size_t nr = collect_runs<false>(n, s);
     for (size_t r = 0; r < nr; ++r) {
-      const size_t first = (size_t)(scratch[r] >> 32), second = (size_t)(scratch[r] & 0xFFFFFFFFu);
+      const uint64_t run = s.scr(r);
+      const size_t first = (size_t)(run >> 32), second = (size_t)(run & 0xFFFFFFFFu);
       if (first == 0 || second == n - 1) {
         continue;
       }
-      const uint32_t left = ids[first - 1];
-      const uint32_t right = ids[second + 1];
+      const uint32_t left = s.id(first - 1);
+      const uint32_t right = s.id(second + 1);
       if (left == right || left == (uint32_t)(right + 1u) || left == (uint32_t)(right - 1u)) {
         for (size_t i = first; i <= second; ++i) {
-          asg[i] = 1;
-          ids[i] = left;
+          s.set_asg(i, 1);
+          s.set_id(i, left);
         }
       }
     }
     // P6 (:771-793): isolated assigned tiles, forward then backward, 2..n-3
     for (size_t i = 2; i + 2 < n; ++i) {
-      if (asg[i] && !asg[i - 1] && !asg[i + 1]) {
-        asg[i] = 0;
+      if (s.asg(i) && !s.asg(i - 1) && !s.asg(i + 1)) {
+        s.set_asg(i, 0);
       }
     }
     for (size_t i = n - 3; i >= 2; --i) {
-      if (asg[i] && !asg[i - 1] && !asg[i + 1]) {
-        asg[i] = 0;
+      if (s.asg(i) && !s.asg(i - 1) && !s.asg(i + 1)) {
+        s.set_asg(i, 0);
       }
     }
     // P7 (:799-822): per ID in ascending order (std::map), between two
@@ -148,71 +205,74 @@ smooth(size_t n, const grp_tile_summary* tiles, const grp_id_count* lists, size_
     // scratch[e] = id<<32 | idx, insertion-sorted (indices arrive ascending).
     size_t ne = 0;
     for (size_t i = 0; i < n; ++i) {
-      if (asg[i]) {
-        const uint64_t key = ((uint64_t)ids[i] << 32) | (uint64_t)i;
+      if (s.asg(i)) {
+        const uint64_t key = ((uint64_t)s.id(i) << 32) | (uint64_t)i;
         size_t j = ne++;
-        while (j > 0 && scratch[j - 1] > key) {
-          scratch[j] = scratch[j - 1];
+        while (j > 0 && s.scr(j - 1) > key) {
+          s.set_scr(j, s.scr(j - 1));
           --j;
         }
-        scratch[j] = key;
+        s.set_scr(j, key);
       }
     }
     for (size_t g = 1; g < ne; ++g) {
-      if ((scratch[g] >> 32) != (scratch[g - 1] >> 32)) {
+      const uint64_t e0 = s.scr(g - 1), e1 = s.scr(g);
+      if ((e1 >> 32) != (e0 >> 32)) {
         continue;
       }
-      const uint32_t a = (uint32_t)scratch[g - 1], b = (uint32_t)scratch[g];
+      const uint32_t a = (uint32_t)e0, b = (uint32_t)e1;
       if (b > a + 1) {
-        const uint32_t v = ids[a];
+        const uint32_t v = s.id(a);
         for (size_t j = (size_t)a + 1; j <= b; ++j) {
-          ids[j] = v;
+          s.set_id(j, v);
         }
       }
     }
     // P8 (:827-838): end tiles, compared in size_t (no 32-bit wrap)
     {
-      const size_t last = ids[n - 1], last2 = ids[n - 2], first = ids[0], second = ids[1];
+      const size_t last = s.id(n - 1), last2 = s.id(n - 2), first = s.id(0), second = s.id(1);
       if (last == last2 || last == last2 + 1 || last == last2 - 1) {
-        asg[n - 1] = 1;
+        s.set_asg(n - 1, 1);
       }
       if (first == second || first == second + 1 || first == second - 1) {
-        asg[0] = 1;
+        s.set_asg(0, 1);
       }
     }
     // P9 (:840-850): a tile unrelated (uint32_t +-1) to both neighbours
     for (size_t i = 1; i + 1 < n; ++i) {
-      const uint32_t c = ids[i], p = ids[i - 1], q = ids[i + 1];
+      const uint32_t c = s.id(i), p = s.id(i - 1), q = s.id(i + 1);
       if (c != q && c != (uint32_t)(q - 1u) && c != (uint32_t)(q + 1u) && c != p && c != (uint32_t)(p - 1u) && c != (uint32_t)(p + 1u)) {
-        asg[i] = 0;
+        s.set_asg(i, 0);
       }
     }
     // P10 (:856-877): assigned runs of length <= 5
-    nr = collect_runs<true>(asg, n, scratch);
+    nr = collect_runs<true>(n, s);
     for (size_t r = 0; r < nr; ++r) {
-      const size_t first = (size_t)(scratch[r] >> 32), second = (size_t)(scratch[r] & 0xFFFFFFFFu);
+      const uint64_t run = s.scr(r);
+      const size_t first = (size_t)(run >> 32), second = (size_t)(run & 0xFFFFFFFFu);
       if (second - first + 1 <= 5) {
         for (size_t i = first; i <= second; ++i) {
-          asg[i] = 0;
+          s.set_asg(i, 0);
         }
       }
     }
   }
   size_t n_assigned = 0;
   for (size_t i = 0; i < n; ++i) {
-    n_assigned += asg[i] ? 1 : 0;
+    n_assigned += s.asg(i) ? 1 : 0;
   }
   return n_assigned;
 }
 
 // goldrush_path.cpp:195-233, branch for branch
+template<class S>
 GR_HD inline void
-longest_stretch(const uint8_t* b, size_t n, long& out_start, long& out_end)
+longest_stretch(size_t n, const S& s, long& out_start, long& out_end)
 {
   size_t start = 0, end = 0, cur = 0, best = 0;
   long best_start = 0, best_end = 0;
   for (size_t i = 1; i + 1 < n; ++i) {
-    const bool c = b[i] != 0, p = b[i - 1] != 0;
+    const bool c = s.asg(i) != 0, p = s.asg(i - 1) != 0;
     const bool at_last = (i + 1 == n - 1);
     if (!c && p) {
       start = i;
@@ -240,61 +300,65 @@ longest_stretch(const uint8_t* b, size_t n, long& out_start, long& out_end)
   out_end = best_end;
 }
 
-struct FlankCount
-{
-  size_t id, n;
-};
-
 // ID histogram of tiles [lo, hi) as std::map<size_t,size_t> -> vector sorted with
 // sort_by_sec.  At most 14 entries, where libstdc++'s std::sort is a plain
 // (stable) insertion sort: equal counts stay in ascending-ID order.
+// Entry e lives in scratch[2e] (id) and scratch[2e+1] (count).
+template<class S>
 GR_HD inline size_t
-flank_histogram(const uint32_t* ids, long lo, long hi, FlankCount* out)
+flank_histogram(long lo, long hi, S& s)
 {
   size_t m = 0;
   for (long i = lo; i < hi; ++i) {
-    const size_t id = ids[i];
+    const size_t id = s.id((size_t)i);
     size_t j = 0;
-    while (j < m && out[j].id != id) {
+    while (j < m && s.scr(2 * j) != id) {
       ++j;
     }
     if (j == m) {
-      out[m].id = id;
-      out[m].n = 1;
+      s.set_scr(2 * m, id);
+      s.set_scr(2 * m + 1, 1);
       ++m;
     } else {
-      ++out[j].n;
+      s.set_scr(2 * j + 1, s.scr(2 * j + 1) + 1);
     }
   }
   // order: count descending, then ID ascending
   for (size_t i = 1; i < m; ++i) {
-    const FlankCount v = out[i];
+    const uint64_t vid = s.scr(2 * i), vn = s.scr(2 * i + 1);
     size_t j = i;
-    while (j > 0 && (out[j - 1].n < v.n || (out[j - 1].n == v.n && out[j - 1].id > v.id))) {
-      out[j] = out[j - 1];
+    while (j > 0 && (s.scr(2 * j - 1) < vn || (s.scr(2 * j - 1) == vn && s.scr(2 * j - 2) > vid))) {
+      s.set_scr(2 * j, s.scr(2 * j - 2));
+      s.set_scr(2 * j + 1, s.scr(2 * j - 1));
       --j;
     }
-    out[j] = v;
+    s.set_scr(2 * j, vid);
+    s.set_scr(2 * j + 1, vn);
   }
   return m;
 }
 
-// the two acceptance rules shared by all four flank tests (:384-403 etc.)
+// the two acceptance rules shared by all four flank tests (:384-403 etc.), on the
+// histogram left in the scratch by flank_histogram
+template<class S>
 GR_HD inline bool
-flank_ok(const FlankCount* v, size_t m, bool need_two_checked)
+flank_ok(const S& s, size_t m, bool need_two_checked)
 {
   const size_t MIN_IDS_IN_FLANK = 2;
-  if (v[0].n >= MIN_IDS_IN_FLANK) {
+  const size_t n0 = (size_t)s.scr(1);
+  if (n0 >= MIN_IDS_IN_FLANK) {
     return true;
   }
   if (need_two_checked && m < 2) {
     return false;
   }
-  return v[0].n + v[1].n > MIN_IDS_IN_FLANK + 1 && (v[0].id - v[1].id == 1 || v[1].id - v[0].id == 1);
+  const size_t id0 = (size_t)s.scr(0), id1 = (size_t)s.scr(2), n1 = (size_t)s.scr(3);
+  return n0 + n1 > MIN_IDS_IN_FLANK + 1 && (id0 - id1 == 1 || id1 - id0 == 1);
 }
 
+template<class S>
 GR_HD inline bool
-flanks(long ls, long le, const uint32_t* ids, size_t n, size_t& trim_start, size_t& trim_end)
+flanks(long ls, long le, size_t n, S& s, size_t& trim_start, size_t& trim_end)
 {
   const size_t SMALL_READ_THRESHOLD = 15;
   const long MAX_TILES_TO_CHECK = 5;
@@ -302,20 +366,19 @@ flanks(long ls, long le, const uint32_t* ids, size_t n, size_t& trim_start, size
   size_t ts = default_start;
   size_t te = (size_t)(le + 1);
   bool good = false;
-  FlankCount hist[16];
 
   if (n < SMALL_READ_THRESHOLD) {
     // :364-447 — whole flanks on both sides, both must pass
     bool left_ok = false, right_ok = false;
-    size_t m = (ls > 0) ? flank_histogram(ids, 0, ls, hist) : 0;
-    if (m != 0 && flank_ok(hist, m, true)) {
+    size_t m = (ls > 0) ? flank_histogram(0, ls, s) : 0;
+    if (m != 0 && flank_ok(s, m, true)) {
       left_ok = true;
     }
     if (ts == 0) {
       left_ok = true;
     }
-    m = (le + 1 < (long)n) ? flank_histogram(ids, le + 1, (long)n, hist) : 0;
-    if (m != 0 && flank_ok(hist, m, true)) {
+    m = (le + 1 < (long)n) ? flank_histogram(le + 1, (long)n, s) : 0;
+    if (m != 0 && flank_ok(s, m, true)) {
       right_ok = true;
     }
     if (te == n - 1) {
@@ -326,8 +389,8 @@ flanks(long ls, long le, const uint32_t* ids, size_t n, size_t& trim_start, size
     // :448-525 — up to 5 tiles on each side, either side passing is enough;
     // a stretch too close to an end extends the trim to that end
     if (ls - MAX_TILES_TO_CHECK >= 1) {
-      size_t m = flank_histogram(ids, ls - MAX_TILES_TO_CHECK, ls, hist);
-      if (flank_ok(hist, m, false)) {
+      size_t m = flank_histogram(ls - MAX_TILES_TO_CHECK, ls, s);
+      if (flank_ok(s, m, false)) {
         good = true; // ts keeps its default
       }
     } else {
@@ -335,8 +398,8 @@ flanks(long ls, long le, const uint32_t* ids, size_t n, size_t& trim_start, size
       ts = 0;
     }
     if (le + MAX_TILES_TO_CHECK < (long)n - 1) {
-      size_t m = flank_histogram(ids, le + 1, le + MAX_TILES_TO_CHECK + 1, hist);
-      if (flank_ok(hist, m, false)) {
+      size_t m = flank_histogram(le + 1, le + MAX_TILES_TO_CHECK + 1, s);
+      if (flank_ok(s, m, false)) {
         good = true; // te keeps its default
       }
     } else {
@@ -349,9 +412,10 @@ flanks(long ls, long le, const uint32_t* ids, size_t n, size_t& trim_start, size
   return good;
 }
 
-// full decision of one read; ids / asg / scratch hold n entries each
+// full decision of one read
+template<class S>
 GR_HD inline void
-decide(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t n, const grp_tile_summary* tiles, const grp_id_count* lists, uint32_t* ids, uint8_t* asg, uint64_t* scratch, gr_read_decision& out)
+decide(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t n, S& s, gr_read_decision& out)
 {
   out.kind = 0;
   out.num_tiles = (uint32_t)n;
@@ -362,10 +426,10 @@ decide(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t n, c
   out.misses = 0;
   out.pad = 0;
   for (size_t i = 0; i < n; ++i) {
-    out.hits += tiles[i].hits;
-    out.misses += tiles[i].misses;
+    out.hits += s.hits(i);
+    out.misses += s.misses(i);
   }
-  const size_t na = smooth(n, tiles, lists, threshold, ids, asg, scratch);
+  const size_t na = smooth(n, threshold, s);
   out.num_assigned = (uint32_t)na;
   const size_t nu = n - na;
   if (nu >= unassigned_min && na <= assigned_max) { // :967-971
@@ -377,15 +441,28 @@ decide(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t n, c
     return;
   }
   long ls = 0, le = 0;
-  longest_stretch(asg, n, ls, le);
+  longest_stretch(n, s, ls, le);
   size_t ts = 0, te = 0;
-  if (flanks(ls, le, ids, n, ts, te)) {
+  if (flanks(ls, le, n, s, ts, te)) {
     out.kind = KIND_INSERT_TRIMMED;
     out.trim_start = (uint32_t)ts;
     out.trim_end = (uint32_t)te;
   } else {
     out.kind = KIND_ASSIGNED;
   }
+}
+
+// pointer form (ids / flags hold n entries, scratch max(n, GR_MIN_SCRATCH))
+GR_HD inline void
+decide(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t n, const grp_tile_summary* tiles, const grp_id_count* lists, uint32_t* ids, uint8_t* asg, uint64_t* scratch, gr_read_decision& out)
+{
+  PtrState s;
+  s.tiles = tiles;
+  s.lists = lists;
+  s.ids = ids;
+  s.flags = asg;
+  s.scratch = scratch;
+  decide(threshold, unassigned_min, assigned_max, n, s, out);
 }
 
 } // namespace core

@@ -87,6 +87,10 @@ SIGNATURES = {
     "grp_classify_reads": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp]),
     "grp_classify_reads_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32]),
     "grp_classify_reads_end": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "grp_classify_stream_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "grp_classify_stream_abort": (C.c_int, [_vp, C.c_uint32]),
+    "grp_classify_stream_poll": (C.c_int, [_vp, C.c_uint32]),
+    "grp_classify_stream_end": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint32)]),
     "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_insert_read": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_reset_ids": (C.c_int, [_vp]),
@@ -394,6 +398,31 @@ class Engine:
         out = np.zeros(count, dtype=decision_dtype)
         self._check(self.lib.grp_classify_reads_end(self._h, slot, _ptr(out)))
         return out
+
+    def stream_begin(self, batch: ReadBatch, first: int, count: int, slot: int, threshold=10, unassigned_min=5, assigned_max=1) -> np.ndarray:
+        """Start a streaming window; returns a live view of the decision records
+        (record j is complete once its "pad" field reads 1)."""
+        dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
+        ptr = C.c_void_p()
+        self._check(self.lib.grp_classify_stream_begin(self._h, batch._h, first, count, C.byref(dp), slot, C.byref(ptr)))
+        if count == 0:
+            return np.zeros(0, dtype=decision_dtype)
+        buf = (C.c_uint8 * (count * decision_dtype.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=decision_dtype)
+
+    def stream_abort(self, slot: int):
+        self._check(self.lib.grp_classify_stream_abort(self._h, slot))
+
+    def stream_poll(self, slot: int) -> bool:
+        rc = self.lib.grp_classify_stream_poll(self._h, slot)
+        if rc < 0:
+            self._check(rc)
+        return rc == 1
+
+    def stream_end(self, slot: int) -> int:
+        n = C.c_uint32()
+        self._check(self.lib.grp_classify_stream_end(self._h, slot, C.byref(n)))
+        return n.value
 
     def tile_states(self, n_tiles: int):
         """(ids, assigned) per tile after the smoothing passes of the last classify_reads window."""

@@ -280,6 +280,31 @@ int grp_classify_reads(grp_ctx* ctx,
 int grp_classify_reads_begin(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot);
 int grp_classify_reads_end(grp_ctx* ctx, uint32_t slot, grp_read_decision* decisions_out);
 
+/*
+ * Streaming window: ONE launch over the reads [first, first+count); the workgroup that
+ * finishes the last tile of a read takes that read's decision on the device and
+ * publishes the 32-byte record in host-visible memory at once, so the host commits
+ * read j while the same launch works on the reads behind it.
+ *   _begin  enqueues the window in slot 0 / 1 and returns the array the records appear
+ *           in: (*decisions)[j].pad becomes 1 (release) when record j is complete;
+ *           kind == 0 then means "take this read through grp_classify_reads" (a tile
+ *           needed the worst-case table or the list arena was too small).  Records
+ *           complete roughly in read order.  The array stays valid until the slot's
+ *           next _begin.
+ *   _abort  (after an insert made the rest of the window stale) workgroups that have
+ *           not started yet exit immediately; records already being worked on may
+ *           still complete.
+ *   _poll   1 when the launch has finished, 0 while it runs (a host spinning on .pad
+ *           calls it now and then to notice a failed launch).
+ *   _end    waits for the launch, frees the slot; *reads_decided = records completed.
+ * Stream-ordered like every other call: an insert issued after _abort runs behind the
+ * (draining) window.
+ */
+int grp_classify_stream_begin(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, const grp_read_decision** decisions);
+int grp_classify_stream_abort(grp_ctx* ctx, uint32_t slot);
+int grp_classify_stream_poll(grp_ctx* ctx, uint32_t slot);
+int grp_classify_stream_end(grp_ctx* ctx, uint32_t slot, uint32_t* reads_decided);
+
 /* ---- phase 2: ID insert ---------------------------------------------------- */
 /*
  * Replaces: miBFCS.insertMIBF(*miBF, hashed_values, tile_start, tile_end, id)

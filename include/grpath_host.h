@@ -38,6 +38,11 @@ typedef struct
   /* optional (both or none): pipelined windows, grp_classify_reads_begin / _end */
   int (*classify_begin)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot);
   int (*classify_end)(void* ctx, uint32_t slot, grp_read_decision* out);
+  /* optional (all four or none): streaming windows, grp_classify_stream_* */
+  int (*stream_begin)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, const grp_read_decision** decisions);
+  int (*stream_abort)(void* ctx, uint32_t slot);
+  int (*stream_poll)(void* ctx, uint32_t slot);
+  int (*stream_end)(void* ctx, uint32_t slot, uint32_t* reads_decided);
   /* optional (all four or none): --ntcard on the device, grp_ntcard_* / grp_set_filter_size */
   int (*ntcard_begin)(void* ctx, uint32_t sbits);
   int (*ntcard_add)(void* ctx, const void* reads, uint32_t first, uint32_t count, const uint32_t* stale_extra);

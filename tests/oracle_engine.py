@@ -9,8 +9,13 @@ from goldrush_amd import host, native
 
 
 class OracleEngine:
-    def __init__(self, orc, m, seeds, tile, k, reads, pipelined=False):
+    def __init__(self, orc, m, seeds, tile, k, reads, pipelined=False, streaming=False, redo_every=0):
         self.pipelined = pipelined
+        self.streaming = streaming
+        self.redo_every = redo_every  # every n-th streamed record asks for the synchronous path (kind 0)
+        self.n_streams = 0
+        self.n_stream_aborts = 0
+        self.n_redo = 0
         self.orc = orc
         self.oseeds = orc.Seeds(seeds)
         self.mf = orc.MiBF(m, self.oseeds, tile, k)
@@ -83,6 +88,54 @@ class OracleEngine:
                 arr[i] = d
             return 0
 
+        # streaming windows: all records are complete at _begin (decided against the state
+        # at that moment, like a launch that ran to the end before the host looked)
+        streams = {}
+
+        def _decide(r, dp):
+            res = self.mf.query_read(self.reads[r])
+            lists = [sorted(((int(a), int(b)) for a, b in x[2]), key=lambda t: (-t[1], t[0])) for x in res]
+            tiles, flat = host.tiles_from([x[0] for x in res], lists)
+            d = host.decide_read(tiles, flat, len(res), dp.threshold, dp.unassigned_min, dp.assigned_max)
+            d.hits = sum(int(x[3][1]) for x in res)
+            d.misses = sum(int(x[3][2]) for x in res)
+            return d
+
+        def stream_begin(ctx, reads, first, count, dp_p, slot, out_pp):
+            assert slot in (0, 1) and slot not in streams and slot not in slots, "slot busy"
+            dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
+            arr = (host.gr_read_decision * max(count, 1))()
+            for j in range(count):
+                self.n_stream_records = getattr(self, "n_stream_records", 0) + 1
+                if self.redo_every and self.n_stream_records % self.redo_every == 0:
+                    arr[j] = host.gr_read_decision()  # kind 0
+                    self.n_redo += 1
+                else:
+                    arr[j] = _decide(first + j, dp)
+                arr[j].pad = 1
+            self.n_queries += count
+            self.n_streams += 1
+            streams[slot] = (arr, count)
+            C.cast(out_pp, C.POINTER(C.c_void_p))[0] = C.addressof(arr)
+            return 0
+
+        def stream_abort(ctx, slot):
+            assert slot in streams
+            self.n_stream_aborts += 1
+            return 0
+
+        def stream_poll(ctx, slot):
+            assert slot in streams
+            return 1
+
+        def stream_end(ctx, slot, n_p):
+            arr, count = streams.pop(slot)
+            self._keep_last = getattr(self, "_keep_last", {})
+            self._keep_last[slot] = arr  # valid until the slot's next _begin
+            if n_p:
+                C.cast(n_p, C.POINTER(C.c_uint32))[0] = count
+            return 0
+
         def insert_tiles(ctx, reads, ri, ts, te, id_):
             self.mf.insert_read_tiles(self.reads[ri], ts, te, id_)
             return 0
@@ -100,6 +153,8 @@ class OracleEngine:
         impl = {}
         if self.pipelined:
             impl.update({"classify_begin": classify_begin, "classify_end": classify_end})
+        if self.streaming:
+            impl.update({"stream_begin": stream_begin, "stream_abort": stream_abort, "stream_poll": stream_poll, "stream_end": stream_end})
         impl.update({"query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync, "last_error": last_error})
         for name, ftype in host.VT_TYPES:
             if name in impl:

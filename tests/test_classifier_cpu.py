@@ -74,6 +74,33 @@ def test_pipelined_windows_match_serial_loop(oracle, native, max_window, monkeyp
     assert cls.state()["reads_committed"] == len(exp)
 
 
+@pytest.mark.parametrize("max_window,redo_every", [(32, 0), (4096, 0), (40, 7)])
+def test_streaming_windows_match_serial_loop(oracle, native, max_window, redo_every, monkeypatch):
+    """Streaming windows (stream_begin / _abort / _end): records behind an insert are
+    never committed, a record of kind 0 goes through the synchronous path."""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine, serial_reference
+
+    monkeypatch.setenv("GRP_STREAM", "force")
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    reads = _workload()
+    m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=90_000, max_paths=2)
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads, streaming=True, redo_every=redo_every)
+    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, target_bases=90_000, max_paths=2, silver_path=True, max_window=max_window)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    skipped = np.zeros(len(reads), dtype=np.uint32)
+    skipped[5] = 2
+    finished = cls.run(None, lens, skipped_before=skipped)
+    assert _strip(cls.commits) == exp
+    assert cls.rollovers == [2] and finished
+    assert np.array_equal(eng.mf.ids(), mf_ref.ids()) and np.array_equal(eng.mf.counts(), mf_ref.counts())
+    assert eng.n_streams >= 3 and eng.n_stream_aborts >= 2
+    assert (eng.n_redo > 0) == (redo_every > 0)
+    assert cls.state()["reads_committed"] == len(exp)
+
+
 def test_skipped_reads_advance_counter(oracle, native):
     from goldrush_amd import host
     from oracle_engine import OracleEngine

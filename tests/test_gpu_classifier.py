@@ -14,11 +14,15 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("max_window", [1, 5, 4096])
-def test_hip_classifier_matches_serial_loop(oracle, native, max_window):
+@pytest.mark.parametrize("max_window,mode", [(1, "auto"), (5, "auto"), (4096, "auto"), (4096, "stream"), (48, "stream"), (4096, "pipeline"), (4096, "sync")])
+def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, monkeypatch):
     from goldrush_amd import host, synth
     from oracle_engine import serial_reference
 
+    env = {"auto": {}, "stream": {"GRP_STREAM": "force"}, "pipeline": {"GRP_STREAM": "off", "GRP_PIPELINE": "force"},
+           "sync": {"GRP_STREAM": "off", "GRP_PIPELINE": "off"}}[mode]
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
     tile, k, h, block = 500, 22, 3, 4
     seeds = default_seeds(h)
     g = synth.random_genome(150_000, 21)
@@ -168,6 +172,43 @@ def test_device_decisions_match_host_and_oracle(oracle, native):
     # empty window
     eng.classify_begin(b, 3, 0, 0)
     assert len(eng.classify_end(0)) == 0
+    # streaming windows (grp_classify_stream_*): every record appears, equal to the window's
+    # decisions; two launches queued; abort leaves the slot reusable
+    import time
+
+    def wait_all(view, slot):
+        t0 = time.time()
+        while not np.all(view["pad"] == 1):
+            assert time.time() - t0 < 60, "records missing"
+            if eng.stream_poll(slot):
+                break
+        assert np.all(view["pad"] == 1)
+
+    ref = eng.classify_reads(b)
+    v0 = eng.stream_begin(b, 0, 30, 0)
+    v1 = eng.stream_begin(b, 30, n - 30, 1)
+    with pytest.raises(native.GrpError):
+        eng.stream_begin(b, 0, 1, 1)
+    wait_all(v0, 0)
+    wait_all(v1, 1)
+    fields = ["kind", "num_tiles", "num_assigned", "trim_start", "trim_end", "hits", "misses"]
+    for f in fields:
+        assert np.array_equal(v0[f], ref[f][:30]) and np.array_equal(v1[f], ref[f][30:]), f
+    assert eng.stream_end(0) == 30 and eng.stream_end(1) == n - 30
+    with pytest.raises(native.GrpError):
+        eng.stream_end(0)
+    v = eng.stream_begin(b, 0, n, 1)
+    eng.stream_abort(1)
+    decided = eng.stream_end(1)
+    assert 0 <= decided <= n
+    done = v["pad"] == 1
+    for f in fields:  # whatever completed is right
+        assert np.array_equal(v[f][done], ref[f][done]), f
+    v = eng.stream_begin(b, 2, 9, 1)
+    wait_all(v, 1)
+    assert eng.stream_end(1) == 9 and np.array_equal(v["kind"], ref["kind"][2:11])
+    assert len(eng.stream_begin(b, 4, 0, 0)) == 0 and eng.stream_end(0) == 0
+    assert np.array_equal(eng.classify_reads(b), ref)
 
 
 def test_hip_classifier_h5_designed_seed(oracle, native):
