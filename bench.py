@@ -235,11 +235,17 @@ def main():
         achieved = kq["units"] * 128 / (kq["ms"] * 1e-3) / 1e9 if kq["ms"] > 0 else 0.0
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the
         # per-probe figure comes from the committed rocprofv3 --pmc pass of the same kernel
-        # (profiles/r01_v4_pmc_summary.json: TCC_EA0_RDREQ x 64 B = FETCH_SIZE x 1024 B)
+        # (newest profiles/r*_pmc_summary.json, tools/pmc_round.sh: TCC_EA0_RDREQ x 64 B = FETCH_SIZE x 1024 B)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_summary.json")))
-            traffic = pmc["k_query<3, 2, 0>"]["hbm_bytes_per_probe"] * probes_per_launch
+            import glob
+
+            newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
+            pmc = json.load(open(newest))
+            if "k_query_all_variants" in pmc:
+                traffic = pmc["k_query_all_variants"]["hbm_bytes_per_probe"] * probes_per_launch
+            else:
+                traffic = pmc["k_query<3, 2, 0>"]["hbm_bytes_per_probe"] * probes_per_launch
         except Exception:
             pass
         out = {

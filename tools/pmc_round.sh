@@ -1,0 +1,14 @@
+#!/bin/bash
+# Run on the GPU box (gpurun): PMC passes of the bench command, one counter group per run
+# (never combined with sys/hip/hsa tracing).   tools/pmc_round.sh <tag>
+tag=${1:-rXX}
+out=gpurun_out
+mkdir -p $out
+export TMPDIR=/tmp
+args="--no-cpu-baseline --steps 12 --warmup 0 --reads 200000"
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $out/${tag}_pmcA -o a -- python3 bench.py $args > $out/${tag}_pmcA_bench.json 2> $out/${tag}_pmcA.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmcB -o b -- python3 bench.py $args > $out/${tag}_pmcB_bench.json 2> $out/${tag}_pmcB.err
+A=$(find $out/${tag}_pmcA -name "*counter_collection.csv" | head -1)
+B=$(find $out/${tag}_pmcB -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_summary.py $out/${tag}_pmc_summary.json $out/${tag}_pmcA_bench.json $A $out/${tag}_pmcB_bench.json $B
+rm -rf $out/${tag}_pmcA $out/${tag}_pmcB

@@ -78,3 +78,18 @@ if a.trials:
     print("median abort->end %.1f us" % sorted(x[0] for x in worst)[len(worst) // 2])
     late = [x for x in worst if x[1] > 500 and x[6] < 0]
     print("trials with delay > 500 us in which the first record was never seen before the abort: %d of %d" % (len(late), sum(1 for x in worst if x[1] > 500)))
+
+# steady-state rate of one long streaming launch vs the synchronous window
+for nwin in (8192,):
+    for rep in range(3):
+        t0 = time.perf_counter()
+        v = eng.stream_begin(rb, 30000, nwin, 0)
+        while not eng.stream_poll(0):
+            pass
+        t1 = time.perf_counter()
+        eng.stream_end(0)
+        t2 = time.perf_counter()
+        eng.classify_reads(rb, 30000, nwin)
+        t3 = time.perf_counter()
+        probes = float(sum(int(x) // tile * tile for x in dr.lens[30000:30000 + nwin])) * h
+        print(f"{nwin} reads: streaming launch {1e3*(t1-t0):.2f} ms ({probes/(t1-t0)/1e9:.1f} G probes/s), synchronous window {1e3*(t3-t2):.2f} ms ({probes/(t3-t2)/1e9:.1f} G probes/s)")
