@@ -235,3 +235,35 @@ def test_hip_classifier_h5_designed_seed(oracle, native):
     assert len(cls.rollovers) >= 2
     ids, counts = eng.export_ids()
     assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
+
+
+@pytest.mark.parametrize("mode", ["stream", "pipeline"])
+def test_long_reads_small_tiles_all_decision_paths(oracle, native, mode, monkeypatch):
+    """tile = 100: reads of 40 .. 320 tiles take every decision path of the device —
+    register state (<= 64 tiles), LDS arrays (<= 256), and, in a streaming window, the
+    hand-back to the synchronous path (kind 0) for longer reads."""
+    from goldrush_amd import host, synth
+    from oracle_engine import serial_reference
+
+    for key, val in ({"GRP_STREAM": "force"} if mode == "stream" else {"GRP_STREAM": "off", "GRP_PIPELINE": "force"}).items():
+        monkeypatch.setenv(key, val)
+    tile, k, h, block = 100, 22, 3, 10
+    seeds = default_seeds(h)
+    g = synth.random_genome(120_000, 41)
+    reads = [r[1] for r in synth.make_reads(g, 70, mean_len=9000, min_len=4000, seed=42, max_len=32000)]
+    reads += [g[5000:5000 + 30500].tobytes(), g[40000:40000 + 26000].tobytes(), g[70000:70000 + 6400].tobytes()]
+    assert max(len(r) for r in reads) // tile > 256 and any(64 < len(r) // tile <= 256 for r in reads)
+    m = oracle.load().orc_calc_optimal_size(3_000_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=100_000, max_paths=4)
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    assert eng.finalize() == mf_ref.pop
+    cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, k=k, h=h, target_bases=100_000, max_paths=4, silver_path=True, max_window=64)
+    cls.run(b._h, b.lens)
+    eng.sync()
+    assert [c[:8] for c in cls.commits] == exp
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
+    kinds = [e[1] for e in exp]
+    assert kinds.count(2) >= 3 and (kinds.count(3) + kinds.count(5)) >= 10, kinds
