@@ -24,7 +24,7 @@ Classifier::Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, v
     p_.world = 1;
   }
   if (p_.max_window == 0) {
-    p_.max_window = 4096;
+    p_.max_window = 8192;
   }
   if (p_.max_window < p_.world) {
     p_.max_window = p_.world;
