@@ -267,3 +267,47 @@ def test_long_reads_small_tiles_all_decision_paths(oracle, native, mode, monkeyp
     assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
     kinds = [e[1] for e in exp]
     assert kinds.count(2) >= 3 and (kinds.count(3) + kinds.count(5)) >= 10, kinds
+
+
+def test_full_size_streaming_equals_synchronous_windows(native, monkeypatch):
+    """BASELINE-scale determinism: 40 000 reads of the C1 stream (G = 8e6 here, so that the
+    golden path keeps inserting) classified three times on fresh engines — streaming
+    windows, pipelined windows, synchronous windows — must commit the same decisions and
+    leave the same IDs / counts behind.  The streaming launch hands summaries from one
+    workgroup to another inside a launch (coherent stores, no fences) and is aborted
+    hundreds of times here: any stale hand-over would show."""
+    from goldrush_amd import host
+
+    k, h, tile, block, G = 22, 3, 1000, 10, 8_000_000
+    seeds = default_seeds(h)
+    hl = host.load()
+    m = hl.gr_calc_optimal_size(hl.gr_hash_universe(16, G, h), 1, 0.1)
+    n = 40_000
+    dr = native.synth_reads(n, G)
+    lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
+    results = []
+    for mode in ({"GRP_STREAM": "force"}, {"GRP_STREAM": "off", "GRP_PIPELINE": "force"}, {"GRP_STREAM": "off", "GRP_PIPELINE": "off"}):
+        for key in ("GRP_STREAM", "GRP_PIPELINE"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in mode.items():
+            monkeypatch.setenv(key, val)
+        eng = native.Engine(k, h, tile, m, seeds)
+        rb = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+        eng.bv_insert(rb)
+        eng.finalize()
+        cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, k=k, h=h, target_bases=int(0.9 * G), max_paths=1, silver_path=False)
+        for first in range(0, n, 8192):
+            cls.run_range(rb._h, lens, first, min(8192, n - first))
+        eng.sync()
+        st = cls.state()
+        ids, counts = eng.export_ids()
+        results.append(([c[:8] for c in cls.commits], ids.copy(), counts.copy(), st["inserts"], st["windows"]))
+        cls.close()
+        eng.close()
+    a = results[0]
+    assert a[3] > 200 and len(a[0]) == n  # many aborts in the streaming run
+    for b in results[1:]:
+        assert a[0] == b[0]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert results[0][4] < results[2][4]  # the streaming run needs far fewer launches
+    dr.free()
