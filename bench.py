@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--trace", action="store_true", help="per-step timing / speculation statistics on stderr")
     ap.add_argument("--no-kernel-timing", action="store_true", help="developer: no HIP events around the launches (roofline fields become meaningless)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for single-GPU plumbing tests)")
+    ap.add_argument("--verify-ranks", action="store_true", help="developer: N > 1, compare the classifier state of all ranks after the run")
     ap.add_argument("--share-gpu", action="store_true", help="developer: all ranks use GPU 0 (plumbing test on a 1-GPU box, use with --backend gloo)")
     a = ap.parse_args()
 
@@ -166,21 +167,24 @@ def main():
     # ---- phase 2: order-exact classification, windows sharded over the ranks ----
     allgather = None
     if world > 1:
-        bufs = {}  # per message size: device in/out tensors + pinned host mirror (no allocation per window)
+        # The decisions the ranks exchange are tiny (32 B per read, a few KB per call) and
+        # already sit in host memory: they go through a CPU (gloo) group.  A GPU collective
+        # here would need free compute units while the persistent query launch owns the
+        # device, and two PCIe copies per call; RCCL is used where bulk data moves (the
+        # bit-vector all-gather above).
+        ctrl = dist.new_group(backend="gloo") if a.backend == "nccl" else None
+        bufs = {}  # per message size: in / out tensors (no allocation per call)
 
         def allgather(user, send, nbytes, recv):  # noqa: E306
             src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
             dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
             b = bufs.get(nbytes)
             if b is None:
-                pin = coll_dev == "cuda"
-                b = (torch.empty(nbytes, dtype=torch.uint8, device=coll_dev), torch.empty(nbytes * world, dtype=torch.uint8, device=coll_dev),
-                     torch.empty(nbytes * world, dtype=torch.uint8, pin_memory=pin))
+                b = (torch.empty(nbytes, dtype=torch.uint8), torch.empty(nbytes * world, dtype=torch.uint8))
                 bufs[nbytes] = b
-            b[0].copy_(torch.from_numpy(src), non_blocking=True)
-            dist.all_gather_into_tensor(b[1], b[0])
-            b[2].copy_(b[1])  # device -> pinned host, synchronises
-            dst[:] = b[2].numpy()
+            b[0].numpy()[:] = src
+            dist.all_gather_into_tensor(b[1], b[0], group=ctrl)
+            dst[:] = b[1].numpy()
             return 0
 
     cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
@@ -226,6 +230,15 @@ def main():
         dt = float(tt.item())
     ks = eng.kernel_stats()
     st1 = cls.state()
+    if world > 1 and a.verify_ranks:
+        keys = ("valid_reads", "total_tiles", "assigned_tiles", "unassigned_tiles", "queries", "hits", "misses", "inserted_bases", "id", "ids_inserted",
+                "reads_committed", "inserts")
+        mine = [int(st1[k_]) for k_ in keys]
+        allst = [None] * world
+        dist.all_gather_object(allst, mine)
+        assert all(x == allst[0] for x in allst), "ranks disagree: %r" % (allst,)
+        if rank == 0:
+            sys.stderr.write("verify-ranks: %d ranks agree on %s\n" % (world, dict(zip(keys, mine))))
 
     if rank == 0:
         kq = ks["query"]

@@ -81,6 +81,9 @@ struct QuerySlot
   unsigned long long* d_executed = nullptr;
   unsigned long long* h_executed = nullptr; // pinned
   bool streaming = false;
+  uint32_t* h_stripe_tiles = nullptr; // pinned: this rank's tiles of a striped window
+  uint32_t* d_stripe_tiles = nullptr;
+  uint64_t stripe_tiles_cap = 0;
   bool busy = false;
   const grp_reads* reads = nullptr;
   uint32_t first = 0, count = 0;
@@ -896,6 +899,9 @@ k_query(DevFilter f,
     out_idx = sTile;
     if (out_idx >= sc.n_tiles) {
       return;
+    }
+    if (tile_idx) { // striped window: this rank's tiles only
+      out_idx = tile_idx[out_idx];
     }
     if (threadIdx.x == 0) {
       nxt = atomicAdd(sc.next_tile, 1u);
@@ -1976,6 +1982,10 @@ grp_destroy(grp_ctx* c)
     if (sl.h_abort) {
       (void)hipHostFree(sl.h_abort);
     }
+    if (sl.h_stripe_tiles) {
+      (void)hipHostFree(sl.h_stripe_tiles);
+    }
+    (void)hipFree(sl.d_stripe_tiles);
     (void)hipFree(sl.d_abort);
     if (sl.h_executed) {
       (void)hipHostFree(sl.h_executed);
@@ -2841,7 +2851,14 @@ grp_classify_reads(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t coun
 int
 grp_classify_stream_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, const grp_read_decision** decisions)
 {
-  if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads || !dp || slot > 1 || !decisions) {
+  return grp_classify_stream_begin_striped(c, r, first, count, dp, slot, 0, 1, 0, decisions);
+}
+
+int
+grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions)
+{
+  if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads || !dp || slot > 1 || !decisions || n_owners == 0 || owner >= n_owners ||
+      (n_owners > 1 && stripe_reads == 0)) {
     return set_err(c, GRP_ERR_INVALID, "grp_classify_stream_begin: bad argument");
   }
   if (!c->finalized) {
@@ -2898,6 +2915,39 @@ grp_classify_stream_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32
   if (rc != GRP_OK) {
     return rc;
   }
+  // striped window (several ranks share it): stripe t = reads [t*stripe, (t+1)*stripe) of
+  // the window belongs to rank t % n_owners; this launch draws only the owner's tiles
+  uint64_t n_mine = nt;
+  const bool striped = n_owners > 1;
+  if (striped) {
+    n_mine = 0;
+    for (uint32_t j = 0; j < count; ++j) {
+      if ((j / stripe_reads) % n_owners == owner) {
+        n_mine += r->tile0[first + j + 1] - r->tile0[first + j];
+      }
+    }
+    if (n_mine > sl.stripe_tiles_cap) {
+      if (sl.h_stripe_tiles) {
+        (void)hipHostFree(sl.h_stripe_tiles);
+        sl.h_stripe_tiles = nullptr;
+      }
+      (void)hipFree(sl.d_stripe_tiles);
+      sl.d_stripe_tiles = nullptr;
+      sl.stripe_tiles_cap = 0;
+      const uint64_t cap = n_mine + n_mine / 4 + 1024;
+      HIP_TRY(c, hipHostMalloc(&sl.h_stripe_tiles, cap * sizeof(uint32_t), hipHostMallocDefault));
+      HIP_TRY(c, hipMalloc(&sl.d_stripe_tiles, cap * sizeof(uint32_t)));
+      sl.stripe_tiles_cap = cap;
+    }
+    uint64_t w = 0;
+    for (uint32_t j = 0; j < count; ++j) {
+      if ((j / stripe_reads) % n_owners == owner) {
+        for (uint64_t t = r->tile0[first + j]; t < r->tile0[first + j + 1]; ++t) {
+          sl.h_stripe_tiles[w++] = (uint32_t)(t - t0);
+        }
+      }
+    }
+  }
   // reads without a single tile are never completed by a workgroup: decided here
   memset(sl.h_sdec, 0, (size_t)count * sizeof(grp_read_decision));
   for (uint32_t j = 0; j < count; ++j) {
@@ -2922,7 +2972,10 @@ grp_classify_stream_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32
     HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.done, 0));
     sl.side_used = false;
   }
-  if (nt) {
+  if (n_mine) {
+    if (striped) {
+      HIP_TRY(c, hipMemcpyAsync(sl.d_stripe_tiles, sl.h_stripe_tiles, n_mine * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(c, hipMemsetAsync(sl.d_abort, 0, 256, c->stream));
     HIP_TRY(c, hipMemsetAsync(sl.d_tiles_done, 0, (size_t)count * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(sl.d_executed, 0, sizeof(unsigned long long), c->stream));
@@ -2932,7 +2985,7 @@ grp_classify_stream_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32
     sc.abort = sl.d_abort;
     sc.abort_host = sl.dmap_abort;
     sc.next_tile = sl.d_abort + 32;
-    sc.n_tiles = (uint32_t)nt;
+    sc.n_tiles = (uint32_t)n_mine;
     sc.dec = sl.dmap_sdec;
     sc.executed = sl.d_executed;
     sc.dp = *dp;
@@ -2943,7 +2996,7 @@ grp_classify_stream_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32
     {
       Timer t(c, GRP_K_QUERY, 0); // the probes actually executed are added at _end
       int lrc = GRP_OK;
-      DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, nt, t0, nullptr, g, sl.list_cap, nullptr, nullptr, 0, &sc));
+      DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, n_mine, t0, striped ? sl.d_stripe_tiles : nullptr, g, sl.list_cap, nullptr, nullptr, 0, &sc));
       if (lrc != GRP_OK) {
         sl.busy = false;
         sl.streaming = false;

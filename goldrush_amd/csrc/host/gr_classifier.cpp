@@ -178,9 +178,16 @@ Classifier::window_plan() const
     // finish, insert kernels, ramp-up) whatever the window size
     const double t_abort = 120e-6;
     // the window size does not matter to an abort (only the resident workgroups are lost),
-    // so the launches are as long as allowed
+    // so the launches are as long as allowed.  Several ranks: every rank works on its own
+    // stripe of the current group, an insert also discards about half a group; the
+    // stripe exchange (~150 us per group) is hidden behind the launches unless it is the
+    // longer of the two.
     const uint32_t S = p_.max_window;
-    const double per_read = t_read + t_host + p * t_abort + g_fix / S;
+    double per_read = t_read / world + t_host + p * t_abort + g_fix / S;
+    if (p_.world > 1) {
+      const double group = (double)stripe_reads() * world;
+      per_read = std::max(t_read / world, 150e-6 / group + t_host) + p * (t_abort + 0.5 * group * t_read / world) + g_fix / S;
+    }
     if (force_stream || 1.0 / per_read > best_rate) {
       return Plan{ S, false, true };
     }
@@ -192,7 +199,24 @@ bool
 Classifier::can_stream() const
 {
   const char* e = getenv("GRP_STREAM");
-  return p_.world == 1 && vt_.stream_begin && vt_.stream_abort && vt_.stream_poll && vt_.stream_end && !(e && !strcmp(e, "off"));
+  return vt_.stream_begin && vt_.stream_abort && vt_.stream_poll && vt_.stream_end && (p_.world == 1 || allgather_cb_) && !(e && !strcmp(e, "off"));
+}
+
+uint32_t
+Classifier::stripe_reads() const
+{
+  if (p_.world == 1) {
+    return 0;
+  }
+  // Ranks exchange finished stripes (one all-gather per group of `world` stripes) while
+  // their launches run: long enough to hide the exchange behind the stripe's GPU time
+  // (~1.6 us per 25 kb read), short enough that an insert discards little.
+  static const uint32_t stripe = [] {
+    const char* e = getenv("GRP_STRIPE");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? (uint32_t)v : 128u;
+  }();
+  return stripe;
 }
 
 int
@@ -200,7 +224,7 @@ Classifier::launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, 
 {
   const grp_decide_params dp{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
   const gr_read_decision* dec = nullptr;
-  int rc = vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, &dec);
+  int rc = vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, stripe_reads(), p_.world, p_.rank, &dec);
   if (rc != GRP_OK) {
     err_ = std::string("stream_begin: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
     return rc;
@@ -595,11 +619,45 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
       const uint32_t S = scur.S;
       uint32_t j = 0;
       bool stale = false, redo = false;
+      // decision of window read j: one rank reads its own record as soon as it is
+      // complete; several ranks exchange the stripes of a group (`world` consecutive
+      // stripes = `world * stripe` consecutive reads) once each has finished its own
+      const uint32_t W = p_.world, C = stripe_reads();
+      uint32_t gbase = UINT32_MAX;
+      auto fetch = [&](uint32_t jj, gr_read_decision& d) -> int {
+        if (W == 1) {
+          const int e = wait_record(scur, jj);
+          if (e == GRP_OK) {
+            d = scur.dec[jj];
+          }
+          return e;
+        }
+        const uint32_t GW = C * W;
+        if (gbase == UINT32_MAX || jj < gbase || jj >= gbase + GW) {
+          gbase = (jj / GW) * GW;
+          const uint32_t lo = std::min(gbase + p_.rank * C, S), hi = std::min(lo + C, S);
+          stripe_send_.assign(C, gr_read_decision{});
+          for (uint32_t q = lo; q < hi; ++q) {
+            const int e = wait_record(scur, q);
+            if (e != GRP_OK) {
+              return e;
+            }
+            stripe_send_[q - lo] = scur.dec[q];
+          }
+          stripe_recv_.resize(GW);
+          if (allgather_cb_(user_, stripe_send_.data(), (uint64_t)C * sizeof(gr_read_decision), stripe_recv_.data()) != 0) {
+            err_ = "allgather callback failed";
+            return GRP_ERR_INVALID;
+          }
+        }
+        d = stripe_recv_[jj - gbase];
+        return GRP_OK;
+      };
       while (j < S) {
         // the next window goes in shortly before this launch runs out of work: early
         // enough to start back to back (the GPU is at most ~100 reads ahead of the host),
         // late enough that an insert rarely has to abort it
-        if (!snext.active && j + 256 >= S && pos + S < n) {
+        if (!snext.active && j + 256 * W >= S && pos + S < n) {
           const Plan plan = window_plan();
           if (plan.streaming) { // queued right behind the current launch
             rc = launch_stream(reads, pos + S, std::min<uint32_t>(plan.S, n - pos - S), scur.slot ^ 1u, snext);
@@ -609,12 +667,12 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
             }
           }
         }
-        rc = wait_record(scur, j);
+        gr_read_decision d;
+        rc = fetch(j, d);
         if (rc != GRP_OK) {
           drop_streams();
           return rc;
         }
-        gr_read_decision d = scur.dec[j];
         d.pad = 0;
         if (d.kind == 0) {
           redo = true; // needs the worst-case table / a larger arena: synchronous path below

@@ -65,6 +65,7 @@ private:
   int end_stream(StreamFlight& f);
   int wait_record(const StreamFlight& f, uint32_t j);
   bool can_stream() const;
+  uint32_t stripe_reads() const; // reads per stripe of a window shared by several ranks (0: one rank)
 
   gr_classifier_params p_;
   grp_engine_vt vt_;
@@ -96,7 +97,7 @@ private:
   uint32_t base_ = 0;
   std::vector<grp_tile_summary> tiles_;
   std::vector<grp_id_count> lists_;
-  std::vector<gr_read_decision> dec_, dec_all_;
+  std::vector<gr_read_decision> dec_, dec_all_, stripe_send_, stripe_recv_;
   std::vector<TileWorkspace> ws_;
   std::string err_;
 };

@@ -34,8 +34,8 @@ hip_engine()
     return grp_classify_reads_begin(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, slot);
   };
   vt.classify_end = [](void* c, uint32_t slot, grp_read_decision* out) { return grp_classify_reads_end(static_cast<grp_ctx*>(c), slot, out); };
-  vt.stream_begin = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, const grp_read_decision** dec) {
-    return grp_classify_stream_begin(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, slot, dec);
+  vt.stream_begin = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, uint32_t stripe, uint32_t n_owners, uint32_t owner, const grp_read_decision** dec) {
+    return grp_classify_stream_begin_striped(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, slot, stripe, n_owners, owner, dec);
   };
   vt.stream_abort = [](void* c, uint32_t slot) { return grp_classify_stream_abort(static_cast<grp_ctx*>(c), slot); };
   vt.stream_poll = [](void* c, uint32_t slot) { return grp_classify_stream_poll(static_cast<grp_ctx*>(c), slot); };

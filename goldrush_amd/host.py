@@ -59,7 +59,7 @@ VT_TYPES = [
     ("insert_read", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)),
     ("classify_begin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32)),
     ("classify_end", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, _vp)),
-    ("stream_begin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp)),
+    ("stream_begin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp)),
     ("stream_abort", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("stream_poll", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("stream_end", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, _vp)),
@@ -209,7 +209,7 @@ def hip_engine_vt() -> grp_engine_vt:
     """Function table filled with the grp_* symbols of libgrpath_hip.so."""
     lib = native.load()
     vt = grp_engine_vt()
-    alias = {"classify_begin": "classify_reads_begin", "classify_end": "classify_reads_end", "stream_begin": "classify_stream_begin",
+    alias = {"classify_begin": "classify_reads_begin", "classify_end": "classify_reads_end", "stream_begin": "classify_stream_begin_striped",
              "stream_abort": "classify_stream_abort", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end"}
     for name, ftype in VT_TYPES:
         sym = getattr(lib, "grp_" + alias.get(name, name))

@@ -88,6 +88,7 @@ SIGNATURES = {
     "grp_classify_reads_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32]),
     "grp_classify_reads_end": (C.c_int, [_vp, C.c_uint32, _vp]),
     "grp_classify_stream_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "grp_classify_stream_begin_striped": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "grp_classify_stream_abort": (C.c_int, [_vp, C.c_uint32]),
     "grp_classify_stream_poll": (C.c_int, [_vp, C.c_uint32]),
     "grp_classify_stream_end": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -399,12 +400,17 @@ class Engine:
         self._check(self.lib.grp_classify_reads_end(self._h, slot, _ptr(out)))
         return out
 
-    def stream_begin(self, batch: ReadBatch, first: int, count: int, slot: int, threshold=10, unassigned_min=5, assigned_max=1) -> np.ndarray:
+    def stream_begin(self, batch: ReadBatch, first: int, count: int, slot: int, threshold=10, unassigned_min=5, assigned_max=1,
+                     stripe: int = 0, n_owners: int = 1, owner: int = 0) -> np.ndarray:
         """Start a streaming window; returns a live view of the decision records
-        (record j is complete once its "pad" field reads 1)."""
+        (record j is complete once its "pad" field reads 1).  n_owners > 1: only the
+        stripes of `owner` are worked on (grp_classify_stream_begin_striped)."""
         dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
         ptr = C.c_void_p()
-        self._check(self.lib.grp_classify_stream_begin(self._h, batch._h, first, count, C.byref(dp), slot, C.byref(ptr)))
+        if n_owners > 1:
+            self._check(self.lib.grp_classify_stream_begin_striped(self._h, batch._h, first, count, C.byref(dp), slot, stripe, n_owners, owner, C.byref(ptr)))
+        else:
+            self._check(self.lib.grp_classify_stream_begin(self._h, batch._h, first, count, C.byref(dp), slot, C.byref(ptr)))
         if count == 0:
             return np.zeros(0, dtype=decision_dtype)
         buf = (C.c_uint8 * (count * decision_dtype.itemsize)).from_address(ptr.value)

@@ -301,6 +301,12 @@ int grp_classify_reads_end(grp_ctx* ctx, uint32_t slot, grp_read_decision* decis
  * (draining) window.
  */
 int grp_classify_stream_begin(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, const grp_read_decision** decisions);
+/* The same for a window shared by several ranks (one process per GPU, replicated miBF):
+ * stripe t of the window, reads [t*stripe_reads, (t+1)*stripe_reads), belongs to rank
+ * t % n_owners; this launch works on the stripes of `owner` only (records of other
+ * stripes stay at pad = 0), in window order, so that the ranks can exchange finished
+ * stripes while their launches run.  n_owners = 1 is grp_classify_stream_begin. */
+int grp_classify_stream_begin_striped(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions);
 int grp_classify_stream_abort(grp_ctx* ctx, uint32_t slot);
 int grp_classify_stream_poll(grp_ctx* ctx, uint32_t slot);
 int grp_classify_stream_end(grp_ctx* ctx, uint32_t slot, uint32_t* reads_decided);

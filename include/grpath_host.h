@@ -39,7 +39,7 @@ typedef struct
   int (*classify_begin)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot);
   int (*classify_end)(void* ctx, uint32_t slot, grp_read_decision* out);
   /* optional (all four or none): streaming windows, grp_classify_stream_* */
-  int (*stream_begin)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, const grp_read_decision** decisions);
+  int (*stream_begin)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions); /* grp_classify_stream_begin_striped */
   int (*stream_abort)(void* ctx, uint32_t slot);
   int (*stream_poll)(void* ctx, uint32_t slot);
   int (*stream_end)(void* ctx, uint32_t slot, uint32_t* reads_decided);

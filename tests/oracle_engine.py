@@ -101,11 +101,13 @@ class OracleEngine:
             d.misses = sum(int(x[3][2]) for x in res)
             return d
 
-        def stream_begin(ctx, reads, first, count, dp_p, slot, out_pp):
+        def stream_begin(ctx, reads, first, count, dp_p, slot, stripe, n_owners, owner, out_pp):
             assert slot in (0, 1) and slot not in streams and slot not in slots, "slot busy"
             dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
             arr = (host.gr_read_decision * max(count, 1))()
             for j in range(count):
+                if n_owners > 1 and (j // stripe) % n_owners != owner:
+                    continue  # another rank's stripe: the record stays at pad = 0
                 self.n_stream_records = getattr(self, "n_stream_records", 0) + 1
                 if self.redo_every and self.n_stream_records % self.redo_every == 0:
                     arr[j] = host.gr_read_decision()  # kind 0
@@ -113,7 +115,7 @@ class OracleEngine:
                 else:
                     arr[j] = _decide(first + j, dp)
                 arr[j].pad = 1
-            self.n_queries += count
+            self.n_queries += sum(1 for j in range(count) if arr[j].pad)
             self.n_streams += 1
             streams[slot] = (arr, count)
             C.cast(out_pp, C.POINTER(C.c_void_p))[0] = C.addressof(arr)

@@ -137,7 +137,8 @@ seeds = default_seeds(h)
 reads = _workload()
 m = orc.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
 PIPE = os.environ.get("GRP_PIPELINE") == "force"
-eng = OracleEngine(orc, m, seeds, tile, k, reads, pipelined=PIPE)   # every rank holds a full replica
+STREAM = os.environ.get("GRP_STREAM") == "force"
+eng = OracleEngine(orc, m, seeds, tile, k, reads, pipelined=PIPE, streaming=STREAM, redo_every=11 if STREAM else 0)   # every rank holds a full replica
 
 
 def allgather(user, send, nbytes, recv):
@@ -150,7 +151,7 @@ def allgather(user, send, nbytes, recv):
     return 0
 
 
-cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, target_bases=90_000, max_paths=2, silver_path=True, max_window=8 if PIPE else 16,
+cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, target_bases=90_000, max_paths=2, silver_path=True, max_window=40 if STREAM else (8 if PIPE else 16),
                       world=world, rank=rank, allgather=allgather)
 lens = np.array([len(r) for r in reads], dtype=np.uint32)
 cls.run(None, lens)
@@ -163,13 +164,14 @@ mine = int(tot.item())
 dist.all_reduce(tot)
 assert mine < int(tot.item())
 assert not PIPE or (eng.n_begun >= 2 and eng.n_abandoned >= 1)
+assert not STREAM or (eng.n_streams >= 3 and eng.n_stream_aborts >= 2 and eng.n_redo >= 1)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok", mine, int(tot.item()), eng.n_begun, eng.n_abandoned)
 """
 
 
-@pytest.mark.parametrize("pipeline", ["off", "force"])
+@pytest.mark.parametrize("pipeline", ["off", "force", "stream"])
 def test_two_ranks_gloo(oracle, native, tmp_path, pipeline):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
@@ -179,7 +181,8 @@ def test_two_ranks_gloo(oracle, native, tmp_path, pipeline):
         port = s.getsockname()[1]
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2", GRP_PIPELINE=pipeline)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+                   **({"GRP_STREAM": "force", "GRP_STRIPE": "3"} if pipeline == "stream" else {"GRP_PIPELINE": pipeline, "GRP_STREAM": "off"}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):

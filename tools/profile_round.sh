@@ -28,7 +28,7 @@ print(open(sys.argv[3]).read())
 PY
 rm -rf $out/${tag}_prof
 # two ranks on the one GPU (gloo): plumbing of the N > 1 path
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 12 --warmup 4 --no-cpu-baseline --backend gloo --share-gpu --reads 400000 > $out/${tag}_bench_2ranks_one_gpu_gloo_plumbing.json 2> $out/${tag}_2ranks.err
-tail -2 $out/${tag}_2ranks.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 12 --warmup 4 --no-cpu-baseline --backend gloo --share-gpu --reads 400000 --verify-ranks > $out/${tag}_bench_2ranks_one_gpu_gloo_plumbing.json 2> $out/${tag}_2ranks.err
+grep verify-ranks $out/${tag}_2ranks.err; tail -2 $out/${tag}_2ranks.err
 cat $out/${tag}_bench_default_flags.json $out/${tag}_bench_full_stream.json $out/${tag}_bench_under_rocprof.json $out/${tag}_bench_2ranks_one_gpu_gloo_plumbing.json
 head -8 $out/${tag}_kernel_stats.csv
