@@ -276,7 +276,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C1: 1M synthetic ONT reads, mean 25 kb, G=100e6, k=22 w=16 h=%d tile=1000 o=0.1, golden-path mode, order-exact" % h,
                        "reads": a.reads, "batch_reads_per_gpu": a.batch, "filter_bits": m, "pop": pop,
-                       "parallelism": "each speculative window sharded over %d GPU(s), replicated miBF, decisions all-gathered" % world},
+                       "parallelism": ("one GPU, streaming windows" if world == 1 else "windows striped over %d GPUs (128-read stripes), replicated miBF, 32-B decisions all-gathered per stripe group" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC pass of the same kernel, scaled by probes)", "kernel": "k_query", "launches": kq["launches"], "avg_launch_ms": avg_ms,
                          "probes_per_launch": probes_per_launch, "bytes_per_probe": 128},
