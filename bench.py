@@ -116,6 +116,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.path.exists("/sys/class/net/lo"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: the hostname may not resolve
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
