@@ -211,11 +211,14 @@ Classifier::stripe_reads() const
   // Ranks exchange finished stripes (one all-gather per group of `world` stripes) while
   // their launches run: long enough to hide the exchange behind the stripe's GPU time
   // (~1.6 us per 25 kb read), short enough that an insert discards little.
-  static const uint32_t stripe = [] {
+  // The all-gather of a group takes ~100 us + ~30 us per rank on a CPU group; a stripe
+  // must cover it with GPU time: 128 reads for 2 ranks, 224 for 8.
+  static const uint32_t env_stripe = [] {
     const char* e = getenv("GRP_STRIPE");
     const long v = e ? atol(e) : 0;
-    return v > 0 ? (uint32_t)v : 128u;
+    return v > 0 ? (uint32_t)v : 0u;
   }();
+  const uint32_t stripe = env_stripe ? env_stripe : 96u + 16u * p_.world;
   return stripe;
 }
 

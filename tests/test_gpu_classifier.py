@@ -209,6 +209,21 @@ def test_device_decisions_match_host_and_oracle(oracle, native):
     assert eng.stream_end(1) == 9 and np.array_equal(v["kind"], ref["kind"][2:11])
     assert len(eng.stream_begin(b, 4, 0, 0)) == 0 and eng.stream_end(0) == 0
     assert np.array_equal(eng.classify_reads(b), ref)
+    # striped window (several ranks share it): only the owner's stripes are worked on
+    seen = np.zeros(n, dtype=bool)
+    for owner in range(3):
+        v = eng.stream_begin(b, 0, n, owner & 1, stripe=7, n_owners=3, owner=owner)
+        mine = (np.arange(n) // 7) % 3 == owner
+        t0 = time.time()
+        while not eng.stream_poll(owner & 1):
+            assert time.time() - t0 < 60
+        zero_tiles = np.array([len(r) // tile == 0 for r in reads])
+        assert np.all(v["pad"][mine] == 1) and not np.any(v["pad"][~mine & ~zero_tiles])
+        for f in fields:
+            assert np.array_equal(v[f][mine], ref[f][mine]), f
+        assert eng.stream_end(owner & 1) == int(v["pad"].sum())
+        seen |= mine
+    assert seen.all()
 
 
 def test_hip_classifier_h5_designed_seed(oracle, native):
