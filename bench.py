@@ -255,7 +255,12 @@ def main():
         try:
             import glob
 
-            newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
+            import re
+
+            def _ver(path):  # r01_v10_... sorts after r01_v9_...
+                return [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
+
+            newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=_ver)[-1]
             pmc = json.load(open(newest))
             if "k_query_all_variants" in pmc:
                 traffic = pmc["k_query_all_variants"]["hbm_bytes_per_probe"] * probes_per_launch
