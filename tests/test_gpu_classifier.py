@@ -284,7 +284,8 @@ def test_long_reads_small_tiles_all_decision_paths(oracle, native, mode, monkeyp
     assert kinds.count(2) >= 3 and (kinds.count(3) + kinds.count(5)) >= 10, kinds
 
 
-def test_full_size_streaming_equals_synchronous_windows(native, monkeypatch):
+@pytest.mark.parametrize("h,n", [(3, 40_000), (5, 16_000)])
+def test_full_size_streaming_equals_synchronous_windows(native, monkeypatch, h, n):
     """BASELINE-scale determinism: 40 000 reads of the C1 stream (G = 8e6 here, so that the
     golden path keeps inserting) classified three times on fresh engines — streaming
     windows, pipelined windows, synchronous windows — must commit the same decisions and
@@ -293,11 +294,10 @@ def test_full_size_streaming_equals_synchronous_windows(native, monkeypatch):
     hundreds of times here: any stale hand-over would show."""
     from goldrush_amd import host
 
-    k, h, tile, block, G = 22, 3, 1000, 10, 8_000_000
+    k, tile, block, G = 22, 1000, 10, 8_000_000
     seeds = default_seeds(h)
     hl = host.load()
     m = hl.gr_calc_optimal_size(hl.gr_hash_universe(16, G, h), 1, 0.1)
-    n = 40_000
     dr = native.synth_reads(n, G)
     lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
     results = []
