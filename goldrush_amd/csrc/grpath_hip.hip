@@ -1756,9 +1756,11 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
       const char* e = getenv("GRP_STREAM_WGS_PER_CU");
       return e ? atoi(e) : 0;
     }();
-    if (cap_per_cu > 0) {
-      per_cu = std::min(per_cu, cap_per_cu);
-    }
+    // 3 .. 6 resident workgroups per CU run equally fast (the kernel is bound by the DRAM
+    // access rate, not by occupancy); 4 keeps the amount of work in flight — what an abort
+    // throws away — small and leaves room on every CU for other kernels (copies, a
+    // collective) beside the persistent launch
+    per_cu = std::min(per_cu, cap_per_cu > 0 ? cap_per_cu : 4);
     const uint64_t resident = (uint64_t)std::max(per_cu, 1) * (uint64_t)std::max(c->n_cus, 1);
     n_launch = std::min<uint64_t>(n_launch, resident);
     return go(kern);
