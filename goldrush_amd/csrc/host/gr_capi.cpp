@@ -2,6 +2,9 @@
 #include "../../../include/grpath_host.h"
 #include "gr_classifier.hpp"
 #include "gr_params.hpp"
+#include "gr_opts.hpp"
+#include <algorithm>
+#include <sstream>
 #include "gr_tiles.hpp"
 
 #include <cstring>
@@ -47,6 +50,47 @@ double
 gr_sum_phred(const char* qual, size_t n)
 {
   return gr::sum_phred(qual, n);
+}
+
+int
+gr_process_options_dump(int argc, char** argv, char* out, size_t cap)
+{
+  gr::Opts o;
+  const int rc = gr::process_options(o, argc, argv);
+  std::ostringstream ss;
+  ss << "assigned_max=" << o.assigned_max << "\n"
+     << "unassigned_min=" << o.unassigned_min << "\n"
+     << "tile_length=" << o.tile_length << "\n"
+     << "block_size=" << o.block_size << "\n"
+     << "hash_universe=" << o.hash_universe << "\n"
+     << "genome_size=" << o.genome_size << "\n"
+     << "kmer_size=" << o.kmer_size << "\n"
+     << "phred_min=" << o.phred_min << "\n"
+     << "phred_delta=" << o.phred_delta << "\n"
+     << "weight=" << o.weight << "\n"
+     << "min_length=" << o.min_length << "\n"
+     << "hash_num=" << o.hash_num << "\n"
+     << "occupancy=" << o.occupancy << "\n"
+     << "ratio=" << o.ratio << "\n"
+     << "jobs=" << o.jobs << "\n"
+     << "max_paths=" << o.max_paths << "\n"
+     << "threshold=" << o.threshold << "\n"
+     << "prefix_file=" << o.prefix_file << "\n"
+     << "input=" << o.input << "\n"
+     << "seed_preset=" << o.seed_preset << "\n"
+     << "filter_file=" << o.filter_file << "\n"
+     << "help=" << o.help << "\n"
+     << "ntcard=" << o.ntcard << "\n"
+     << "silver_path=" << o.silver_path << "\n"
+     << "verbose=" << o.verbose << "\n"
+     << "debug=" << o.debug << "\n";
+  const std::string t = ss.str();
+  if (out && cap) {
+    const size_t n = std::min(cap - 1, t.size());
+    std::memcpy(out, t.data(), n);
+    out[n] = '\0';
+  }
+  return rc;
 }
 
 unsigned

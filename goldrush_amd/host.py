@@ -90,6 +90,7 @@ SIGNATURES = {
     "gr_sum_phred": (C.c_double, [C.c_char_p, C.c_size_t]),
     "gr_pack_2bit": (C.c_int, [C.c_char_p, C.c_size_t, _vp]),
     "gr_effective_cpus": (C.c_uint, []),
+    "gr_process_options_dump": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_size_t]),
     "gr_ntcard_sbits": (C.c_uint, [C.c_uint64]),
     "gr_ntcard_f0": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint]),
     "gr_ntcard_split": (C.c_size_t, [C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, _vp, _vp, _vp, C.c_size_t]),
@@ -148,6 +149,15 @@ def pack_2bit(seq: bytes):
     out = np.zeros((len(seq) + 15) // 16 or 1, dtype=np.uint32)
     rc = load().gr_pack_2bit(seq, len(seq), _p(out))
     return rc, out[: (len(seq) + 15) // 16]
+
+
+def process_options_dump(argv):
+    """(exit code or -1, {name: value}) of the host's process_options on argv (no program name)."""
+    args = [b"goldrush_path"] + [a.encode() if isinstance(a, str) else a for a in argv]
+    arr = (C.c_char_p * (len(args) + 1))(*args, None)
+    buf = C.create_string_buffer(1 << 16)
+    rc = load().gr_process_options_dump(len(args), arr, buf, len(buf))
+    return rc, dict(l.split("=", 1) for l in buf.value.decode().splitlines() if "=" in l)
 
 
 def ntcard_split(seq: bytes, k: int, h: int):

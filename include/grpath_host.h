@@ -77,6 +77,10 @@ int gr_pack_2bit(const char* seq, size_t n, uint32_t* out_words);
 unsigned gr_ntcard_sbits(uint64_t input_bytes);
 uint64_t gr_ntcard_f0(uint64_t zero0, uint64_t zero1, unsigned sbits);
 size_t gr_ntcard_split(const char* seq, size_t n, unsigned k, unsigned h, uint64_t* run_off, uint64_t* run_len, uint32_t* extra, size_t cap);
+/* process_options (goldrush_path/opt.cpp:89-217) on argv; writes one "name=value" line per
+ * option into out (for the parity tests).  Returns -1 when the run would continue,
+ * otherwise the exit code the reference exits with (messages go to stdout / stderr). */
+int gr_process_options_dump(int argc, char** argv, char* out, size_t cap);
 /* CPUs this process may use: min(affinity mask, cgroup cpu.max quota) */
 unsigned gr_effective_cpus(void);
 

@@ -10,9 +10,13 @@
  *   goldrush_path/goldrush_path.cpp       everything else (cited per function)
  *   goldrush_path/opt.cpp                 flags
  *
- * PARITY UNPINNED: the reference has no unit tests / golden vectors for this
- * path and cannot be compiled in this image (btllib, sdsl-lite, sparsehash
- * absent).
+ * PARITY UNPINNED for the path as a whole: the reference has no unit tests / golden
+ * vectors for it and cannot be compiled in this image (btllib, sdsl-lite, sparsehash
+ * absent).  PINNED parts: make_seed_pattern, calc_phred_average /
+ * sum_phred and process_options are checked against the reference's own translation
+ * units (spaced_seeds.cpp, calc_phred_average.cpp, opt.cpp build from their sources
+ * alone: `make ref` -> oracle/_ref/, tests/test_reference_parts.py,
+ * tests/golden/reference_parts.json).
  */
 #ifndef ORC_PATH_H
 #define ORC_PATH_H
