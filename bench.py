@@ -290,6 +290,8 @@ def main():
             "aux": {"fill_reads_per_s": a.reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill,
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors all-gathered and OR-merged" % world, "synth_s": t_synth,
                     "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit")},
+                    "query_Gprobes_per_s": kq["units"] / (kq["ms"] * 1e-3) / 1e9 if kq["ms"] > 0 else 0.0,
+                    "random_64B_line_ceiling_Gps": 50.0,  # tools/gather_bench.hip on MI355X: 48-55 G random 64-byte lines/s (one line per probe)
                     "query_kernel_s": kq["ms"] * 1e-3, "decide_kernel_s": ks["decide"]["ms"] * 1e-3, "decide_launches": ks["decide"]["launches"],
                     "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
                     "wall_s": dt},
