@@ -572,6 +572,209 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
   return inserted;
 }
 
+// one read of the current range: the reads filtered out before it only advance the
+// counter, then process_read's tail; keeps the insert-rate estimates up to date
+bool
+Classifier::commit_one(uint32_t r, const gr_read_decision& d, int& rc)
+{
+  if (rg_.skipped_before) {
+    skip_reads(rg_.skipped_before[r]);
+  }
+  const bool ins = commit(rg_.reads, rg_.lens, r, d, rc);
+  if (rc != GRP_OK) {
+    return ins;
+  }
+  ++n_committed_;
+  p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
+  p_insert_slow_ += (1.0 / 8192.0) * ((ins ? 1.0 : 0.0) - p_insert_slow_);
+  n_inserts_ += ins ? 1 : 0;
+  return ins;
+}
+
+void
+Classifier::drop_streams()
+{
+  for (StreamFlight* f : { &scur_, &snext_ }) {
+    if (f->active) {
+      (void)vt_.stream_abort(ctx_, f->slot);
+      (void)end_stream(*f);
+    }
+  }
+}
+
+// Decision of read j of the streaming window scur_.  One rank reads its own record as
+// soon as it is complete; several ranks exchange the stripes of a group (`world`
+// consecutive stripes = world * stripe consecutive reads) once each has finished its own.
+int
+Classifier::stream_decision(uint32_t j, gr_read_decision& d)
+{
+  const uint32_t W = p_.world, S = scur_.S;
+  if (W == 1) {
+    const int e = wait_record(scur_, j);
+    if (e == GRP_OK) {
+      d = scur_.dec[j];
+    }
+    return e;
+  }
+  const uint32_t C = stripe_reads(), GW = C * W;
+  if (group_base_ == UINT32_MAX || j < group_base_ || j >= group_base_ + GW) {
+    group_base_ = (j / GW) * GW;
+    const uint32_t lo = std::min(group_base_ + p_.rank * C, S), hi = std::min(lo + C, S);
+    stripe_send_.assign(C, gr_read_decision{});
+    for (uint32_t q = lo; q < hi; ++q) {
+      const int e = wait_record(scur_, q);
+      if (e != GRP_OK) {
+        return e;
+      }
+      stripe_send_[q - lo] = scur_.dec[q];
+    }
+    stripe_recv_.resize(GW);
+    if (allgather_cb_(user_, stripe_send_.data(), (uint64_t)C * sizeof(gr_read_decision), stripe_recv_.data()) != 0) {
+      err_ = "allgather callback failed";
+      return GRP_ERR_INVALID;
+    }
+  }
+  d = stripe_recv_[j - group_base_];
+  return GRP_OK;
+}
+
+// ---- streaming window: consume the decisions while the launch is running ----------
+int
+Classifier::stream_round(uint32_t& pos)
+{
+  const uint32_t n = rg_.n;
+  int rc = GRP_OK;
+  if (snext_.active) {
+    scur_ = snext_; // starts at pos: an insert would have aborted it
+    snext_.active = false;
+  } else {
+    const Plan plan = window_plan();
+    rc = launch_stream(rg_.reads, pos, std::min<uint32_t>(plan.S, n - pos), 0, scur_);
+    if (rc != GRP_OK) {
+      return rc;
+    }
+  }
+  const uint32_t S = scur_.S;
+  group_base_ = UINT32_MAX;
+  uint32_t j = 0;
+  bool stale = false, redo = false;
+  while (j < S) {
+    // the next window goes in shortly before this launch runs out of work: early
+    // enough to start back to back (the GPU is at most ~100 reads ahead of the host),
+    // late enough that an insert rarely has to abort it
+    if (!snext_.active && j + 256 * p_.world >= S && pos + S < n) {
+      const Plan plan = window_plan();
+      if (plan.streaming) { // queued right behind the current launch
+        rc = launch_stream(rg_.reads, pos + S, std::min<uint32_t>(plan.S, n - pos - S), scur_.slot ^ 1u, snext_);
+        if (rc != GRP_OK) {
+          break;
+        }
+      }
+    }
+    gr_read_decision d;
+    rc = stream_decision(j, d);
+    if (rc != GRP_OK) {
+      break;
+    }
+    d.pad = 0;
+    if (d.kind == 0) {
+      redo = true; // needs the worst-case table / a larger arena: synchronous path below
+      break;
+    }
+    if (d.kind == DEC_INSERT_WHOLE || d.kind == DEC_INSERT_TRIMMED) {
+      // everything behind this read is stale: stop the launches before the insert is queued
+      (void)vt_.stream_abort(ctx_, scur_.slot);
+      if (snext_.active) {
+        (void)vt_.stream_abort(ctx_, snext_.slot);
+      }
+      stale = true;
+    }
+    commit_one(pos + j, d, rc);
+    if (rc != GRP_OK) {
+      break;
+    }
+    ++j;
+    if (stale || finished_) {
+      break;
+    }
+  }
+  pos += j;
+  if (rc != GRP_OK || stale || finished_ || redo) {
+    drop_streams();
+  } else {
+    rc = end_stream(scur_); // completed: returns at once
+    if (rc != GRP_OK) {
+      drop_streams();
+    }
+  }
+  if (rc == GRP_OK && redo && !finished_) {
+    // one read through the synchronous path (it redoes flagged tiles / grows the arena)
+    rc = query_window(rg_.reads, rg_.lens, pos, 1);
+    if (rc == GRP_OK) {
+      commit_one(pos, dec_all_[0], rc);
+      ++pos;
+    }
+  }
+  return rc;
+}
+
+// ---- synchronous / pipelined window: all decisions of the window, then the commit -----
+int
+Classifier::window_round(uint32_t& pos)
+{
+  const uint32_t n = rg_.n;
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc = GRP_OK;
+  Flight cur;
+  uint32_t S;
+  if (next_.active) {
+    cur = next_; // starts at pos: an insert would have abandoned it
+    next_.active = false;
+    S = cur.S;
+  } else {
+    const Plan plan = window_plan();
+    S = std::min<uint32_t>(plan.S, n - pos);
+    rc = plan.pipelined ? launch_window(rg_.reads, pos, S, 0, cur) : query_window(rg_.reads, rg_.lens, pos, S);
+    if (rc != GRP_OK) {
+      return rc;
+    }
+  }
+  if (cur.active) {
+    if (pos + S < n) {
+      const Plan plan = window_plan();
+      const uint32_t S2 = std::min<uint32_t>(plan.S, n - pos - S);
+      if (plan.pipelined && (S2 >= 16 * p_.world || S2 == plan.S)) {
+        rc = launch_window(rg_.reads, pos + S, S2, cur.slot ^ 1u, next_);
+      }
+    }
+    if (rc == GRP_OK) {
+      rc = finish_window(cur);
+    }
+    if (rc != GRP_OK) {
+      abandon_window(next_);
+      return rc;
+    }
+  }
+  const auto t1 = std::chrono::steady_clock::now();
+  t_windows_ += std::chrono::duration<double>(t1 - t0).count();
+  uint32_t j = 0;
+  bool stale = false;
+  while (j < S && !stale && !finished_) {
+    stale = commit_one(pos + j, dec_all_[j], rc); // an insert changes the miBF: later speculative results are stale
+    if (rc != GRP_OK) {
+      abandon_window(next_);
+      return rc;
+    }
+    ++j;
+  }
+  if (stale || finished_) {
+    abandon_window(next_);
+  }
+  pos += j;
+  t_commit_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+  return GRP_OK;
+}
+
 int
 Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, const uint32_t* skipped_before, uint32_t skipped_after, bool& finished)
 {
@@ -580,14 +783,14 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
     return GRP_OK;
   }
   base_ = first;
-  lens += first;
-  if (skipped_before) {
-    skipped_before += first;
-  }
+  rg_.reads = reads;
+  rg_.lens = lens + first;
+  rg_.skipped_before = skipped_before ? skipped_before + first : nullptr;
+  rg_.n = n;
   tile0_.resize((size_t)n + 1);
   tile0_[0] = 0;
   for (uint32_t i = 0; i < n; ++i) {
-    tile0_[i + 1] = tile0_[i] + lens[i] / p_.tile_length;
+    tile0_[i + 1] = tile0_[i] + rg_.lens[i] / p_.tile_length;
   }
   if (n) {
     // frames x seeds per read of this range (every tile has ~tile_length frames)
@@ -595,219 +798,20 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
   }
   uint32_t pos = 0;
   int rc = GRP_OK;
-  Flight next; // the window after the current one, already on the GPU
-  StreamFlight scur, snext;
-  auto drop_streams = [&]() {
-    for (StreamFlight* f : { &scur, &snext }) {
-      if (f->active) {
-        (void)vt_.stream_abort(ctx_, f->slot);
-        (void)end_stream(*f);
-      }
-    }
-  };
-  while (pos < n && !finished_) {
-    const auto t0 = std::chrono::steady_clock::now();
-    // ---- streaming window: consume the decisions while the launch is running ----
-    if (!next.active && (snext.active || window_plan().streaming)) {
-      if (snext.active) {
-        scur = snext; // starts at pos: an insert would have aborted it
-        snext.active = false;
-      } else {
-        const Plan plan = window_plan();
-        rc = launch_stream(reads, pos, std::min<uint32_t>(plan.S, n - pos), 0, scur);
-        if (rc != GRP_OK) {
-          return rc;
-        }
-      }
-      const uint32_t S = scur.S;
-      uint32_t j = 0;
-      bool stale = false, redo = false;
-      // decision of window read j: one rank reads its own record as soon as it is
-      // complete; several ranks exchange the stripes of a group (`world` consecutive
-      // stripes = `world * stripe` consecutive reads) once each has finished its own
-      const uint32_t W = p_.world, C = stripe_reads();
-      uint32_t gbase = UINT32_MAX;
-      auto fetch = [&](uint32_t jj, gr_read_decision& d) -> int {
-        if (W == 1) {
-          const int e = wait_record(scur, jj);
-          if (e == GRP_OK) {
-            d = scur.dec[jj];
-          }
-          return e;
-        }
-        const uint32_t GW = C * W;
-        if (gbase == UINT32_MAX || jj < gbase || jj >= gbase + GW) {
-          gbase = (jj / GW) * GW;
-          const uint32_t lo = std::min(gbase + p_.rank * C, S), hi = std::min(lo + C, S);
-          stripe_send_.assign(C, gr_read_decision{});
-          for (uint32_t q = lo; q < hi; ++q) {
-            const int e = wait_record(scur, q);
-            if (e != GRP_OK) {
-              return e;
-            }
-            stripe_send_[q - lo] = scur.dec[q];
-          }
-          stripe_recv_.resize(GW);
-          if (allgather_cb_(user_, stripe_send_.data(), (uint64_t)C * sizeof(gr_read_decision), stripe_recv_.data()) != 0) {
-            err_ = "allgather callback failed";
-            return GRP_ERR_INVALID;
-          }
-        }
-        d = stripe_recv_[jj - gbase];
-        return GRP_OK;
-      };
-      while (j < S) {
-        // the next window goes in shortly before this launch runs out of work: early
-        // enough to start back to back (the GPU is at most ~100 reads ahead of the host),
-        // late enough that an insert rarely has to abort it
-        if (!snext.active && j + 256 * W >= S && pos + S < n) {
-          const Plan plan = window_plan();
-          if (plan.streaming) { // queued right behind the current launch
-            rc = launch_stream(reads, pos + S, std::min<uint32_t>(plan.S, n - pos - S), scur.slot ^ 1u, snext);
-            if (rc != GRP_OK) {
-              drop_streams();
-              return rc;
-            }
-          }
-        }
-        gr_read_decision d;
-        rc = fetch(j, d);
-        if (rc != GRP_OK) {
-          drop_streams();
-          return rc;
-        }
-        d.pad = 0;
-        if (d.kind == 0) {
-          redo = true; // needs the worst-case table / a larger arena: synchronous path below
-          break;
-        }
-        if (d.kind == DEC_INSERT_WHOLE || d.kind == DEC_INSERT_TRIMMED) {
-          // everything behind this read is stale: stop the launches before the insert is queued
-          (void)vt_.stream_abort(ctx_, scur.slot);
-          if (snext.active) {
-            (void)vt_.stream_abort(ctx_, snext.slot);
-          }
-          stale = true;
-        }
-        if (skipped_before) {
-          skip_reads(skipped_before[pos + j]);
-        }
-        const bool ins = commit(reads, lens, pos + j, d, rc);
-        if (rc != GRP_OK) {
-          drop_streams();
-          return rc;
-        }
-        ++n_committed_;
-        p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
-        p_insert_slow_ += (1.0 / 8192.0) * ((ins ? 1.0 : 0.0) - p_insert_slow_);
-        ++j;
-        if (ins) {
-          ++n_inserts_;
-        }
-        if (stale || finished_) {
-          break;
-        }
-      }
-      pos += j;
-      if (stale || finished_ || redo) {
-        drop_streams();
-      } else {
-        rc = end_stream(scur); // completed: returns at once
-        if (rc != GRP_OK) {
-          drop_streams();
-          return rc;
-        }
-      }
-      if (redo && !finished_) {
-        // one read through the synchronous path (it redoes flagged tiles / grows the arena)
-        rc = query_window(reads, lens, pos, 1);
-        if (rc != GRP_OK) {
-          return rc;
-        }
-        if (skipped_before) {
-          skip_reads(skipped_before[pos]);
-        }
-        const bool ins = commit(reads, lens, pos, dec_all_[0], rc);
-        if (rc != GRP_OK) {
-          return rc;
-        }
-        ++n_committed_;
-        p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
-        p_insert_slow_ += (1.0 / 8192.0) * ((ins ? 1.0 : 0.0) - p_insert_slow_);
-        n_inserts_ += ins ? 1 : 0;
-        ++pos;
-      }
+  while (rc == GRP_OK && pos < n && !finished_) {
+    if (!next_.active && (snext_.active || window_plan().streaming)) {
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = stream_round(pos);
       t_windows_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      continue;
-    }
-    Flight cur;
-    uint32_t S;
-    if (next.active) {
-      cur = next; // starts at pos: an insert would have abandoned it
-      next.active = false;
-      S = cur.S;
     } else {
-      const Plan plan = window_plan();
-      S = std::min<uint32_t>(plan.S, n - pos);
-      if (plan.pipelined) {
-        rc = launch_window(reads, pos, S, 0, cur);
-      } else {
-        rc = query_window(reads, lens, pos, S);
-      }
-      if (rc != GRP_OK) {
-        return rc;
-      }
+      rc = window_round(pos);
     }
-    if (cur.active) {
-      if (pos + S < n) {
-        const Plan plan = window_plan();
-        const uint32_t S2 = std::min<uint32_t>(plan.S, n - pos - S);
-        if (plan.pipelined && (S2 >= 16 * p_.world || S2 == plan.S)) {
-          rc = launch_window(reads, pos + S, S2, cur.slot ^ 1u, next);
-        }
-      }
-      if (rc == GRP_OK) {
-        rc = finish_window(cur);
-      }
-      if (rc != GRP_OK) {
-        abandon_window(next);
-        return rc;
-      }
-    }
-    const auto t1 = std::chrono::steady_clock::now();
-    t_windows_ += std::chrono::duration<double>(t1 - t0).count();
-    uint32_t j = 0;
-    bool stale = false;
-    while (j < S) {
-      if (skipped_before) {
-        skip_reads(skipped_before[pos + j]);
-      }
-      const bool ins = commit(reads, lens, pos + j, dec_all_[j], rc);
-      if (rc != GRP_OK) {
-        abandon_window(next);
-        return rc;
-      }
-      ++n_committed_;
-      p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
-      p_insert_slow_ += (1.0 / 8192.0) * ((ins ? 1.0 : 0.0) - p_insert_slow_);
-      ++j;
-      if (ins) {
-        ++n_inserts_;
-        stale = true; // the miBF changed: later speculative results are stale
-        break;
-      }
-      if (finished_) {
-        break;
-      }
-    }
-    if (stale || finished_) {
-      abandon_window(next);
-    }
-    pos += j;
-    t_commit_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   }
-  abandon_window(next);
+  abandon_window(next_);
   drop_streams();
+  if (rc != GRP_OK) {
+    return rc;
+  }
   if (!finished_) {
     skip_reads(skipped_after);
   }

@@ -65,6 +65,11 @@ private:
   int end_stream(StreamFlight& f);
   int wait_record(const StreamFlight& f, uint32_t j);
   bool can_stream() const;
+  bool commit_one(uint32_t r, const gr_read_decision& d, int& rc);
+  void drop_streams();
+  int stream_decision(uint32_t j, gr_read_decision& d);
+  int stream_round(uint32_t& pos);
+  int window_round(uint32_t& pos);
   uint32_t stripe_reads() const; // reads per stripe of a window shared by several ranks (0: one rank)
 
   gr_classifier_params p_;
@@ -91,6 +96,18 @@ private:
   double avg_probes_per_read_ = 75000.0;
   uint64_t n_windows_ = 0, n_queried_ = 0, n_committed_ = 0, n_inserts_ = 0;
   double t_windows_ = 0, t_commit_ = 0;
+
+  // the range being classified (run) and what is in flight on the engine
+  struct Range
+  {
+    void* reads = nullptr;
+    const uint32_t* lens = nullptr;           // indexed from the range's first read
+    const uint32_t* skipped_before = nullptr; // same, or null
+    uint32_t n = 0;
+  } rg_;
+  Flight next_;              // pipelined: the window after the current one
+  StreamFlight scur_, snext_; // streaming: the current window and the one queued behind it
+  uint32_t group_base_ = UINT32_MAX; // first read of the stripe group held in stripe_recv_
 
   // scratch
   std::vector<uint64_t> tile0_; // tile prefix of the current range, relative to base_
