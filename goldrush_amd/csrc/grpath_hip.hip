@@ -1,5 +1,7 @@
 // libgrpath_hip.so — hand-written gfx950 (CDNA4) kernels + the C ABI of
 // include/grpath.h.  Integer / bit-vector work, HBM-transaction bound: no MFMA.
+// This file: context, launch logic and the exported functions; the kernels live in
+// grp_kernels.inc (hot path), grp_ingest.inc (FASTQ), grp_ntcard.inc (--ntcard).
 //
 // Kernels
 //   k_fill        spaced-seed ntHash of every read position + test-and-set of
@@ -227,1355 +229,7 @@ const uint64_t BASE_SEED[4] = { 0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x
 
 } // namespace
 
-// ---------------------------------------------------------------------------
-// device code
-// ---------------------------------------------------------------------------
-
-// 64-bit window of 2-bit bases starting at base index `b` of the staged words
-__device__ inline uint64_t
-window_at(const uint32_t* sBases, uint32_t b)
-{
-  uint32_t bit = b * 2u;
-  uint32_t wi = bit >> 5;
-  uint32_t sh = bit & 31u;
-  uint64_t lo = (uint64_t)sBases[wi] | ((uint64_t)sBases[wi + 1] << 32);
-  uint64_t w = lo >> sh;
-  if (sh) {
-    w |= (uint64_t)sBases[wi + 2] << (64u - sh);
-  }
-  return w;
-}
-
-// hash of seed s on window w (closed form: XOR of per-position table entries,
-// fwd + rev); tab is the LDS copy [s][i][b]
-__device__ inline uint64_t
-seed_hash(const ulonglong2* sTab, const DevSeeds* __restrict__ sd, uint32_t s, uint64_t w)
-{
-  uint64_t fwd = 0, rev = 0;
-  const uint32_t wt = sd->weight[s];
-  const ulonglong2* t = sTab + (size_t)s * sd->wmax * 4u;
-  for (uint32_t i = 0; i < wt; ++i) {
-    uint32_t b = (uint32_t)(w >> sd->shift[s][i]) & 3u;
-    ulonglong2 e = t[i * 4u + b];
-    fwd ^= e.x;
-    rev ^= e.y;
-  }
-  return fwd + rev;
-}
-
-__device__ inline void
-load_tab(ulonglong2* sTab, const DevSeeds* __restrict__ sd)
-{
-  const uint32_t n = sd->h * sd->wmax * 4u;
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    uint32_t s = i / (sd->wmax * 4u);
-    uint32_t r = i - s * sd->wmax * 4u;
-    sTab[i] = sd->tab[s][r >> 2][r & 3u];
-  }
-}
-
-// stage bases [b0, b0+nb) of a read into LDS words (plus 2 zero pad words);
-// returns the base offset of b0 inside the staged words
-__device__ inline uint32_t
-stage_bases(uint32_t* sBases, const uint32_t* __restrict__ packed, uint64_t word_off, uint32_t len, uint32_t b0, uint32_t nb)
-{
-  const uint32_t w0 = b0 >> 4;
-  const uint32_t w_last = (b0 + nb + 15u) >> 4; // exclusive
-  const uint32_t w_read = (len + 15u) >> 4;     // words the read owns
-  const uint32_t nw = w_last - w0 + 2u;
-  for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) {
-    uint32_t w = w0 + i;
-    sBases[i] = (w < w_read) ? packed[word_off + w] : 0u;
-  }
-  return b0 & 15u;
-}
-
-// ---- wave / block reductions -------------------------------------------------
-
-__device__ inline uint32_t
-wave_sum(uint32_t v)
-{
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    v += __shfl_xor(v, o, 64);
-  }
-  return v;
-}
-
-// ---- fill ------------------------------------------------------------------------
-
-template<int H>
-__global__ void __launch_bounds__(THREADS)
-k_fill(DevFilter f, DevReads rd, const DevSeeds* __restrict__ sd, uint64_t chunk_begin)
-{
-  extern __shared__ uint4 smem4[];
-  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
-  uint32_t* sBases = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
-
-  const uint64_t chunk = chunk_begin + blockIdx.x;
-  const uint32_t r = rd.chunk_read[chunk];
-  const uint32_t ci = (uint32_t)(chunk - rd.chunk0[r]);
-  const uint32_t len = rd.len[r];
-  const uint32_t k = sd->k;
-  const uint32_t npos = len - k + 1u; // chunk exists => len >= k + H - 1
-  const uint32_t p0 = ci * FILL_CHUNK;
-  const uint32_t np = min(FILL_CHUNK, npos - p0);
-
-  load_tab(sTab, sd);
-  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[r], len, p0, np + k + H - 2u);
-  __syncthreads();
-
-  uint32_t* words = f.bv;
-  constexpr int FR = 4;
-  for (uint32_t i0 = threadIdx.x; i0 < np; i0 += THREADS * FR) {
-    uint64_t widx[FR][H];
-    uint32_t mask[FR][H];
-    uint32_t val[FR][H];
-#pragma unroll
-    for (int j = 0; j < FR; ++j) {
-      const uint32_t i = i0 + j * THREADS;
-      const uint32_t p = p0 + i;
-#pragma unroll
-      for (int s = 0; s < H; ++s) {
-        // seed s is valid at read position p iff p + span_s <= len
-        // (stale re-inserts of the iterator set the same bit again)
-        const bool ok = (i < np) && (p + sd->span[s] <= len);
-        mask[j][s] = 0;
-        widx[j][s] = 0;
-        if (ok) {
-          uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + i));
-          uint64_t pos = grp_mod_m(hv, f.m, f.m_inv);
-          widx[j][s] = pos >> 5;
-          mask[j][s] = 1u << (uint32_t)(pos & 31u);
-        }
-      }
-    }
-    // test first (plain load), set only where needed: the filter saturates and
-    // most probes find their bit already set
-#pragma unroll
-    for (int j = 0; j < FR; ++j) {
-#pragma unroll
-      for (int s = 0; s < H; ++s) {
-        val[j][s] = mask[j][s] ? words[widx[j][s]] : 0xFFFFFFFFu;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < FR; ++j) {
-#pragma unroll
-      for (int s = 0; s < H; ++s) {
-        if (mask[j][s] & ~val[j][s]) {
-          atomicOr(&words[widx[j][s]], mask[j][s]);
-        }
-      }
-    }
-  }
-}
-
-// dst |= src, 16 bytes per lane (streaming)
-__global__ void __launch_bounds__(THREADS)
-k_bv_or(uint4* __restrict__ dst, const uint4* __restrict__ src, uint64_t n4, uint32_t* __restrict__ dst_tail, const uint32_t* __restrict__ src_tail, uint32_t n_tail)
-{
-  for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * THREADS) {
-    const uint4 a = dst[i], b = src[i];
-    dst[i] = make_uint4(a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w);
-  }
-  if (blockIdx.x == 0 && threadIdx.x < n_tail) {
-    dst_tail[threadIdx.x] |= src_tail[threadIdx.x];
-  }
-}
-
-// ---- finalize: plain bit vector -> 64-byte buckets -----------------------------
-
-__global__ void __launch_bounds__(THREADS)
-k_popcount(const uint32_t* __restrict__ bv, uint64_t n_words, unsigned long long* __restrict__ out)
-{
-  __shared__ uint32_t sW[THREADS / 64];
-  uint32_t acc = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * THREADS) {
-    acc += __popc(bv[i]);
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) {
-    sW[threadIdx.x >> 6] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long t = 0;
-    for (int w = 0; w < THREADS / 64; ++w) {
-      t += sW[w];
-    }
-    atomicAdd(out, t);
-  }
-}
-
-// the W filter bits of bucket b (bv is padded with 3 zero words)
-__device__ inline uint64_t
-bucket_bits(const uint32_t* __restrict__ bv, uint64_t b, uint32_t W, uint64_t m)
-{
-  const uint64_t s = b * W;
-  const uint64_t w = s >> 5;
-  const uint32_t sh = (uint32_t)(s & 31u);
-  uint64_t v = ((uint64_t)bv[w] | ((uint64_t)bv[w + 1] << 32)) >> sh;
-  if (sh) {
-    v |= (uint64_t)bv[w + 2] << (64u - sh);
-  }
-  const uint64_t n = (s + W <= m) ? W : (m - s); // the last bucket may be short
-  if (n < 64) {
-    v &= (1ull << n) - 1ull;
-  }
-  return v;
-}
-
-__global__ void __launch_bounds__(THREADS)
-k_bucket_chunk_sums(const uint32_t* __restrict__ bv, uint64_t m, uint32_t W, uint64_t n_buckets, uint32_t* __restrict__ chunk_sum)
-{
-  __shared__ uint32_t sW[THREADS / 64];
-  const uint64_t b0 = (uint64_t)blockIdx.x * GRP_CHUNK_BUCKETS;
-  uint32_t acc = 0;
-  for (uint32_t i = threadIdx.x; i < GRP_CHUNK_BUCKETS; i += THREADS) {
-    const uint64_t b = b0 + i;
-    if (b < n_buckets) {
-      acc += (uint32_t)__popcll(bucket_bits(bv, b, W, m));
-    }
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) {
-    sW[threadIdx.x >> 6] = acc;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int w = 0; w < THREADS / 64; ++w) {
-      t += sW[w];
-    }
-    chunk_sum[blockIdx.x] = t;
-  }
-}
-
-// single workgroup: exclusive scan of the chunk sums (uint64), superbucket table, pop
-__global__ void __launch_bounds__(1024)
-k_scan_chunks(const uint32_t* __restrict__ chunk_sum, uint64_t n_chunks, uint64_t* __restrict__ chunk_base, uint64_t* __restrict__ super, uint64_t* __restrict__ pop_out)
-{
-  __shared__ uint64_t sScan[1024];
-  __shared__ uint64_t sCarry;
-  if (threadIdx.x == 0) {
-    sCarry = 0;
-  }
-  __syncthreads();
-  const uint32_t chunks_per_super = (1u << GRP_SUPER_SHIFT) / GRP_CHUNK_BUCKETS;
-  for (uint64_t c0 = 0; c0 < n_chunks; c0 += 1024) {
-    uint64_t c = c0 + threadIdx.x;
-    uint64_t v = (c < n_chunks) ? chunk_sum[c] : 0;
-    sScan[threadIdx.x] = v;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) { // Hillis-Steele inclusive scan
-      uint64_t t = (threadIdx.x >= o) ? sScan[threadIdx.x - o] : 0;
-      __syncthreads();
-      sScan[threadIdx.x] += t;
-      __syncthreads();
-    }
-    uint64_t excl = sCarry + sScan[threadIdx.x] - v;
-    if (c < n_chunks) {
-      chunk_base[c] = excl;
-      if (c % chunks_per_super == 0) {
-        super[c / chunks_per_super] = excl;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) {
-      sCarry += sScan[1023];
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    *pop_out = sCarry;
-  }
-}
-
-// write every bucket of a chunk: {rel, bitmap, ids = 0}; count overflow entries
-__global__ void __launch_bounds__(THREADS)
-k_bucket_write(const uint32_t* __restrict__ bv, uint64_t m, uint32_t W, uint64_t n_buckets, uint4* __restrict__ buckets, const uint64_t* __restrict__ chunk_base, const uint64_t* __restrict__ super, unsigned long long* __restrict__ n_ovf)
-{
-  constexpr uint32_t PER = GRP_CHUNK_BUCKETS / THREADS; // consecutive buckets per thread
-  __shared__ uint32_t sScan[THREADS];
-  const uint64_t chunk = blockIdx.x;
-  const uint64_t b0 = chunk * GRP_CHUNK_BUCKETS + (uint64_t)threadIdx.x * PER;
-  uint64_t bm[PER];
-  uint32_t tot = 0, ovf = 0;
-#pragma unroll
-  for (uint32_t i = 0; i < PER; ++i) {
-    const uint64_t b = b0 + i;
-    bm[i] = (b < n_buckets) ? bucket_bits(bv, b, W, m) : 0ull;
-    const uint32_t c = (uint32_t)__popcll(bm[i]);
-    tot += c;
-    ovf += (c > GRP_BUCKET_IDS) ? (c - GRP_BUCKET_IDS) : 0u;
-  }
-  sScan[threadIdx.x] = tot;
-  __syncthreads();
-  for (uint32_t o = 1; o < THREADS; o <<= 1) {
-    uint32_t t = (threadIdx.x >= o) ? sScan[threadIdx.x - o] : 0;
-    __syncthreads();
-    sScan[threadIdx.x] += t;
-    __syncthreads();
-  }
-  const uint64_t sb = (chunk * GRP_CHUNK_BUCKETS) >> GRP_SUPER_SHIFT;
-  uint32_t rel = (uint32_t)(chunk_base[chunk] - super[sb]) + sScan[threadIdx.x] - tot;
-#pragma unroll
-  for (uint32_t i = 0; i < PER; ++i) {
-    const uint64_t b = b0 + i;
-    if (b < n_buckets) {
-      buckets[b * 4 + 0] = make_uint4(rel, (uint32_t)bm[i], (uint32_t)(bm[i] >> 32), 0u);
-      buckets[b * 4 + 1] = make_uint4(0, 0, 0, 0);
-      buckets[b * 4 + 2] = make_uint4(0, 0, 0, 0);
-      buckets[b * 4 + 3] = make_uint4(0, 0, 0, 0);
-    }
-    rel += (uint32_t)__popcll(bm[i]);
-  }
-  ovf = wave_sum(ovf);
-  if ((threadIdx.x & 63) == 0 && ovf) {
-    atomicAdd(n_ovf, (unsigned long long)ovf);
-  }
-}
-
-// zero every ID (bucket slots), keep rel + bitmap
-__global__ void __launch_bounds__(THREADS)
-k_reset_bucket_ids(uint4* __restrict__ buckets, uint64_t n_buckets)
-{
-  // four lanes per bucket, one 16-byte piece each
-  const uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-  const uint64_t b = i >> 2;
-  const uint32_t q = (uint32_t)(i & 3u);
-  if (b >= n_buckets) {
-    return;
-  }
-  if (q == 0) {
-    reinterpret_cast<uint32_t*>(&buckets[b * 4])[3] = 0u;
-  } else {
-    buckets[b * 4 + q] = make_uint4(0, 0, 0, 0);
-  }
-}
-
-// ---- quad exchange (DPP) ------------------------------------------------------------
-
-// value of quad lane G in every lane of the quad (v_mov_b32 dpp quad_perm:[G,G,G,G])
-template<int G>
-__device__ inline uint32_t
-quad_bcast(uint32_t v)
-{
-  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, G * 0x55, 0xF, 0xF, true);
-}
-
-template<int G>
-__device__ inline uint64_t
-quad_bcast64(uint64_t v)
-{
-  return (uint64_t)quad_bcast<G>((uint32_t)v) | ((uint64_t)quad_bcast<G>((uint32_t)(v >> 32)) << 32);
-}
-
-struct QuadAnswer
-{
-  uint32_t bit; // filter bit of the probe
-  uint32_t lr;  // set bits below it inside its bucket
-  uint32_t id;  // ID slot min(lr, 12) of the bucket
-  uint32_t rel; // bucket's relative rank (for the overflow table)
-};
-
-// Round G: `piece` is this lane's 16 bytes of the bucket probed by quad lane G,
-// `off` this lane's OWN bit offset (lane G's is broadcast).  Every lane of the
-// quad computes lane G's answer; lane G keeps it.
-template<int G>
-__device__ inline QuadAnswer
-quad_answer(const uint4& piece, uint32_t off, uint32_t quad_base)
-{
-  const uint32_t o = quad_bcast<G>(off);
-  // header words live in quad lane 0: {rel, bitmap lo, bitmap hi, ids[0]}
-  const uint64_t bm = (uint64_t)quad_bcast<0>(piece.y) | ((uint64_t)quad_bcast<0>(piece.z) << 32);
-  QuadAnswer a;
-  a.rel = quad_bcast<0>(piece.x);
-  a.bit = (uint32_t)((bm >> o) & 1ull);
-  a.lr = grp_local_rank(bm, o);
-  const uint32_t slot = 3u + min(a.lr, GRP_BUCKET_IDS - 1u); // dword index inside the bucket
-  const uint32_t comp = slot & 3u;
-  const uint32_t word = (comp == 0u) ? piece.x : (comp == 1u) ? piece.y : (comp == 2u) ? piece.z : piece.w;
-  a.id = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((quad_base + (slot >> 2)) << 2), (int)word);
-  return a;
-}
-
-// ---- query -------------------------------------------------------------------------
-
-// per-tile count table in LDS: open addressing, key = ID (0 = empty).  An
-// insert is only attempted while fewer than `limit` distinct IDs are stored
-// (limit <= capacity - THREADS*H - 1, so concurrent claims can never fill the
-// table and probing always terminates); otherwise the tile is flagged and
-// recomputed by the full-capacity launch.
-__device__ inline void
-hist_add(uint32_t* keys, uint32_t* cnts, uint32_t mask, uint32_t id, uint32_t* sDistinct, uint32_t limit, uint32_t* sOverflow)
-{
-  if (*reinterpret_cast<volatile uint32_t*>(sDistinct) >= limit) {
-    *sOverflow = 1u;
-    return;
-  }
-  uint32_t slot = (id * 2654435761u) & mask;
-  for (;;) {
-    uint32_t old = atomicCAS(&keys[slot], 0u, id);
-    if (old == 0u) {
-      atomicAdd(sDistinct, 1u);
-    }
-    if (old == 0u || old == id) {
-      atomicAdd(&cnts[slot], 1u);
-      return;
-    }
-    slot = (slot + 1u) & mask;
-  }
-}
-
-// (count, id) ordering of calc_num_assigned_tiles :607-615: larger count wins,
-// equal counts -> smaller id (std::map ascending + strict '>')
-__device__ inline bool
-better(uint32_t c, uint32_t id, uint32_t bc, uint32_t bid)
-{
-  return (c > bc) || (c == bc && c != 0u && id < bid);
-}
-
-// WT > 0: every seed has weight WT (make_seed_pattern's seeds do) and the care
-// loop is fully unrolled; WT == 0: run-time weights
-template<int WT>
-__device__ inline uint64_t
-seed_hash_t(const ulonglong2* sTab, const DevSeeds* __restrict__ sd, uint32_t s, uint64_t w)
-{
-  if constexpr (WT == 0) {
-    return seed_hash(sTab, sd, s, w);
-  } else {
-    uint64_t fwd = 0, rev = 0;
-    const ulonglong2* t = sTab + (size_t)s * WT * 4u;
-#pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)WT; ++i) {
-      const uint32_t b = (uint32_t)(w >> sd->shift[s][i]) & 3u;
-      const ulonglong2 e = t[i * 4u + b];
-      fwd ^= e.x;
-      rev ^= e.y;
-    }
-    return fwd + rev;
-  }
-}
-
-#define GRP_TILE_FLAGGED 0xFFFFFFFFu
-
-// Stores / loads that are coherent across the XCDs' L2s inside one launch (agent scope,
-// "sc1": written through to / read from the memory side).  The streaming window uses
-// them for everything one workgroup hands to another; with them the hand-over needs no
-// device-scope fence (whose L2 write-back + invalidate per workgroup costs the query
-// kernel 5x, measured).
-__device__ inline void
-store_coherent(unsigned long long* p, unsigned long long v)
-{
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ inline unsigned long long
-load_coherent(const unsigned long long* p)
-{
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-static_assert(sizeof(grp_tile_summary) == 24 && sizeof(grp_id_count) == 8, "coherent copies move these as 64-bit words");
-
-// Streaming window (grp_classify_stream_*): persistent k_query<.., true> workgroups draw
-// the window's tiles in order; the workgroup that finishes the LAST tile of a read takes
-// that read's decision on the spot (first wave, register-resident state: a few
-// microseconds) and publishes it in mapped host memory, so the host commits reads while
-// the same launch is still working on later ones.  An abort (an insert made the rest of
-// the window stale) parks the tile dispenser: the launch ends as soon as the resident
-// tiles are done.
-// (Measured alternatives: a decision by one lane walking LDS arrays keeps a 141-VGPR wave
-// slot for ~100 us per read and costs the query kernel 10 %; resident decision waves in a
-// second kernel do not fit beside 3 query workgroups per CU — they either displace one
-// (-20 %) or starve until the launch ends.)
-struct DevStreamCtl
-{
-  uint32_t first = 0;                    // batch index of the window's first read
-  uint32_t* tiles_done = nullptr;        // [reads of the window] finished tiles, zeroed before the launch
-  uint32_t* abort = nullptr;             // device memory: what every workgroup tests
-  const uint32_t* abort_host = nullptr;  // mapped host memory: raised by the host, relayed by every 64th workgroup
-  grp_read_decision* dec = nullptr;      // mapped host memory [reads]; .pad = 1 once the record is complete
-  uint32_t* next_tile = nullptr;         // tile dispenser of the persistent workgroups; >= n_tiles: stop
-  uint32_t n_tiles = 0;
-  unsigned long long* executed = nullptr; // probes of the tiles that were processed
-  grp_decide_params dp{};
-  uint32_t* g_ids = nullptr;             // per-tile results (inspection) / scratch of long reads
-  uint8_t* g_asg = nullptr;
-  uint64_t* g_scratch = nullptr;
-};
-
-// reads of up to this many tiles are decided inside the streaming launch (37 bytes of the
-// idle count-table area per tile: 9.5 KB of the >= 16 KB the small geometry owns)
-constexpr uint32_t STREAM_LDS_TILES = 256;
-
-// ---- wave-register state for the decision core (csrc/host/gr_tiles_core.hpp) -------
-// Tile i of the read lives in lane i (reads of up to 64 tiles); every access is a
-// v_readlane / v_writelane with a wave-uniform index, so the passes run as scalar code
-// executed by the whole wave in lockstep.
-__device__ inline uint32_t
-lane_get(uint32_t v, size_t i)
-{
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i);
-}
-
-// v_writelane by hand (this compiler has no builtin for it): value and index are
-// wave-uniform, every lane executes — a compare and a select
-__device__ inline uint32_t
-lane_set(uint32_t v, size_t i, uint32_t reg)
-{
-  return (__lane_id() == (uint32_t)i) ? v : reg;
-}
-
-struct LaneState
-{
-  uint32_t v_top_id = 0, v_top_count = 0, v_list_n = 0, v_list_off = 0, v_hits = 0, v_misses = 0;
-  uint32_t v_id = 0, v_asg = 0, v_lo = 0, v_hi = 0;
-  const grp_id_count* lists = nullptr;
-
-  __device__ uint32_t top_id(size_t i) const { return lane_get(v_top_id, i); }
-  __device__ uint32_t top_count(size_t i) const { return lane_get(v_top_count, i); }
-  __device__ uint32_t list_n(size_t i) const { return lane_get(v_list_n, i); }
-  __device__ uint32_t list_off(size_t i) const { return lane_get(v_list_off, i); }
-  __device__ uint32_t hits(size_t i) const { return lane_get(v_hits, i); }
-  __device__ uint32_t misses(size_t i) const { return lane_get(v_misses, i); }
-  __device__ grp_id_count list_entry(size_t k) const { return gr::core::load_list_entry(lists + k); }
-  __device__ uint32_t id(size_t i) const { return lane_get(v_id, i); }
-  __device__ void set_id(size_t i, uint32_t v) { v_id = lane_set(v, i, v_id); }
-  __device__ uint32_t asg(size_t i) const { return lane_get(v_asg, i); }
-  __device__ void set_asg(size_t i, uint32_t v) { v_asg = lane_set(v, i, v_asg); }
-  __device__ uint64_t scr(size_t i) const { return (uint64_t)lane_get(v_lo, i) | ((uint64_t)lane_get(v_hi, i) << 32); }
-  __device__ void set_scr(size_t i, uint64_t v)
-  {
-    v_lo = lane_set((uint32_t)v, i, v_lo);
-    v_hi = lane_set((uint32_t)(v >> 32), i, v_hi);
-  }
-  __device__ void load(const grp_tile_summary& t)
-  {
-    v_top_id = t.top_id;
-    v_top_count = t.top_count;
-    v_list_n = t.list_n;
-    v_list_off = t.list_off;
-    v_hits = t.hits;
-    v_misses = t.misses;
-  }
-};
-constexpr uint32_t LANE_TILES = 64;
-
-// One wave (all 64 lanes), read `rj` of a streaming window complete (tiles [a, a+n) of the
-// window): the decision, published to the host.  Summaries and lists were written by other
-// workgroups during this launch: coherent loads.  `lds` / cap_tiles: work space for reads
-// of more than 64 tiles (the idle count-table area of the workgroup).
-__device__ inline void
-stream_decide(const DevStreamCtl& sc, uint32_t rj, uint64_t a, uint32_t n, const grp_tile_summary* tiles, const grp_id_count* lists, uint64_t lists_cap, uint32_t* lds, uint32_t cap_tiles)
-{
-  const uint32_t lane = threadIdx.x;
-  grp_read_decision d{};
-  auto fetch = [&](uint32_t i) {
-    union
-    {
-      unsigned long long w[3];
-      grp_tile_summary t;
-    } u;
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(tiles + a + i);
-    u.w[0] = load_coherent(src);
-    u.w[1] = load_coherent(src + 1);
-    u.w[2] = load_coherent(src + 2);
-    return u.t;
-  };
-  if (n <= LANE_TILES) {
-    LaneState st;
-    st.lists = lists;
-    bool bad = false;
-    if (lane < n) {
-      const grp_tile_summary t = fetch(lane);
-      st.load(t);
-      bad = t.list_n == GRP_TILE_FLAGGED || (uint64_t)t.list_off + t.list_n > lists_cap;
-    }
-    if (__ballot(bad) == 0ull) { // else kind stays 0: the host takes this read through the synchronous path
-      gr::core::decide(sc.dp.threshold, sc.dp.unassigned_min, sc.dp.assigned_max, (size_t)n, st, d);
-      if (lane < n) {
-        sc.g_ids[a + lane] = st.v_id;
-        sc.g_asg[a + lane] = (uint8_t)st.v_asg;
-      }
-    }
-  } else if (n <= cap_tiles) {
-    uint64_t* sScratch = reinterpret_cast<uint64_t*>(lds);
-    grp_tile_summary* sTiles = reinterpret_cast<grp_tile_summary*>(sScratch + cap_tiles);
-    uint32_t* sIds = reinterpret_cast<uint32_t*>(sTiles + cap_tiles);
-    uint8_t* sAsg = reinterpret_cast<uint8_t*>(sIds + cap_tiles);
-    bool bad = false;
-    for (uint32_t i = lane; i < n; i += 64u) {
-      const grp_tile_summary t = fetch(i);
-      sTiles[i] = t;
-      bad = bad || t.list_n == GRP_TILE_FLAGGED || (uint64_t)t.list_off + t.list_n > lists_cap;
-    }
-    const bool redo = __ballot(bad) != 0ull;
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0 && !redo) {
-      gr::core::decide(sc.dp.threshold, sc.dp.unassigned_min, sc.dp.assigned_max, (size_t)n, sTiles, lists, sIds, sAsg, sScratch, d);
-      for (uint32_t i = 0; i < n; ++i) {
-        sc.g_ids[a + i] = sIds[i];
-        sc.g_asg[a + i] = sAsg[i];
-      }
-    }
-  } // longer still: synchronous path (kind stays 0)
-  if (lane == 0) {
-    // The record goes to host memory with system-scope stores (no L2 involved); the flag
-    // follows once they are acknowledged.  No fence: a system-scope release would write
-    // back and invalidate the whole L2 once per read.
-    unsigned long long* o = reinterpret_cast<unsigned long long*>(sc.dec + rj);
-    __hip_atomic_store(o, (unsigned long long)d.kind | ((unsigned long long)d.num_tiles << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(o + 1, (unsigned long long)d.num_assigned | ((unsigned long long)d.trim_start << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(o + 2, (unsigned long long)d.trim_end | ((unsigned long long)d.hits << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(reinterpret_cast<uint32_t*>(o + 3), d.misses, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_s_waitcnt(0);
-    __hip_atomic_store(reinterpret_cast<uint32_t*>(o + 3) + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-template<int H, int FR, int WT, bool ST>
-__global__ void __launch_bounds__(THREADS)
-k_query(DevFilter f,
-        DevReads rd,
-        const DevSeeds* __restrict__ sd,
-        uint32_t tile_len,
-        uint64_t tile_begin,
-        const uint32_t* __restrict__ tile_idx, // NULL: tile = tile_begin + blockIdx.x
-        uint32_t hist_cap,
-        uint32_t distinct_limit,
-        uint32_t list_cap_lds,
-        grp_tile_summary* __restrict__ tiles_out,
-        grp_id_count* __restrict__ lists_out,
-        uint64_t lists_cap,
-        unsigned long long* __restrict__ ctr,
-        uint32_t* __restrict__ flagged_out, // indices of flagged tiles (NULL in the redo launch)
-        uint32_t flagged_cap,
-        uint32_t direct_stride, // != 0: tile i owns lists_out[i*stride ..) (no arena, no counters:
-                                // small windows write straight into mapped host memory)
-        DevStreamCtl sc)        // ST only
-{
-  extern __shared__ uint4 smem4[];
-  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
-  uint32_t* sKeys = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
-  uint32_t* sCnts = sKeys + hist_cap;
-  grp_id_count* sList = reinterpret_cast<grp_id_count*>(sCnts + hist_cap);
-  uint32_t* sBases = reinterpret_cast<uint32_t*>(sList + list_cap_lds);
-  __shared__ uint32_t sListN, sDistinct, sOverflow, sListOff;
-  __shared__ uint32_t sRed[2 * (THREADS / 64)];
-  __shared__ uint32_t sBest[2 * (THREADS / 64)];
-  __shared__ uint32_t sTile;
-
-  load_tab(sTab, sd);
-  // ST: persistent workgroups (one launch fills the device once) draw tile after tile
-  // from a dispenser, in window order; an abort parks the dispenser beyond the last
-  // tile, so a stale window ends as soon as the resident tiles are done.  The next
-  // index is fetched while the current tile is being processed.
-  constexpr uint32_t STREAM_STOP = 0x40000000u;
-  uint32_t nxt = 0;
-  uint32_t stop = 0; // thread 0: the device abort flag, read while the previous tile was finishing
-  if constexpr (ST) {
-    if (threadIdx.x == 0) {
-      // a window that was aborted before it started (the host read an insert out of the
-      // previous launch) must not begin a single tile: every workgroup asks the host
-      // flag once, here — one PCIe read per workgroup and launch
-      if (__hip_atomic_load(sc.abort_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
-        atomicMax(sc.next_tile, STREAM_STOP);
-        __hip_atomic_store(sc.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        stop = 1u;
-      }
-      nxt = atomicAdd(sc.next_tile, 1u);
-    }
-  }
-  for (;;) {
-  uint32_t out_idx;
-  if constexpr (ST) {
-    if (threadIdx.x == 0) {
-      sTile = stop ? STREAM_STOP : nxt;
-    }
-    __syncthreads();
-    out_idx = sTile;
-    if (out_idx >= sc.n_tiles) {
-      return;
-    }
-    if (tile_idx) { // striped window: this rank's tiles only
-      out_idx = tile_idx[out_idx];
-    }
-    if (threadIdx.x == 0) {
-      nxt = atomicAdd(sc.next_tile, 1u);
-      if (blockIdx.x < 32u) { // relays of the host's abort flag (a PCIe read: only a few workgroups pay for it)
-        if (__hip_atomic_load(sc.abort_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
-          atomicMax(sc.next_tile, STREAM_STOP);
-          __hip_atomic_store(sc.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-    }
-  } else {
-    out_idx = tile_idx ? tile_idx[blockIdx.x] : blockIdx.x;
-  }
-  const uint64_t t = tile_begin + out_idx;
-  const uint32_t r = rd.tile_read[t];
-  const uint32_t ti = (uint32_t)(t - rd.tile0[r]);
-  const uint32_t len = rd.len[r];
-  const uint32_t k = sd->k;
-  // tile string = seq.substr(ti*tile, tile + k - 1)   (read_hashing.cpp:44-45)
-  const uint32_t start = ti * tile_len;
-  const uint32_t Lp = min(tile_len + k - 1u, len - start);
-  const uint32_t frames = (Lp >= k) ? (Lp - k + 1u) : 0u;
-
-  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[r], len, start, Lp);
-  for (uint32_t i = threadIdx.x; i < hist_cap; i += THREADS) {
-    sKeys[i] = 0u;
-    sCnts[i] = 0u;
-  }
-  if (threadIdx.x == 0) {
-    sListN = 0;
-    sDistinct = 0;
-    sOverflow = 0;
-  }
-  __syncthreads();
-  if constexpr (ST) {
-    if (threadIdx.x == 0) {
-      atomicAdd(sc.executed, (unsigned long long)frames * H);
-    }
-  }
-
-  const uint32_t hmask = hist_cap - 1u;
-  uint32_t n_hit = 0, n_miss = 0;
-  uint32_t last[H];
-#pragma unroll
-  for (int s = 0; s < H; ++s) {
-    // a seed that can no longer roll keeps its last value
-    // (multiLensfrHashIterator.hpp:49-68): its frame index is clamped
-    last[s] = Lp - sd->span[s];
-  }
-  const uint32_t sub = threadIdx.x & 3u;         // my 16-byte piece of a bucket
-  const uint32_t quad_base = (threadIdx.x & 63u) & ~3u;
-
-  // Every lane owns FR frames per pass; the 64-byte bucket of each probe is
-  // read by the lane's quad with ONE coalesced access (4 x 16 B) and the bitmap /
-  // ID slot are exchanged inside the quad with DPP / bpermute.  Random 16-byte
-  // loads issued per lane run at ~27 G/s on MI355X, quad-coalesced bucket reads
-  // at ~48 G buckets/s (tools/gather_bench.hip modes 7 / 10).
-  const uint32_t passes = (frames + THREADS * FR - 1u) / (THREADS * FR);
-  for (uint32_t pass = 0; pass < passes; ++pass) {
-    uint64_t bk[FR][H];
-    uint32_t off[FR][H];
-    uint4 piece[FR][H][4];
-    // 1) hashes -> positions.  Frames past the end recompute the last frame: all
-    //    lanes stay active (the quad exchange needs them) and all addresses valid
-#pragma unroll
-    for (int j = 0; j < FR; ++j) {
-      const uint32_t fr = min((pass * FR + j) * THREADS + threadIdx.x, frames - 1u);
-#pragma unroll
-      for (int s = 0; s < H; ++s) {
-        const uint64_t hv = seed_hash_t<WT>(sTab, sd, s, window_at(sBases, boff + min(fr, last[s])));
-        const Probe p = grp_locate(f, hv);
-        bk[j][s] = p.b;
-        off[j][s] = p.off;
-      }
-    }
-    // 2) round g: the quad reads the bucket of its lane g's probe
-#pragma unroll
-    for (int j = 0; j < FR; ++j) {
-#pragma unroll
-      for (int s = 0; s < H; ++s) {
-        piece[j][s][0] = f.buckets[quad_bcast64<0>(bk[j][s]) * 4 + sub];
-        piece[j][s][1] = f.buckets[quad_bcast64<1>(bk[j][s]) * 4 + sub];
-        piece[j][s][2] = f.buckets[quad_bcast64<2>(bk[j][s]) * 4 + sub];
-        piece[j][s][3] = f.buckets[quad_bcast64<3>(bk[j][s]) * 4 + sub];
-      }
-    }
-    // 3) bit test + ID slot, exchanged inside the quad; per-frame ID set -> tile count table
-#pragma unroll
-    for (int j = 0; j < FR; ++j) {
-      const bool live = ((pass * FR + j) * THREADS + threadIdx.x) < frames;
-      bool all = live;
-      uint32_t idv[H];
-#pragma unroll
-      for (int s = 0; s < H; ++s) {
-        QuadAnswer a0 = quad_answer<0>(piece[j][s][0], off[j][s], quad_base);
-        QuadAnswer a1 = quad_answer<1>(piece[j][s][1], off[j][s], quad_base);
-        QuadAnswer a2 = quad_answer<2>(piece[j][s][2], off[j][s], quad_base);
-        QuadAnswer a3 = quad_answer<3>(piece[j][s][3], off[j][s], quad_base);
-        const QuadAnswer mine = (sub == 0) ? a0 : (sub == 1) ? a1 : (sub == 2) ? a2 : a3;
-        all = all && mine.bit; // atRank (MIBloomFilter.hpp:465-476)
-        uint32_t d = mine.id;  // getData (:614-621)
-        if (mine.lr >= GRP_BUCKET_IDS && live) { // 14th.. set bit of its bucket: rare side table
-          d = grp_ovf_get(f, f.super[bk[j][s] >> GRP_SUPER_SHIFT] + mine.rel + mine.lr);
-        }
-        idv[s] = d;
-      }
-      if (!all) {
-        continue;
-      }
-      uint32_t ids[H];
-#pragma unroll
-      for (int s = 0; s < H; ++s) {
-        const uint32_t d = idv[s];
-        // saturation bit stripped exactly as goldrush_path.cpp:573-594
-        const uint32_t id = (d > 0x80000000u) ? (d & 0x7FFFFFFFu) : d;
-        if (id == 0u) {
-          ++n_miss;
-        } else {
-          ++n_hit;
-        }
-        bool dup = false;
-#pragma unroll
-        for (int u = 0; u < s; ++u) {
-          dup = dup || (ids[u] == id);
-        }
-        ids[s] = id;
-        if (id != 0u && !dup) {
-          hist_add(sKeys, sCnts, hmask, id, &sDistinct, distinct_limit, &sOverflow);
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // top ID + count>2 list
-  uint32_t bc = 0, bid = 0;
-  for (uint32_t i = threadIdx.x; i < hist_cap; i += THREADS) {
-    uint32_t key = sKeys[i];
-    if (key != 0u) {
-      uint32_t c = sCnts[i];
-      if (better(c, key, bc, bid)) {
-        bc = c;
-        bid = key;
-      }
-      if (c > 2u) {
-        uint32_t li = atomicAdd(&sListN, 1u);
-        if (li < list_cap_lds) {
-          sList[li].id = key;
-          sList[li].count = c;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    uint32_t oc = __shfl_xor(bc, o, 64);
-    uint32_t oid = __shfl_xor(bid, o, 64);
-    if (better(oc, oid, bc, bid)) {
-      bc = oc;
-      bid = oid;
-    }
-  }
-  n_hit = wave_sum(n_hit);
-  n_miss = wave_sum(n_miss);
-  const uint32_t wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-    sBest[2 * wave] = bc;
-    sBest[2 * wave + 1] = bid;
-    sRed[2 * wave] = n_hit;
-    sRed[2 * wave + 1] = n_miss;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t hsum = 0, msum = 0;
-    for (int w = 0; w < THREADS / 64; ++w) {
-      if (better(sBest[2 * w], sBest[2 * w + 1], bc, bid)) {
-        bc = sBest[2 * w];
-        bid = sBest[2 * w + 1];
-      }
-      hsum += sRed[2 * w];
-      msum += sRed[2 * w + 1];
-    }
-    const uint32_t n = sListN;
-    const bool flagged = sOverflow != 0u || n > list_cap_lds || (direct_stride != 0u && n > direct_stride);
-    uint64_t lo = 0;
-    if (direct_stride != 0u) {
-      lo = (uint64_t)out_idx * direct_stride;
-    } else if (n && !flagged) {
-      lo = atomicAdd(&ctr[3], (unsigned long long)n);
-    }
-    sListOff = (uint32_t)lo;
-    if (flagged) {
-      sListN = 0; // nothing is copied out; the full-capacity launch redoes this tile
-      if (direct_stride == 0u) {
-        const unsigned long long fi = atomicAdd(&ctr[4], 1ull);
-        if (flagged_out && fi < flagged_cap) {
-          flagged_out[fi] = out_idx;
-        }
-      }
-    }
-    grp_tile_summary ts;
-    ts.top_id = bid;
-    ts.top_count = bc;
-    ts.list_off = (uint32_t)lo;
-    ts.list_n = flagged ? GRP_TILE_FLAGGED : n;
-    ts.hits = hsum;
-    ts.misses = msum;
-    if constexpr (ST) {
-      unsigned long long* dst = reinterpret_cast<unsigned long long*>(tiles_out + out_idx);
-      store_coherent(dst, (unsigned long long)ts.top_id | ((unsigned long long)ts.top_count << 32));
-      store_coherent(dst + 1, (unsigned long long)ts.list_off | ((unsigned long long)ts.list_n << 32));
-      store_coherent(dst + 2, (unsigned long long)ts.hits | ((unsigned long long)ts.misses << 32));
-    } else {
-      tiles_out[out_idx] = ts;
-    }
-  }
-  __syncthreads();
-  const uint32_t n = sListN;
-  const uint64_t lo = sListOff;
-  for (uint32_t i = threadIdx.x; i < n; i += THREADS) {
-    if (lo + i < lists_cap) {
-      if constexpr (ST) {
-        store_coherent(reinterpret_cast<unsigned long long*>(lists_out + lo + i), (unsigned long long)sList[i].id | ((unsigned long long)sList[i].count << 32));
-      } else {
-        lists_out[lo + i] = sList[i];
-      }
-    }
-  }
-  if constexpr (ST) {
-    // "last block" hand-over without device-scope fences: the summaries and lists went
-    // out as coherent stores; once they are acknowledged (vmcnt = 0 in every wave, then
-    // the barrier) one lane counts the tile with a device-scope atomic.  The workgroup
-    // that sees the read complete reads them back with coherent loads.
-    if (threadIdx.x == 0) { // the prefetched tile index is only used if the window is still live
-      stop = __hip_atomic_load(sc.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    const uint32_t rj = r - sc.first;
-    const uint32_t nt_read = (uint32_t)(rd.tile0[r + 1] - rd.tile0[r]);
-    if (threadIdx.x == 0) {
-      sTile = (atomicAdd(&sc.tiles_done[rj], 1u) + 1u == nt_read) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (sTile != 0u && threadIdx.x < 64u) {
-      stream_decide(sc, rj, rd.tile0[r] - tile_begin, nt_read, tiles_out, lists_out, lists_cap, reinterpret_cast<uint32_t*>(sKeys), min(STREAM_LDS_TILES, hist_cap * 8u / 40u));
-    }
-    // (the barrier at the top of the loop keeps sTile / the count-table area untouched
-    // until the deciding wave is back)
-  } else {
-    return;
-  }
-  } // next tile (ST)
-}
-
-// ---- read decision --------------------------------------------------------------
-
-// threshold + smoothing passes + flank test + decision of every read of a window (the
-// shared host/device core, csrc/host/gr_tiles_core.hpp), one WAVE per read.
-//   reads of up to 64 tiles: tile i sits in lane i, the passes run as wave-uniform scalar
-//     code on v_readlane / v_writelane (LaneState) — no LDS, no divergence
-//   longer reads: lane 0 walks a slice of a global scratch area
-// History (profiles/): 64 reads in the lanes of one wave serialised on divergence
-// (~300 us per window), one lane per wave over LDS arrays ~120 us, this form ~10 us.
-constexpr int DECIDE_THREADS = 64;
-
-__global__ void __launch_bounds__(DECIDE_THREADS)
-k_decide(DevReads rd,
-         uint32_t first,
-         uint32_t count,
-         grp_decide_params dp,
-         const grp_tile_summary* __restrict__ tiles,
-         const grp_id_count* __restrict__ lists,
-         uint64_t lists_cap,
-         uint32_t* __restrict__ g_ids,
-         uint8_t* __restrict__ g_asg,
-         uint64_t* __restrict__ g_scratch,
-         grp_read_decision* __restrict__ out)
-{
-  const uint32_t lane = threadIdx.x;
-  const uint32_t j = blockIdx.x;
-  const uint64_t t_base = rd.tile0[first];
-  const uint64_t a = rd.tile0[first + j] - t_base;
-  const uint64_t n = rd.tile0[first + j + 1] - rd.tile0[first + j];
-  grp_read_decision d{};
-  if (n <= LANE_TILES) {
-    LaneState st;
-    st.lists = lists;
-    bool bad = false;
-    if (lane < n) {
-      const grp_tile_summary t = tiles[a + lane];
-      st.load(t);
-      // decided again after the flagged tiles have been redone / the list arena enlarged
-      bad = t.list_n == GRP_TILE_FLAGGED || (uint64_t)t.list_off + t.list_n > lists_cap;
-    }
-    if (__ballot(bad) == 0ull) {
-      gr::core::decide(dp.threshold, dp.unassigned_min, dp.assigned_max, (size_t)n, st, d);
-      if (lane < n) { // keep the per-tile result inspectable (grp_debug_tile_states)
-        g_ids[a + lane] = st.v_id;
-        g_asg[a + lane] = (uint8_t)st.v_asg;
-      }
-    }
-    if (lane == 0) {
-      out[j] = d;
-    }
-  } else {
-    if (lane != 0) {
-      return;
-    }
-    const grp_tile_summary* my_tiles = tiles + a;
-    bool redo = false;
-    for (uint64_t i = 0; i < n; ++i) {
-      redo = redo || my_tiles[i].list_n == GRP_TILE_FLAGGED || (uint64_t)my_tiles[i].list_off + my_tiles[i].list_n > lists_cap;
-    }
-    if (!redo) {
-      gr::core::decide(dp.threshold, dp.unassigned_min, dp.assigned_max, (size_t)n, my_tiles, lists, g_ids + a, g_asg + a, g_scratch + a, d);
-    }
-    out[j] = d;
-  }
-}
-
-// ---- insert ------------------------------------------------------------------------
-
-// claim `key` in the per-call dedup set; true for exactly one caller per key.
-// Entries tagged with an older epoch count as empty (no clearing between calls).
-__device__ inline bool
-dedup_claim(unsigned long long* table, uint64_t cap_mask, unsigned long long key, unsigned long long epoch_tag)
-{
-  uint64_t slot = (key * 0x9E3779B97F4A7C15ULL) >> 20 & cap_mask;
-  for (;;) {
-    unsigned long long cur = table[slot];
-    for (;;) {
-      if (cur == key) {
-        return false;
-      }
-      if ((cur & 0xFFFFFF0000000000ULL) == epoch_tag) {
-        break; // occupied by another rank of this call -> next slot
-      }
-      unsigned long long prev = atomicCAS(&table[slot], cur, key);
-      if (prev == cur) {
-        return true;
-      }
-      cur = prev;
-    }
-    slot = (slot + 1) & cap_mask;
-  }
-}
-
-template<int H>
-__global__ void __launch_bounds__(THREADS)
-k_insert(DevFilter f,
-         DevReads rd,
-         const DevSeeds* __restrict__ sd,
-         uint32_t tile_len,
-         uint32_t read_idx,
-         uint32_t tile_start,
-         uint32_t id,
-         unsigned long long* __restrict__ dedup,
-         uint64_t dedup_mask,
-         unsigned long long epoch_tag)
-{
-  extern __shared__ uint4 smem4[];
-  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
-  uint32_t* sBases = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
-
-  const uint32_t r = read_idx;
-  // one frame per thread: `parts` workgroups share a tile
-  const uint32_t parts = (tile_len + THREADS - 1) / THREADS;
-  const uint32_t ti = tile_start + blockIdx.x / parts;
-  const uint32_t part = blockIdx.x % parts;
-  const uint32_t len = rd.len[r];
-  const uint32_t k = sd->k;
-  const uint32_t start = ti * tile_len;
-  const uint32_t Lp = min(tile_len + k - 1u, len - start);
-  const uint32_t frames = (Lp >= k) ? (Lp - k + 1u) : 0u;
-
-  load_tab(sTab, sd);
-  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[r], len, start, Lp);
-  __syncthreads();
-
-  for (uint32_t fr = part * THREADS + threadIdx.x; fr < frames; fr += THREADS * parts) {
-    Probe pr[H];
-    uint4 hd[H];
-#pragma unroll
-    for (int s = 0; s < H; ++s) {
-      const uint32_t fs = min(fr, Lp - sd->span[s]);
-      pr[s] = grp_locate(f, seed_hash(sTab, sd, s, window_at(sBases, boff + fs)));
-    }
-#pragma unroll
-    for (int s = 0; s < H; ++s) {
-      hd[s] = f.buckets[pr[s].b * 4];
-    }
-#pragma unroll
-    for (int s = 0; s < H; ++s) {
-      // getRankPos (MIBloomFilter.hpp:488-491): rank only, the bit is not tested
-      const uint32_t lr = grp_local_rank(grp_bitmap(hd[s]), pr[s].off);
-      const uint64_t rank = f.super[pr[s].b >> GRP_SUPER_SHIFT] + hd[s].x + lr;
-      if (rank >= f.pop || !((grp_bitmap(hd[s]) >> pr[s].off) & 1ull)) {
-        // an unset bit has no slot of its own; unreachable for reads that went
-        // through the fill (it covers a superset of all tile positions)
-        continue;
-      }
-      if (dedup_claim(dedup, dedup_mask, epoch_tag | rank, epoch_tag)) {
-        // MIBFConstructSupport.hpp:274-282 ; the only writer of this rank in this call
-        const uint32_t count = f.counts[rank] + 1u;
-        f.counts[rank] = count;
-        const uint32_t random_num = (uint32_t)(rank ^ (uint64_t)id) % count;
-        if (random_num == count - 1u) {
-          uint32_t* slot = (lr < GRP_BUCKET_IDS) ? &reinterpret_cast<uint32_t*>(f.buckets)[pr[s].b * 16 + 3 + lr] : nullptr;
-          const uint32_t old = slot ? *slot : grp_ovf_get(f, rank);
-          // setData (MIBloomFilter.hpp:593-602): keep a set saturation bit
-          const uint32_t nv = (old > 0x80000000u) ? (id | 0x80000000u) : id;
-          if (slot) {
-            *slot = nv;
-          } else {
-            grp_ovf_put(f, rank, nv);
-          }
-        }
-      }
-    }
-  }
-}
-
-// ---- whole-read insert (all ID blocks of a read in two launches) ------------------
-//
-// process_read inserts a read as consecutive blocks of `block` tiles, one
-// insertMIBF call (= one dedup scope, one ID) per block, in order
-// (goldrush_path.cpp:982-990, 1040-1051).  k_insert_collect gathers, for every
-// distinct rank of the read, the SET of blocks that touch it (bit j = block j);
-// k_insert_apply then replays the blocks in ascending order per rank:
-// c = ++count; if (uint32(rank ^ id_j) % c == c-1) id = id_j — identical to the
-// sequential calls because different ranks never interact.
-struct InsertTable
-{
-  unsigned long long* keys;  // rank + 1, 0 = free (left clean by k_insert_apply)
-  unsigned long long* masks; // blocks touching the rank
-  unsigned long long* locs;  // dword index of the ID slot, or ~0 for the overflow table
-  uint32_t* slots;           // claimed slots, in claim order
-  uint32_t* counter;         // [2], alternating per call
-  uint64_t cap_mask;
-};
-
-template<int H>
-__global__ void __launch_bounds__(THREADS)
-k_insert_collect(DevFilter f, DevReads rd, const DevSeeds* __restrict__ sd, uint32_t tile_len, uint32_t read_idx, uint32_t tile_start, uint32_t block_tiles, InsertTable tb, uint32_t parity)
-{
-  extern __shared__ uint4 smem4[];
-  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
-  uint32_t* sBases = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
-
-  const uint32_t parts = (tile_len + THREADS - 1) / THREADS;
-  const uint32_t tj = blockIdx.x / parts; // tile inside the inserted range
-  const uint32_t ti = tile_start + tj;
-  const uint32_t part = blockIdx.x % parts;
-  const unsigned long long block_bit = 1ull << (tj / block_tiles);
-  const uint32_t len = rd.len[read_idx];
-  const uint32_t k = sd->k;
-  const uint32_t start = ti * tile_len;
-  const uint32_t Lp = min(tile_len + k - 1u, len - start);
-  const uint32_t frames = (Lp >= k) ? (Lp - k + 1u) : 0u;
-
-  load_tab(sTab, sd);
-  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[read_idx], len, start, Lp);
-  __syncthreads();
-
-  for (uint32_t fr = part * THREADS + threadIdx.x; fr < frames; fr += THREADS * parts) {
-    Probe pr[H];
-    uint4 hd[H];
-#pragma unroll
-    for (int s = 0; s < H; ++s) {
-      const uint32_t fs = min(fr, Lp - sd->span[s]);
-      pr[s] = grp_locate(f, seed_hash(sTab, sd, s, window_at(sBases, boff + fs)));
-    }
-#pragma unroll
-    for (int s = 0; s < H; ++s) {
-      hd[s] = f.buckets[pr[s].b * 4];
-    }
-#pragma unroll
-    for (int s = 0; s < H; ++s) {
-      const uint64_t bm = grp_bitmap(hd[s]);
-      const uint32_t lr = grp_local_rank(bm, pr[s].off);
-      const uint64_t rank = f.super[pr[s].b >> GRP_SUPER_SHIFT] + hd[s].x + lr;
-      if (rank >= f.pop || !((bm >> pr[s].off) & 1ull)) {
-        continue; // see k_insert
-      }
-      const unsigned long long key = rank + 1;
-      uint64_t slot = (key * 0x9E3779B97F4A7C15ULL) >> 20 & tb.cap_mask;
-      for (;;) {
-        unsigned long long cur = tb.keys[slot];
-        if (cur == 0) {
-          cur = atomicCAS(&tb.keys[slot], 0ull, key);
-          if (cur == 0) { // claimed: remember where the rank's ID lives
-            tb.locs[slot] = (lr < GRP_BUCKET_IDS) ? (unsigned long long)(pr[s].b * 16 + 3 + lr) : ~0ull;
-            tb.slots[atomicAdd(&tb.counter[parity], 1u)] = (uint32_t)slot;
-            cur = key;
-          }
-        }
-        if (cur == key) {
-          break;
-        }
-        slot = (slot + 1) & tb.cap_mask;
-      }
-      atomicOr(&tb.masks[slot], block_bit);
-    }
-  }
-}
-
-__global__ void __launch_bounds__(THREADS)
-k_insert_apply(DevFilter f, InsertTable tb, uint32_t parity, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset)
-{
-  const uint32_t n = tb.counter[parity];
-  const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
-  if (i == 0) {
-    tb.counter[parity ^ 1u] = 0; // the next call's counter
-  }
-  if (i >= n) {
-    return;
-  }
-  const uint32_t slot = tb.slots[i];
-  const uint64_t rank = tb.keys[slot] - 1;
-  unsigned long long mask = tb.masks[slot];
-  const unsigned long long loc = tb.locs[slot];
-  tb.keys[slot] = 0;
-  tb.masks[slot] = 0;
-  uint32_t count = f.counts[rank];
-  uint32_t new_id = 0;
-  bool write = false;
-  while (mask) {
-    const uint32_t j = (uint32_t)__ffsll((long long)mask) - 1u;
-    mask &= mask - 1;
-    // MIBFConstructSupport.hpp:274-282, block j's call
-    ++count;
-    const uint32_t id = first_id + (j * block_tiles + id_offset) / block_tiles;
-    if ((uint32_t)(rank ^ (uint64_t)id) % count == count - 1u) {
-      new_id = id;
-      write = true;
-    }
-  }
-  f.counts[rank] = count;
-  if (write) {
-    uint32_t* p = (loc != ~0ull) ? &reinterpret_cast<uint32_t*>(f.buckets)[loc] : nullptr;
-    const uint32_t old = p ? *p : grp_ovf_get(f, rank);
-    // setData (MIBloomFilter.hpp:593-602): keep a set saturation bit
-    const uint32_t nv = (old > 0x80000000u) ? (new_id | 0x80000000u) : new_id;
-    if (p) {
-      *p = nv;
-    } else {
-      grp_ovf_put(f, rank, nv);
-    }
-  }
-}
-
-// ---- inspection kernels ----------------------------------------------------------
-
-// buckets -> plain bit vector (out zeroed by the caller, 32-bit words)
-__global__ void
-k_export_bits(const uint4* __restrict__ buckets, uint64_t n_buckets, uint32_t W, uint32_t* __restrict__ out)
-{
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_buckets) {
-    return;
-  }
-  const uint64_t bm = grp_bitmap(buckets[b * 4]);
-  if (!bm) {
-    return;
-  }
-  const uint64_t s = b * W;
-  const uint64_t w = s >> 5;
-  const uint32_t sh = (uint32_t)(s & 31u);
-  atomicOr(&out[w], (uint32_t)(bm << sh));
-  const uint64_t rest = sh ? (bm >> (32u - sh)) : (bm >> 32) ;
-  if (sh) {
-    if ((uint32_t)rest) {
-      atomicOr(&out[w + 1], (uint32_t)rest);
-    }
-    if ((uint32_t)(rest >> 32)) {
-      atomicOr(&out[w + 2], (uint32_t)(rest >> 32));
-    }
-  } else if ((uint32_t)rest) {
-    atomicOr(&out[w + 1], (uint32_t)rest);
-  }
-}
-
-__global__ void
-k_rank_positions(DevFilter f, const uint64_t* __restrict__ pos, uint64_t n, uint8_t* __restrict__ bit, uint64_t* __restrict__ rank)
-{
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) {
-    return;
-  }
-  const uint64_t p = pos[i];
-  const uint64_t b = grp_div_w(p, f.w_magic);
-  const uint32_t off = (uint32_t)(p - b * f.W);
-  const uint4 hd = f.buckets[b * 4];
-  const uint64_t bm = grp_bitmap(hd);
-  bit[i] = (uint8_t)((bm >> off) & 1ull);
-  rank[i] = f.super[b >> GRP_SUPER_SHIFT] + hd.x + grp_local_rank(bm, off);
-}
-
-// ids / counts of ranks [first, first+n): one thread per bucket
-__global__ void
-k_export_ids(DevFilter f, uint64_t first, uint64_t n, uint32_t* __restrict__ ids, uint32_t* __restrict__ counts)
-{
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= f.n_buckets) {
-    return;
-  }
-  const uint4 hd = f.buckets[b * 4];
-  const uint32_t c = (uint32_t)__popcll(grp_bitmap(hd));
-  const uint64_t base = f.super[b >> GRP_SUPER_SHIFT] + hd.x;
-  for (uint32_t lr = 0; lr < c; ++lr) {
-    const uint64_t rank = base + lr;
-    if (rank >= first && rank < first + n) {
-      const uint32_t v = (lr < GRP_BUCKET_IDS) ? reinterpret_cast<const uint32_t*>(f.buckets)[b * 16 + 3 + lr] : grp_ovf_get(f, rank);
-      ids[rank - first] = v;
-      counts[rank - first] = f.counts[rank];
-    }
-  }
-}
-
-__global__ void
-k_import_ids(DevFilter f, uint64_t first, uint64_t n, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ counts)
-{
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= f.n_buckets) {
-    return;
-  }
-  const uint4 hd = f.buckets[b * 4];
-  const uint32_t c = (uint32_t)__popcll(grp_bitmap(hd));
-  const uint64_t base = f.super[b >> GRP_SUPER_SHIFT] + hd.x;
-  for (uint32_t lr = 0; lr < c; ++lr) {
-    const uint64_t rank = base + lr;
-    if (rank >= first && rank < first + n) {
-      if (ids) {
-        if (lr < GRP_BUCKET_IDS) {
-          reinterpret_cast<uint32_t*>(f.buckets)[b * 16 + 3 + lr] = ids[rank - first];
-        } else {
-          grp_ovf_put(f, rank, ids[rank - first]);
-        }
-      }
-      if (counts) {
-        f.counts[rank] = counts[rank - first];
-      }
-    }
-  }
-}
-
-template<int H>
-__global__ void __launch_bounds__(THREADS)
-k_debug_tile_hashes(DevReads rd, const DevSeeds* __restrict__ sd, uint32_t tile_len, uint32_t read_idx, uint32_t tile_idx, uint64_t* __restrict__ out, uint64_t cap)
-{
-  extern __shared__ uint4 smem4[];
-  ulonglong2* sTab = reinterpret_cast<ulonglong2*>(smem4);
-  uint32_t* sBases = reinterpret_cast<uint32_t*>(sTab + H * sd->wmax * 4u);
-  const uint32_t len = rd.len[read_idx];
-  const uint32_t k = sd->k;
-  const uint32_t start = tile_idx * tile_len;
-  const uint32_t Lp = min(tile_len + k - 1u, len - start);
-  const uint32_t frames = (Lp >= k) ? (Lp - k + 1u) : 0u;
-  load_tab(sTab, sd);
-  const uint32_t boff = stage_bases(sBases, rd.packed, rd.word_off[read_idx], len, start, Lp);
-  __syncthreads();
-  for (uint32_t fr = threadIdx.x; fr < frames; fr += THREADS) {
-#pragma unroll
-    for (int s = 0; s < H; ++s) {
-      const uint32_t fs = min(fr, Lp - sd->span[s]);
-      uint64_t hv = seed_hash(sTab, sd, s, window_at(sBases, boff + fs));
-      uint64_t o = (uint64_t)fr * H + s;
-      if (o < cap) {
-        out[o] = hv;
-      }
-    }
-  }
-}
+#include "grp_kernels.inc"
 
 // ---------------------------------------------------------------------------
 // host side
