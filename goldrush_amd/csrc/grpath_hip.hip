@@ -112,6 +112,7 @@ struct grp_ctx
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
 
   uint64_t n_flagged_tiles = 0; // statistics
+  uint64_t n_direct_windows = 0, n_direct_fallbacks = 0, n_general_windows = 0, n_redo_launches = 0; // GRP_DEBUG_STATS
   uint64_t n_chunks = 0; // rank-build chunks
   uint64_t* d_super = nullptr;
   bool finalized = false;
@@ -204,7 +205,7 @@ set_err(const grp_ctx* ctx, int code, const char* fmt, ...)
 
 constexpr uint32_t FILL_CHUNK = 2048; // read positions per fill workgroup
 constexpr uint64_t LIST_PREFIX = 8192; // list entries copied back together with the tile summaries
-constexpr uint32_t SMALL_TILES = 256;  // windows up to this many tiles use the direct (zero-copy) path
+constexpr uint32_t SMALL_TILES = 512;  // windows up to this many tiles use the direct (zero-copy) path
 constexpr uint32_t SMALL_STRIDE = 32;  // list entries per tile in the direct path
 constexpr int THREADS = 256;
 
@@ -366,11 +367,19 @@ query_geom(const grp_ctx* c, bool full)
   const uint64_t max_ids = (uint64_t)tile * h;
   QueryGeom g;
   const uint32_t cap_full = next_pow2(max_ids + (uint64_t)THREADS * h + 2);
-  if (full || cap_full <= 2048) {
+  // 4096 entries hold every possible tile of the default geometry (tile 1000, h = 3: at
+  // most 3000 distinct IDs, limit 4096 - 768 - 1), cost nothing measurable against 2048
+  // (the kernel is not occupancy-bound) and spare repeat-rich tiles the flagged redo; 8192
+  // (h = 5 worst case) halves the kernel's rate, so larger geometries keep the redo.
+  static const uint32_t small_cap = [] { // developer hook
+    const char* e = getenv("GRP_SMALL_HIST");
+    return e ? (uint32_t)atoi(e) : 4096u;
+  }();
+  if (full || cap_full <= small_cap) {
     g.hist_cap = cap_full;
     g.list_cap_lds = (uint32_t)(max_ids / 3 + 1);
   } else {
-    g.hist_cap = 2048;
+    g.hist_cap = small_cap;
     g.list_cap_lds = 256;
   }
   g.distinct_limit = g.hist_cap - THREADS * h - 1;
@@ -602,6 +611,10 @@ grp_destroy(grp_ctx* c)
 {
   if (!c) {
     return;
+  }
+  if (getenv("GRP_DEBUG_STATS")) {
+    fprintf(stderr, "grp stats: direct windows %llu (fallbacks %llu), general windows %llu, redo launches %llu, flagged tiles %llu\n", (unsigned long long)c->n_direct_windows,
+            (unsigned long long)c->n_direct_fallbacks, (unsigned long long)c->n_general_windows, (unsigned long long)c->n_redo_launches, (unsigned long long)c->n_flagged_tiles);
   }
   if (c->stream2) {
     (void)hipStreamSynchronize(c->stream2);
@@ -1115,6 +1128,7 @@ enqueue_redo_flagged(grp_ctx* c, const grp_reads* r, uint64_t list_cap, QueryRun
 {
   q.flagged = c->q->h_qctr[4];
   c->n_flagged_tiles += q.flagged;
+  ++c->n_redo_launches;
   // continue the list arena where the first launch stopped
   uint64_t cursor[8] = { 0, 0, 0, c->q->h_qctr[3], 0, 0, 0, 0 };
   HIP_TRY(c, hipMemcpyAsync(c->q->d_qctr, cursor, sizeof(cursor), hipMemcpyHostToDevice, c->stream));
@@ -1192,6 +1206,7 @@ grp_query_tiles(grp_ctx* c,
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    ++c->n_direct_windows;
     bool any_flagged = false;
     uint64_t used = 0;
     for (uint64_t i = 0; i < nt; ++i) {
@@ -1231,6 +1246,7 @@ grp_query_tiles(grp_ctx* c,
       return GRP_OK;
     }
     // a tile needs the worst-case table or a longer list: take the general path
+    ++c->n_direct_fallbacks;
   }
   if (nt > c->h_tiles_cap) {
     if (c->h_tiles) {
@@ -1242,6 +1258,7 @@ grp_query_tiles(grp_ctx* c,
     HIP_TRY(c, hipHostMalloc(&c->h_tiles, cap * sizeof(grp_tile_summary), hipHostMallocDefault));
     c->h_tiles_cap = cap;
   }
+  ++c->n_general_windows;
   QueryRun q;
   int rc = enqueue_query(c, r, first, count, list_cap, q);
   if (rc != GRP_OK) {

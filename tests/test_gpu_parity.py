@@ -145,6 +145,38 @@ def test_query_dense_random_ids_and_saturation_bit(oracle, native):
         _compare_queries(eng, omf, b, reads)
 
 
+def test_flagged_tiles_are_redone_with_the_worst_case_table(oracle, native):
+    """h = 5, tile 1000: up to 5000 distinct IDs per tile do not fit the 4096-entry LDS
+    table of the first launch (limit 2815) — the tile is flagged and recomputed with the
+    worst-case geometry, in grp_query_tiles, in grp_classify_reads and (kind 0 hand-back)
+    in a streaming window.  Same results as the oracle."""
+    eng, oseeds, omf, m = _mk(oracle, native, h=5, m=oracle.load().orc_calc_optimal_size(300_000, 1, 0.1))
+    reads = random_reads(5, 2500, 5200, seed=43)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    for s in reads:
+        omf.bv_insert_read(s)
+    pop = eng.finalize()
+    assert pop == omf.finalize()
+    rng = np.random.default_rng(8)
+    ids = rng.integers(1, 1 << 30, size=pop, dtype=np.uint32)  # (almost) every probe another ID
+    eng.import_ids(0, ids=ids, counts=np.zeros(pop, dtype=np.uint32))
+    omf.ids()[:] = ids
+    _compare_queries(eng, omf, b, reads)
+    dec = eng.classify_reads(b)
+    assert all(int(d["num_tiles"]) == len(r) // TILE for d, r in zip(dec, reads))
+    v = eng.stream_begin(b, 0, len(reads), 0)
+    import time
+    t0 = time.time()
+    while not eng.stream_poll(0):
+        assert time.time() - t0 < 60
+    assert np.all(v["pad"] == 1) and np.any(v["kind"] == 0)  # flagged tiles: handed back to the synchronous path
+    ok = v["kind"] != 0
+    for f in ("kind", "num_tiles", "num_assigned", "trim_start", "trim_end", "hits", "misses"):
+        assert np.array_equal(v[f][ok], dec[f][ok]), f
+    eng.stream_end(0)
+
+
 @pytest.mark.parametrize("h,tile", [(1, 1000), (5, 1000), (3, 500), (2, 64)])
 def test_other_geometries(oracle, native, h, tile):
     k = 22
