@@ -183,10 +183,14 @@ Classifier::window_plan() const
     // stripe exchange (~150 us per group) is hidden behind the launches unless it is the
     // longer of the two.
     const uint32_t S = p_.max_window;
-    double per_read = t_read / world + t_host + p * t_abort + g_fix / S;
+    // a record handed back (a tile needed the worst-case table) costs an abort plus a
+    // synchronous single-read round: where that is frequent (large h on repeat-rich
+    // data) the windows that redo flagged tiles in bulk win
+    const double t_redo = t_abort + t_small + t_read;
+    double per_read = t_read / world + t_host + p * t_abort + p_redo_ * t_redo + g_fix / S;
     if (p_.world > 1) {
       const double group = (double)stripe_reads() * world;
-      per_read = std::max(t_read / world, 150e-6 / group + t_host) + p * (t_abort + 0.5 * group * t_read / world) + g_fix / S;
+      per_read = std::max(t_read / world, 150e-6 / group + t_host) + p * (t_abort + 0.5 * group * t_read / world) + p_redo_ * t_redo + g_fix / S;
     }
     if (force_stream || 1.0 / per_read > best_rate) {
       return Plan{ S, false, true };
@@ -587,6 +591,7 @@ Classifier::commit_one(uint32_t r, const gr_read_decision& d, int& rc)
   ++n_committed_;
   p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
   p_insert_slow_ += (1.0 / 8192.0) * ((ins ? 1.0 : 0.0) - p_insert_slow_);
+  p_redo_ -= p_redo_ / 4096.0; // forgotten slowly where no streaming window measures it
   n_inserts_ += ins ? 1 : 0;
   return ins;
 }
@@ -677,6 +682,7 @@ Classifier::stream_round(uint32_t& pos)
       break;
     }
     d.pad = 0;
+    p_redo_ += (1.0 / 64.0) * ((d.kind == 0 ? 1.0 : 0.0) - p_redo_);
     if (d.kind == 0) {
       redo = true; // needs the worst-case table / a larger arena: synchronous path below
       break;

@@ -93,6 +93,7 @@ private:
   // speculation control / statistics
   double p_insert_ = 1.0;        // EMA over ~32 reads
   double p_insert_slow_ = 0.0;   // EMA over ~8192 reads
+  double p_redo_ = 0.0;          // streaming records handed back to the synchronous path (EMA over ~64 reads)
   double avg_probes_per_read_ = 75000.0;
   uint64_t n_windows_ = 0, n_queried_ = 0, n_committed_ = 0, n_inserts_ = 0;
   double t_windows_ = 0, t_commit_ = 0;
