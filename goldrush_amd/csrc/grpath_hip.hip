@@ -596,8 +596,8 @@ grp_create(const grp_params* p, grp_ctx** out)
     CREATE_TRY(hipHostMalloc(&sl.h_executed, sizeof(unsigned long long), hipHostMallocDefault));
   }
   CREATE_TRY(hipHostMalloc(&c->h_lists, LIST_PREFIX * sizeof(grp_id_count), hipHostMallocDefault));
-  CREATE_TRY(hipHostMalloc(&c->h_small_tiles, SMALL_TILES * sizeof(grp_tile_summary), hipHostMallocMapped));
-  CREATE_TRY(hipHostMalloc(&c->h_small_lists, (size_t)SMALL_TILES * SMALL_STRIDE * sizeof(grp_id_count), hipHostMallocMapped));
+  CREATE_TRY(hipHostMalloc(&c->h_small_tiles, SMALL_TILES * sizeof(grp_tile_summary), hipHostMallocMapped | hipHostMallocCoherent));
+  CREATE_TRY(hipHostMalloc(&c->h_small_lists, (size_t)SMALL_TILES * SMALL_STRIDE * sizeof(grp_id_count), hipHostMallocMapped | hipHostMallocCoherent));
   CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->dmap_small_tiles), c->h_small_tiles, 0));
   CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->dmap_small_lists), c->h_small_lists, 0));
   CREATE_TRY(hipStreamSynchronize(c->stream));
@@ -1195,6 +1195,10 @@ grp_query_tiles(grp_ctx* c,
     // no counters; one stream synchronisation
     const uint64_t t0 = r->tile0[first];
     const uint64_t probes = count_probes(c, r, first, count);
+    constexpr uint32_t PENDING = 0xFFFFFFFEu; // list_n of a summary the kernel has not written yet
+    for (uint64_t i = 0; i < nt; ++i) {
+      c->h_small_tiles[i].list_n = PENDING;
+    }
     {
       const QueryGeom g = query_geom(c, false);
       Timer t(c, GRP_K_QUERY, probes);
@@ -1205,7 +1209,29 @@ grp_query_tiles(grp_ctx* c,
       }
     }
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the summaries arrive in host memory while the launch runs (lists first, the word with
+    // list_n last): spin on them instead of waiting for the end-of-kernel signal; a launch
+    // that never delivers falls back to the stream synchronisation
+    {
+      uint64_t i = 0;
+      uint32_t spins = 0;
+      while (i < nt) {
+        if (__atomic_load_n(&c->h_small_tiles[i].list_n, __ATOMIC_ACQUIRE) != PENDING) {
+          ++i;
+          continue;
+        }
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFu) == 0 && hipStreamQuery(c->stream) != hipErrorNotReady) {
+          HIP_TRY(c, hipStreamSynchronize(c->stream));
+          for (uint64_t j = i; j < nt; ++j) {
+            if (__atomic_load_n(&c->h_small_tiles[j].list_n, __ATOMIC_ACQUIRE) == PENDING) {
+              return set_err(c, GRP_ERR_HIP, "grp_query_tiles: the launch ended without delivering tile %llu", (unsigned long long)j);
+            }
+          }
+          break;
+        }
+      }
+    }
     ++c->n_direct_windows;
     bool any_flagged = false;
     uint64_t used = 0;
