@@ -174,7 +174,15 @@ def main():
         # here would need free compute units while the persistent query launch owns the
         # device, and two PCIe copies per call; RCCL is used where bulk data moves (the
         # bit-vector all-gather above).
-        ctrl = dist.new_group(backend="gloo") if a.backend == "nccl" else None
+        ctrl, ctrl_dev = None, "cpu"
+        if a.backend == "nccl":
+            try:
+                ctrl = dist.new_group(backend="gloo")
+            except Exception as e:  # no usable CPU transport: stay on RCCL, without persistent launches beside it
+                if rank == 0:
+                    sys.stderr.write("bench: no gloo group (%s); decisions go through RCCL, streaming windows off\n" % e)
+                ctrl, ctrl_dev = None, "cuda"
+                os.environ["GRP_STREAM"] = "off"
         bufs = {}  # per message size: in / out tensors (no allocation per call)
 
         def allgather(user, send, nbytes, recv):  # noqa: E306
@@ -182,11 +190,16 @@ def main():
             dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
             b = bufs.get(nbytes)
             if b is None:
-                b = (torch.empty(nbytes, dtype=torch.uint8), torch.empty(nbytes * world, dtype=torch.uint8))
+                b = (torch.empty(nbytes, dtype=torch.uint8, device=ctrl_dev), torch.empty(nbytes * world, dtype=torch.uint8, device=ctrl_dev))
                 bufs[nbytes] = b
-            b[0].numpy()[:] = src
-            dist.all_gather_into_tensor(b[1], b[0], group=ctrl)
-            dst[:] = b[1].numpy()
+            if ctrl_dev == "cpu":
+                b[0].numpy()[:] = src
+                dist.all_gather_into_tensor(b[1], b[0], group=ctrl)
+                dst[:] = b[1].numpy()
+            else:
+                b[0].copy_(torch.from_numpy(src))
+                dist.all_gather_into_tensor(b[1], b[0])
+                dst[:] = b[1].cpu().numpy()
             return 0
 
     cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
