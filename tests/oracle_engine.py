@@ -232,3 +232,107 @@ def serial_reference(orc, m, seeds, tile, k, reads, block=10, threshold=10, u=5,
         if finished:
             break
     return out, mf
+
+
+class OracleCliEngine:
+    """A COMPLETE engine function table backed by the CPU oracle (create, read upload, fill,
+    finalize, query, insert, reset), so that the product's whole host program
+    (gr_path_main: options, FASTQ reading, filters, passes, classifier, output files) can
+    run without a GPU.  No ingest / classify / stream / ntcard entry points: the host takes
+    its plain paths."""
+
+    def __init__(self, orc):
+        self.orc = orc
+        self.ctx = None       # one context at a time is enough for the CLI
+        self.batches = {}     # handle -> list of reads (bytes)
+        self._next = 1
+        self._keep = []
+        self.vt = self._make_vt()
+
+    def _make_vt(self):
+        vt = host.grp_engine_vt()
+        orc = self.orc
+
+        def create(params_p, out_pp):
+            p = params_p[0]
+            seeds = [p.seeds[i].decode() for i in range(p.h)]
+            self.ctx = {"seeds": orc.Seeds(seeds), "k": p.k, "h": p.h, "tile": p.tile, "m": p.m, "mf": None}
+            self.ctx["mf"] = orc.MiBF(p.m, self.ctx["seeds"], p.tile, p.k)
+            out_pp[0] = 1
+            return 0
+
+        def destroy(ctx):
+            self.ctx = None
+
+        def last_error(ctx):
+            return b"oracle cli engine"
+
+        def reads_upload(ctx, packed_p, word_off_p, len_p, n, out_pp):
+            word_off = np.ctypeslib.as_array(C.cast(word_off_p, C.POINTER(C.c_uint64)), shape=(n + 1,))
+            lens = np.ctypeslib.as_array(C.cast(len_p, C.POINTER(C.c_uint32)), shape=(n,))
+            nw = int(word_off[n])
+            packed = np.ctypeslib.as_array(C.cast(packed_p, C.POINTER(C.c_uint32)), shape=(max(nw, 1),))
+            lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+            reads = []
+            for i in range(n):
+                w = packed[int(word_off[i]):int(word_off[i + 1])]
+                codes = ((w[:, None] >> (2 * np.arange(16, dtype=np.uint32))[None, :]) & 3).astype(np.uint8).ravel()[: int(lens[i])]
+                reads.append(lut[codes].tobytes())
+            hnd = self._next
+            self._next += 1
+            self.batches[hnd] = reads
+            out_pp[0] = hnd
+            return 0
+
+        def reads_free(hnd):
+            self.batches.pop(hnd, None)
+
+        def bv_insert(ctx, hnd, first, count):
+            k, h = self.ctx["k"], self.ctx["h"]
+            for s in self.batches[hnd][first:first + count]:
+                if len(s) >= k + h - 1:
+                    self.ctx["mf"].bv_insert_read(s)
+            return 0
+
+        def finalize(ctx, pop_p):
+            pop_p[0] = self.ctx["mf"].finalize()
+            return 0
+
+        def query_tiles(ctx, hnd, first, count, tiles_p, lists_p, cap, used_p, stats_p):
+            res = []
+            for s in self.batches[hnd][first:first + count]:
+                res.extend(self.ctx["mf"].query_read(s))
+            need = sum(len(x[2]) for x in res)
+            used_p[0] = need
+            if need > cap:
+                return native.GRP_ERR_NOMEM
+            tiles = np.ctypeslib.as_array(C.cast(tiles_p, C.POINTER(C.c_uint32)), shape=(max(len(res), 1) * 6,)).view(native.tile_summary_dtype)
+            lists = np.ctypeslib.as_array(C.cast(lists_p, C.POINTER(C.c_uint32)), shape=(max(cap, 1) * 2,)).view(native.id_count_dtype)
+            off = 0
+            for i, (tid, tc, lst, ctr) in enumerate(res):
+                lst = sorted(((int(a), int(b)) for a, b in lst), key=lambda t: (-t[1], t[0]))
+                tiles[i] = (tid, tc, off, len(lst), ctr[1], ctr[2])
+                for j, (a, b) in enumerate(lst):
+                    lists[off + j] = (a, b)
+                off += len(lst)
+            return 0
+
+        def insert_tiles(ctx, hnd, ri, ts, te, id_):
+            self.ctx["mf"].insert_read_tiles(self.batches[hnd][ri], ts, te, id_)
+            return 0
+
+        def reset_ids(ctx):
+            self.ctx["mf"].reset_ids()
+            return 0
+
+        def sync(ctx):
+            return 0
+
+        impl = {"create": create, "destroy": destroy, "last_error": last_error, "reads_upload": reads_upload, "reads_free": reads_free, "bv_insert": bv_insert,
+                "finalize": finalize, "query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync}
+        for name, ftype in host.VT_TYPES:
+            if name in impl:
+                cb = ftype(impl[name])
+                self._keep.append(cb)
+                setattr(vt, name, cb)
+        return vt

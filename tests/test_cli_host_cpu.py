@@ -1,0 +1,54 @@
+"""CPU: the product's whole host program (gr_path_main in libgrpath_host.so: options, FASTQ
+reader, read filters, Phred median, the three passes, the order-exact classifier, output
+files) over an engine function table backed by the oracle — byte-identical files against
+the oracle CLI, without a GPU.  (tests/test_gpu_cli.py does the same with the HIP engine.)"""
+import ctypes as C
+import filecmp
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+RUNNER = textwrap.dedent("""
+    import ctypes as C, os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+    import orc
+    from goldrush_amd import host
+    from oracle_engine import OracleCliEngine
+    eng = OracleCliEngine(orc)
+    args = [b"goldrush_path"] + [a.encode() for a in sys.argv[1:]]
+    arr = (C.c_char_p * (len(args) + 1))(*args, None)
+    rc = host.load().gr_path_main(len(args), arr, C.byref(eng.vt))
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(rc)
+""")
+
+
+@pytest.mark.parametrize("mode", ["silver", "golden"])
+def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_path, mode):
+    fq = os.path.join(GOLD, "tiny.fq")
+    common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-i", fq, "--verbose"]
+    args = common + (["-P0", "-r0.9", "--silver_path", "-M3", "-m1500"] if mode == "silver" else ["-P12", "-m0"])
+    d_o, d_p = tmp_path / "o", tmp_path / "p"
+    d_o.mkdir()
+    d_p.mkdir()
+    ro = oracle.run_cli(args + ["-p", str(d_o / "out")], timeout=600)
+    script = tmp_path / "runner.py"
+    script.write_text(RUNNER.format(root=ROOT))
+    rp = subprocess.run([sys.executable, str(script)] + args + ["-p", str(d_p / "out")], capture_output=True, text=True, timeout=900,
+                        env=dict(os.environ, GRP_HOST_INGEST="1", OMP_NUM_THREADS="2"))
+    assert rp.returncode == ro.returncode, (rp.returncode, ro.returncode, rp.stderr[-3000:])
+    fo, fp = sorted(os.listdir(d_o)), sorted(os.listdir(d_p))
+    assert fo == fp and fo, (fo, fp)
+    for f in fo:
+        assert filecmp.cmp(d_o / f, d_p / f, shallow=False), f
+    assert any(os.path.getsize(d_p / f) > 0 for f in fo)
+    keep = ("Visited", "Saw:", "Assigned:", "Unassigned:", "Total queries", "Total hits", "Total misses", "Num reads", "m_filterSize", "\texpected hash space",
+            "\tminimum average phred", "num_", "Total reads skipped")
+    pick = lambda text: [l for l in text.splitlines() if l.startswith(keep)]  # noqa: E731
+    assert pick(rp.stderr) == pick(ro.stderr)
