@@ -1365,6 +1365,12 @@ fill_bit_vector(orc_path* p)
       continue;
     }
     const orc_record* rec = &p->reads->rec[r];
+    /* a read shorter than the longest seed span is outside the reference's defined
+     * behaviour (btllib::SeedNtHash on a too-short string; only reachable with -m below
+     * k + h - 1): it contributes nothing — the rule the product documents */
+    if (rec->len < p->seeds[p->h - 1].span) {
+      continue;
+    }
     /* multiLensfrHashIterator itr(record.seq, seeds); insertBV(itr) :304-305 */
     size_t frames = orc_multi_hash(p->seeds, p->h, rec->seq, rec->len, NULL, 0);
     uint64_t* hv = (uint64_t*)malloc((frames * p->h + 1) * sizeof(uint64_t));

@@ -238,8 +238,8 @@ class OracleCliEngine:
     """A COMPLETE engine function table backed by the CPU oracle (create, read upload, fill,
     finalize, query, insert, reset), so that the product's whole host program
     (gr_path_main: options, FASTQ reading, filters, passes, classifier, output files) can
-    run without a GPU.  No ingest / classify / stream / ntcard entry points: the host takes
-    its plain paths."""
+    run without a GPU.  No ingest / classify / stream entry points: the host takes its
+    plain paths; the --ntcard entry points restate the kernel's rule with oracle hashes."""
 
     def __init__(self, orc):
         self.orc = orc
@@ -257,7 +257,8 @@ class OracleCliEngine:
             p = params_p[0]
             seeds = [p.seeds[i].decode() for i in range(p.h)]
             self.ctx = {"seeds": orc.Seeds(seeds), "k": p.k, "h": p.h, "tile": p.tile, "m": p.m, "mf": None}
-            self.ctx["mf"] = orc.MiBF(p.m, self.ctx["seeds"], p.tile, p.k)
+            if p.m:  # m = 0: sized after the --ntcard pass (set_filter_size)
+                self.ctx["mf"] = orc.MiBF(p.m, self.ctx["seeds"], p.tile, p.k)
             out_pp[0] = 1
             return 0
 
@@ -328,8 +329,52 @@ class OracleCliEngine:
         def sync(ctx):
             return 0
 
+        # --ntcard entry points: the kernel's rule (grpath.h) stated with oracle hashes — every
+        # entry is an ACGT run, each seed counts all its windows once and its last window
+        # `extra` more times (default: span_s - k); zero buckets count modulo 2^16
+        nt = {}
+
+        def ntcard_begin(ctx, sbits):
+            nt.clear()
+            nt["sbits"] = sbits
+            nt["tables"] = [dict() for _ in range(2 * self.ctx["h"])]
+            nt["single"] = [orc.Seeds([p_]) for p_ in self.ctx["seeds"].patterns]
+            return 0
+
+        def ntcard_add(ctx, hnd, first, count, extra_p):
+            h, k, sbits = self.ctx["h"], self.ctx["k"], nt["sbits"]
+            extra = np.ctypeslib.as_array(C.cast(extra_p, C.POINTER(C.c_uint32)), shape=(count * h,)) if extra_p else None
+            for j, run in enumerate(self.batches[hnd][first:first + count]):
+                for s_ in range(h):
+                    K = k + s_
+                    if len(run) < K:
+                        continue
+                    hv = nt["single"][s_].multi_hash(run).astype(np.uint64)
+                    times = np.ones(hv.size, dtype=np.uint64)
+                    times[-1] += int(extra[j * h + s_]) if extra is not None else s_
+                    ind = np.full(hv.size, 2, dtype=np.uint64)
+                    ind[(hv >> np.uint64(63 - sbits)) == 1] = 0
+                    ind[(hv >> np.uint64(64 - sbits)) == np.uint64((1 << (sbits - 1)) - 1)] = 1
+                    sel = ind < 2
+                    for t_, b_, w_ in zip(ind[sel], hv[sel] & np.uint64((1 << 27) - 1), times[sel]):
+                        tab = nt["tables"][2 * s_ + int(t_)]
+                        tab[int(b_)] = tab.get(int(b_), 0) + int(w_)
+            return 0
+
+        def ntcard_finish(ctx, zeros_p):
+            z = C.cast(zeros_p, C.POINTER(C.c_uint64))
+            for i, tab in enumerate(nt["tables"]):
+                z[i] = (1 << 27) - sum(1 for v in tab.values() if v % 65536 != 0)
+            return 0
+
+        def set_filter_size(ctx, m):
+            self.ctx["m"] = m
+            self.ctx["mf"] = orc.MiBF(m, self.ctx["seeds"], self.ctx["tile"], self.ctx["k"])
+            return 0
+
         impl = {"create": create, "destroy": destroy, "last_error": last_error, "reads_upload": reads_upload, "reads_free": reads_free, "bv_insert": bv_insert,
-                "finalize": finalize, "query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync}
+                "finalize": finalize, "query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync,
+                "ntcard_begin": ntcard_begin, "ntcard_add": ntcard_add, "ntcard_finish": ntcard_finish, "set_filter_size": set_filter_size}
         for name, ftype in host.VT_TYPES:
             if name in impl:
                 cb = ftype(impl[name])

@@ -29,10 +29,18 @@ RUNNER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("mode", ["silver", "golden"])
+@pytest.mark.parametrize("mode", ["silver", "golden", "ntcard"])
 def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_path, mode):
     fq = os.path.join(GOLD, "tiny.fq")
     common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-i", fq, "--verbose"]
+    if mode == "ntcard":  # the estimate replaces -H: drop it (and add a record with N, a short one, lower case)
+        common = [a for a in common if not a.startswith("-H")] + ["--ntcard"]
+        fq2 = str(tmp_path / "reads.fq")
+        with open(fq, "rb") as src, open(fq2, "wb") as dst:
+            dst.write(src.read())
+            for i, seq in enumerate([b"ACGTACGTACGTACGTACGTACG", b"acgtnACGTACGTACGTACGTACGTACGTAC", b"ACGTAC" * 10 + b"RY" + b"TTGCA" * 9]):
+                dst.write(b"@x%d\n%s\n+\n%s\n" % (i, seq, b"5" * len(seq)))
+        common[common.index(fq)] = fq2
     args = common + (["-P0", "-r0.9", "--silver_path", "-M3", "-m1500"] if mode == "silver" else ["-P12", "-m0"])
     d_o, d_p = tmp_path / "o", tmp_path / "p"
     d_o.mkdir()
@@ -48,7 +56,7 @@ def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_
     for f in fo:
         assert filecmp.cmp(d_o / f, d_p / f, shallow=False), f
     assert any(os.path.getsize(d_p / f) > 0 for f in fo)
-    keep = ("Visited", "Saw:", "Assigned:", "Unassigned:", "Total queries", "Total hits", "Total misses", "Num reads", "m_filterSize", "\texpected hash space",
+    keep = ("Expected entries", "Total expected entries", "\toccupancy", "Visited", "Saw:", "Assigned:", "Unassigned:", "Total queries", "Total hits", "Total misses", "Num reads", "m_filterSize", "\texpected hash space",
             "\tminimum average phred", "num_", "Total reads skipped")
     pick = lambda text: [l for l in text.splitlines() if l.startswith(keep)]  # noqa: E731
     assert pick(rp.stderr) == pick(ro.stderr)
