@@ -29,8 +29,8 @@ RUNNER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("mode", ["silver", "golden", "ntcard"])
-def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_path, mode):
+@pytest.mark.parametrize("mode,batch", [("silver", 0), ("silver", 1), ("silver", 7), ("golden", 0), ("ntcard", 0), ("ntcard", 5)])
+def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_path, mode, batch):
     fq = os.path.join(GOLD, "tiny.fq")
     common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-i", fq, "--verbose"]
     if mode == "ntcard":  # the estimate replaces -H: drop it (and add a record with N, a short one, lower case)
@@ -49,7 +49,7 @@ def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_
     script = tmp_path / "runner.py"
     script.write_text(RUNNER.format(root=ROOT))
     rp = subprocess.run([sys.executable, str(script)] + args + ["-p", str(d_p / "out")], capture_output=True, text=True, timeout=900,
-                        env=dict(os.environ, GRP_HOST_INGEST="1", OMP_NUM_THREADS="2"))
+                        env=dict(os.environ, GRP_HOST_INGEST="1", OMP_NUM_THREADS="2", **({"GRP_BATCH_RECORDS": str(batch)} if batch else {})))
     assert rp.returncode == ro.returncode, (rp.returncode, ro.returncode, rp.stderr[-3000:])
     fo, fp = sorted(os.listdir(d_o)), sorted(os.listdir(d_p))
     assert fo == fp and fo, (fo, fp)
