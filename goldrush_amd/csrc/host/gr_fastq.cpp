@@ -1,27 +1,68 @@
 #include "gr_fastq.hpp"
 
+#include <algorithm>
 #include <cctype>
 #include <cstring>
+#include <zlib.h>
 
 namespace gr {
 
-FastqStream::FastqStream(const std::string& path)
+InputFile::InputFile(const std::string& path)
 {
-  fp_ = fopen(path.c_str(), "rb");
+  gzFile f = gzopen(path.c_str(), "rb");
+  if (f) {
+    gzbuffer(f, 1u << 20);
+  }
+  f_ = f;
+}
+
+InputFile::~InputFile()
+{
+  if (f_) {
+    gzclose(static_cast<gzFile>(f_));
+  }
+}
+
+size_t
+InputFile::read(char* dst, size_t n)
+{
+  size_t got = 0;
+  while (f_ && got < n) { // gzread takes an unsigned length
+    const unsigned want = (unsigned)std::min<size_t>(n - got, 1u << 30);
+    const int r = gzread(static_cast<gzFile>(f_), dst + got, want);
+    if (r <= 0) {
+      break;
+    }
+    got += (size_t)r;
+  }
+  return got;
+}
+
+int
+InputFile::peek()
+{
+  if (!f_) {
+    return -1;
+  }
+  const int c = gzgetc(static_cast<gzFile>(f_));
+  if (c >= 0) {
+    gzungetc(c, static_cast<gzFile>(f_));
+  }
+  return c;
+}
+
+FastqStream::FastqStream(const std::string& path)
+  : in_(path)
+{
   buf_.resize(size_t(8) << 20);
 }
 
-FastqStream::~FastqStream()
-{
-  if (fp_) {
-    fclose(fp_);
-  }
-}
+FastqStream::~FastqStream() {}
 
 bool
 FastqStream::fill()
 {
-  if (eof_ || !fp_) {
+  if (eof_ || !in_.ok()) {
     return false;
   }
   // keep the unread tail, refill the rest
@@ -34,7 +75,7 @@ FastqStream::fill()
   if (end_ == buf_.size()) {
     buf_.resize(buf_.size() * 2); // a single line longer than the buffer
   }
-  const size_t got = fread(buf_.data() + end_, 1, buf_.size() - end_, fp_);
+  const size_t got = in_.read(buf_.data() + end_, buf_.size() - end_);
   if (got == 0) {
     eof_ = true;
     return false;

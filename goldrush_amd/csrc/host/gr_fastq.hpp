@@ -1,7 +1,8 @@
 // Streaming FASTQ reader with the record semantics the reference gets from
 // btllib::SeqReader (LONG_MODE, default flags): id = header up to the first
 // whitespace, sequence case-folded to upper case, 4-line records, records in
-// file order.  Plain-text input only.
+// file order.  Plain or gzip-compressed text (zlib; btllib::SeqReader pipes compressed
+// input through an external decompressor).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -10,6 +11,22 @@
 #include <vector>
 
 namespace gr {
+
+// the input file, plain or gzip'ed (gzread passes plain files through)
+class InputFile
+{
+public:
+  explicit InputFile(const std::string& path);
+  ~InputFile();
+  InputFile(const InputFile&) = delete;
+  InputFile& operator=(const InputFile&) = delete;
+  bool ok() const { return f_ != nullptr; }
+  size_t read(char* dst, size_t n); // 0 at the end of the data (or on a read error)
+  int peek();                      // next byte without consuming it, -1 at the end
+
+private:
+  void* f_ = nullptr; // gzFile
+};
 
 struct RecordRef
 {
@@ -41,7 +58,7 @@ class FastqStream
 public:
   explicit FastqStream(const std::string& path);
   ~FastqStream();
-  bool ok() const { return fp_ != nullptr; }
+  bool ok() const { return in_.ok(); }
   // SeqReader::get_format() == FASTQ  <=>  first byte of the file is '@'
   bool is_fastq();
   // appends up to max_records / ~max_bases to `out` (cleared first); false at EOF
@@ -50,7 +67,7 @@ public:
 private:
   bool fill();
   bool get_line(const char*& p, size_t& n); // without the trailing newline / CR / blanks
-  FILE* fp_ = nullptr;
+  InputFile in_;
   std::vector<char> buf_;
   size_t pos_ = 0, end_ = 0;
   bool eof_ = false;

@@ -192,30 +192,13 @@ class GpuSource : public RecordSource
 public:
   GpuSource(PathRun& run)
     : run_(run)
+    , in_(run.opt.input)
   {
-    fp_ = fopen(run.opt.input.c_str(), "rb");
     buf_.resize(ingest_chunk_bytes());
   }
-  ~GpuSource() override
-  {
-    release();
-    if (fp_) {
-      fclose(fp_);
-    }
-  }
-  bool ok() const override { return fp_ != nullptr; }
-  bool is_fastq() override
-  {
-    if (!fp_) {
-      return false;
-    }
-    const int c = fgetc(fp_);
-    if (c == EOF) {
-      return false;
-    }
-    ungetc(c, fp_);
-    return c == '@';
-  }
+  ~GpuSource() override { release(); }
+  bool ok() const override { return in_.ok(); }
+  bool is_fastq() override { return in_.peek() == '@'; }
   bool next(Batch& b) override
   {
     release();
@@ -226,7 +209,7 @@ public:
       size_t fill = tail_len_;
       tail_off_ = 0;
       while (!eof_ && fill < buf_.size()) {
-        const size_t got = fread(buf_.data() + fill, 1, buf_.size() - fill, fp_);
+        const size_t got = in_.read(buf_.data() + fill, buf_.size() - fill);
         if (got == 0) {
           eof_ = true;
         }
@@ -306,7 +289,7 @@ private:
     }
   }
   PathRun& run_;
-  FILE* fp_ = nullptr;
+  InputFile in_;
   std::vector<char> buf_;
   size_t tail_off_ = 0, tail_len_ = 0;
   bool eof_ = false, done_ = false, failed_ = false;

@@ -29,7 +29,7 @@ RUNNER = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("mode,batch", [("silver", 0), ("silver", 1), ("silver", 7), ("golden", 0), ("ntcard", 0), ("ntcard", 5)])
+@pytest.mark.parametrize("mode,batch", [("silver", 0), ("silver", 1), ("silver", 7), ("golden", 0), ("ntcard", 0), ("ntcard", 5), ("gz", 0), ("gz", 3)])
 def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_path, mode, batch):
     fq = os.path.join(GOLD, "tiny.fq")
     common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-i", fq, "--verbose"]
@@ -41,14 +41,22 @@ def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_
             for i, seq in enumerate([b"ACGTACGTACGTACGTACGTACG", b"acgtnACGTACGTACGTACGTACGTACGTAC", b"ACGTAC" * 10 + b"RY" + b"TTGCA" * 9]):
                 dst.write(b"@x%d\n%s\n+\n%s\n" % (i, seq, b"5" * len(seq)))
         common[common.index(fq)] = fq2
-    args = common + (["-P0", "-r0.9", "--silver_path", "-M3", "-m1500"] if mode == "silver" else ["-P12", "-m0"])
+    args = common + (["-P0", "-r0.9", "--silver_path", "-M3", "-m1500"] if mode in ("silver", "gz") else ["-P12", "-m0"])
+    args_p = list(args)
+    if mode == "gz":  # gzip-compressed input for the product, the plain file for the oracle
+        import gzip
+
+        gz = str(tmp_path / "reads.fq.gz")
+        with open(fq, "rb") as src, gzip.open(gz, "wb") as dst:
+            dst.write(src.read())
+        args_p[args_p.index(fq)] = gz
     d_o, d_p = tmp_path / "o", tmp_path / "p"
     d_o.mkdir()
     d_p.mkdir()
     ro = oracle.run_cli(args + ["-p", str(d_o / "out")], timeout=600)
     script = tmp_path / "runner.py"
     script.write_text(RUNNER.format(root=ROOT))
-    rp = subprocess.run([sys.executable, str(script)] + args + ["-p", str(d_p / "out")], capture_output=True, text=True, timeout=900,
+    rp = subprocess.run([sys.executable, str(script)] + args_p + ["-p", str(d_p / "out")], capture_output=True, text=True, timeout=900,
                         env=dict(os.environ, GRP_HOST_INGEST="1", OMP_NUM_THREADS="2", **({"GRP_BATCH_RECORDS": str(batch)} if batch else {})))
     assert rp.returncode == ro.returncode, (rp.returncode, ro.returncode, rp.stderr[-3000:])
     fo, fp = sorted(os.listdir(d_o)), sorted(os.listdir(d_p))

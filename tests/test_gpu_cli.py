@@ -133,6 +133,33 @@ def test_ntcard_sizes_the_filter(oracle, host, tmp_path, host_ingest):
     assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
 
 
+def test_gzip_input(oracle, host, tmp_path):
+    """gzip-compressed FASTQ (GPU ingest of the inflated chunks, and the host reader): the
+    same files as the oracle on the plain text."""
+    import gzip
+
+    fq = str(tmp_path / "reads.fq")
+    _mk_fastq(fq, 150_000, 260, 6000, 4000, seed=31, lower=True, with_n=13)
+    gz = fq + ".gz"
+    with open(fq, "rb") as src, gzip.open(gz, "wb", compresslevel=1) as dst:
+        dst.write(src.read())
+    args = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j4", "-d5", "-x10", "-s1011011110110111101101", "-g150000", "-b4", "-H2500000", "-P0", "-r0.9",
+            "--silver_path", "-M2", "-m3500", "--verbose"]
+    d_o = tmp_path / "o"
+    d_o.mkdir()
+    ro = oracle.run_cli(args + ["-i", fq, "-p", str(d_o / "out")], timeout=900)
+    for tag, env in (("gpu_ingest", {"GRP_INGEST_CHUNK": "400000"}), ("host_ingest", {"GRP_HOST_INGEST": "1"})):
+        d_p = tmp_path / tag
+        d_p.mkdir()
+        rp = subprocess.run([host.CLI_PATH] + args + ["-i", gz, "-p", str(d_p / "out")], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert rp.returncode == ro.returncode, rp.stderr[-2000:]
+        files = sorted(os.listdir(d_o))
+        assert files == sorted(os.listdir(d_p)) and files
+        for f in files:
+            assert filecmp.cmp(d_o / f, d_p / f, shallow=False), (tag, f)
+        assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+
+
 def test_cli_error_paths(oracle, host, tmp_path):
     fa = tmp_path / "x.fa"
     fa.write_text(">r1\nACGT\n")
