@@ -1189,7 +1189,7 @@ grp_query_tiles(grp_ctx* c,
   if (!tiles_out) {
     return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: tiles_out is NULL");
   }
-  if (nt <= SMALL_TILES) {
+  if (nt <= SMALL_TILES && !getenv("GRP_NO_DIRECT")) { // (developer hook: force the general path)
     // latency path (insert-heavy phases query one read at a time): the kernel
     // writes summaries and lists straight into mapped host memory, no copies,
     // no counters; one stream synchronisation
