@@ -133,6 +133,30 @@ def test_ntcard_sizes_the_filter(oracle, host, tmp_path, host_ingest):
     assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
 
 
+def test_c0_demo_configuration(oracle, host, tmp_path):
+    """BASELINE configs[0] (the reference's own demo, tests/goldrush_test_demo.sh: G = 1e6,
+    k22 w16 h3, tile 1000, -P 0, 5 silver paths of 0.9 G, then the golden path over them) on
+    a synthetic 1 Mbp genome with 25 kb reads: both goldrush-path processes of bin/goldrush,
+    byte-identical to the oracle CLI."""
+    from goldrush_amd import synth
+
+    fq = str(tmp_path / "test_reads.fq")
+    synth.make_fastq(fq, 1_000_000, 1200, genome_seed=1, seed=2)
+    common = ["-k22", "-w16", "-t1000", "-u5", "-a1", "-o0.1", "-h3", "-j4", "-d5", "-x10", "-s1011011110110111101101", "-g1000000", "-b10"]
+    silver = common + ["-P0", "-r0.9", "--silver_path", "-M5", "-m20000", "-i", fq, "--verbose"]
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, silver, "c0_silver")
+    assert files == ["out_%d.fq" % i for i in range(1, 6)] and all(os.path.getsize(d_p / f) > 0 for f in files)
+    assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+    allfq = str(tmp_path / "all.fq")
+    with open(allfq, "wb") as out:
+        for f in files:
+            out.write(open(d_p / f, "rb").read())
+    golden = common + ["-P0", "-m0", "-i", allfq, "--verbose"]
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, golden, "c0_golden")
+    assert files == ["out.fa"] and os.path.getsize(d_p / "out.fa") > 0
+    assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+
+
 def test_gzip_input(oracle, host, tmp_path):
     """gzip-compressed FASTQ (GPU ingest of the inflated chunks, and the host reader): the
     same files as the oracle on the plain text."""
