@@ -236,6 +236,10 @@ def main():
                 if rank == 0:
                     sys.stderr.write("bench: no /dev/shm exchange (%s), using a gloo group\n" % e)
                 shm = None
+        if shm is not None:
+            # the exchange costs tens of microseconds here, not hundreds: shorter stripes
+            # (less speculative work lost per insert) still hide it behind the launches
+            os.environ.setdefault("GRP_STRIPE", str(64 + 8 * world))
         ctrl, ctrl_dev = None, "cpu"
         if shm is None and a.backend == "nccl":
             try:
