@@ -587,7 +587,7 @@ grp_create(const grp_params* p, grp_ctx** out)
     CREATE_TRY(hipMemsetAsync(sl.d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
     CREATE_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&sl.qdone, hipEventDisableTiming));
-    CREATE_TRY(hipMalloc(&sl.d_abort, 256)); // [0] abort flag, [32] tile dispenser (its own 128-byte line)
+    CREATE_TRY(hipMalloc(&sl.d_abort, 256)); // [0] abort flag, [32] tile dispenser (its own 128-byte line), [48] park
     CREATE_TRY(hipMemsetAsync(sl.d_abort, 0, 256, c->stream));
     CREATE_TRY(hipHostMalloc(&sl.h_abort, 64, hipHostMallocMapped | hipHostMallocCoherent));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_abort), sl.h_abort, 0));
@@ -1679,6 +1679,7 @@ grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first
       HIP_TRY(c, hipMemcpyAsync(sl.d_stripe_tiles, sl.h_stripe_tiles, n_mine * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     }
     HIP_TRY(c, hipMemsetAsync(sl.d_abort, 0, 256, c->stream));
+    HIP_TRY(c, hipMemsetAsync(sl.d_abort + 48, 0xFF, sizeof(uint32_t), c->stream)); // park: nothing stale yet
     HIP_TRY(c, hipMemsetAsync(sl.d_tiles_done, 0, (size_t)count * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(sl.d_executed, 0, sizeof(unsigned long long), c->stream));
     DevStreamCtl sc;
@@ -1687,6 +1688,7 @@ grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first
     sc.abort = sl.d_abort;
     sc.abort_host = sl.dmap_abort;
     sc.next_tile = sl.d_abort + 32;
+    sc.park = sl.d_abort + 48;
     sc.n_tiles = (uint32_t)n_mine;
     sc.dec = sl.dmap_sdec;
     sc.executed = sl.d_executed;

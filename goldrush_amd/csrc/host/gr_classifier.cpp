@@ -632,6 +632,10 @@ Classifier::stream_decision(uint32_t j, gr_read_decision& d)
         return e;
       }
       stripe_send_[q - lo] = scur_.dec[q];
+      const uint32_t kind = scur_.dec[q].kind;
+      if (kind == DEC_INSERT_WHOLE || kind == DEC_INSERT_TRIMMED || kind == 0) {
+        break; // the launch parks itself behind such a record: later records of the stripe never come, and no rank reads them
+      }
     }
     stripe_recv_.resize(GW);
     if (allgather_cb_(user_, stripe_send_.data(), (uint64_t)C * sizeof(gr_read_decision), stripe_recv_.data()) != 0) {

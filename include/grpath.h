@@ -289,8 +289,11 @@ int grp_classify_reads_end(grp_ctx* ctx, uint32_t slot, grp_read_decision* decis
  *           in: (*decisions)[j].pad becomes 1 (release) when record j is complete;
  *           kind == 0 then means "take this read through grp_classify_reads" (a tile
  *           needed the worst-case table or the list arena was too small).  Records
- *           complete roughly in read order.  The array stays valid until the slot's
- *           next _begin.
+ *           complete roughly in read order.  The window PARKS ITSELF behind the first
+ *           record that is an insert (kind 2 / 4) or a hand-back (kind 0): every read
+ *           after it is stale whatever the earlier reads decide, so their records may
+ *           never complete (all records before it still do).  The array stays valid
+ *           until the slot's next _begin.
  *   _abort  (after an insert made the rest of the window stale) workgroups that have
  *           not started yet exit immediately; records already being worked on may
  *           still complete.

@@ -176,27 +176,46 @@ def test_device_decisions_match_host_and_oracle(oracle, native):
     # decisions; two launches queued; abort leaves the slot reusable
     import time
 
-    def wait_all(view, slot):
+    def first_stop(kinds):  # the window parks itself behind the first insert / hand-back record
+        for i, kd in enumerate(kinds):
+            if int(kd) in (0, 2, 4):
+                return i
+        return len(kinds) - 1
+
+    def wait_all(view, slot, expect):
+        """Wait for the launch; every record up to the first insert / hand-back one must be there."""
         t0 = time.time()
-        while not np.all(view["pad"] == 1):
-            assert time.time() - t0 < 60, "records missing"
-            if eng.stream_poll(slot):
-                break
-        assert np.all(view["pad"] == 1)
+        while not eng.stream_poll(slot):
+            assert time.time() - t0 < 60, "launch does not end"
+        must = first_stop(expect["kind"]) + 1
+        assert np.all(view["pad"][:must] == 1), (must, view["pad"][:must])
+        return view["pad"] == 1
 
     ref = eng.classify_reads(b)
     v0 = eng.stream_begin(b, 0, 30, 0)
     v1 = eng.stream_begin(b, 30, n - 30, 1)
     with pytest.raises(native.GrpError):
         eng.stream_begin(b, 0, 1, 1)
-    wait_all(v0, 0)
-    wait_all(v1, 1)
+    d0 = wait_all(v0, 0, ref[:30])
+    d1 = wait_all(v1, 1, ref[30:])
     fields = ["kind", "num_tiles", "num_assigned", "trim_start", "trim_end", "hits", "misses"]
-    for f in fields:
-        assert np.array_equal(v0[f], ref[f][:30]) and np.array_equal(v1[f], ref[f][30:]), f
-    assert eng.stream_end(0) == 30 and eng.stream_end(1) == n - 30
+    for f in fields:  # whatever completed is right
+        assert np.array_equal(v0[f][d0], ref[f][:30][d0]) and np.array_equal(v1[f][d1], ref[f][30:][d1]), f
+    assert eng.stream_end(0) == int(d0.sum()) and eng.stream_end(1) == int(d1.sum())
     with pytest.raises(native.GrpError):
         eng.stream_end(0)
+    # walking the whole batch the way the classifier does: restart behind every parking record
+    pos, seen = 0, np.zeros(n, dtype=bool)
+    while pos < n:
+        v = eng.stream_begin(b, pos, n - pos, 0)
+        done = wait_all(v, 0, ref[pos:])
+        stop = first_stop(ref["kind"][pos:])
+        for f in fields:
+            assert np.array_equal(v[f][: stop + 1], ref[f][pos: pos + stop + 1]), (f, pos)
+        eng.stream_end(0)
+        seen[pos: pos + stop + 1] = True
+        pos += stop + 1
+    assert seen.all()
     v = eng.stream_begin(b, 0, n, 1)
     eng.stream_abort(1)
     decided = eng.stream_end(1)
@@ -204,26 +223,25 @@ def test_device_decisions_match_host_and_oracle(oracle, native):
     done = v["pad"] == 1
     for f in fields:  # whatever completed is right
         assert np.array_equal(v[f][done], ref[f][done]), f
-    v = eng.stream_begin(b, 2, 9, 1)
-    wait_all(v, 1)
-    assert eng.stream_end(1) == 9 and np.array_equal(v["kind"], ref["kind"][2:11])
     assert len(eng.stream_begin(b, 4, 0, 0)) == 0 and eng.stream_end(0) == 0
     assert np.array_equal(eng.classify_reads(b), ref)
-    # striped window (several ranks share it): only the owner's stripes are worked on
-    seen = np.zeros(n, dtype=bool)
+    # striped window (several ranks share it): only the owner's stripes are worked on, up to
+    # the owner's first insert / hand-back record
+    zero_tiles = np.array([len(r) // tile == 0 for r in reads])
     for owner in range(3):
         v = eng.stream_begin(b, 0, n, owner & 1, stripe=7, n_owners=3, owner=owner)
         mine = (np.arange(n) // 7) % 3 == owner
         t0 = time.time()
         while not eng.stream_poll(owner & 1):
             assert time.time() - t0 < 60
-        zero_tiles = np.array([len(r) // tile == 0 for r in reads])
-        assert np.all(v["pad"][mine] == 1) and not np.any(v["pad"][~mine & ~zero_tiles])
+        idx = np.flatnonzero(mine)
+        stop = idx[first_stop(ref["kind"][idx])]
+        must = mine & (np.arange(n) <= stop)
+        assert np.all(v["pad"][must] == 1) and not np.any(v["pad"][~mine & ~zero_tiles])
+        done = (v["pad"] == 1) & mine
         for f in fields:
-            assert np.array_equal(v[f][mine], ref[f][mine]), f
+            assert np.array_equal(v[f][done], ref[f][done]), f
         assert eng.stream_end(owner & 1) == int(v["pad"].sum())
-        seen |= mine
-    assert seen.all()
 
 
 def test_hip_classifier_h5_designed_seed(oracle, native):

@@ -170,8 +170,12 @@ def test_flagged_tiles_are_redone_with_the_worst_case_table(oracle, native):
     t0 = time.time()
     while not eng.stream_poll(0):
         assert time.time() - t0 < 60
-    assert np.all(v["pad"] == 1) and np.any(v["kind"] == 0)  # flagged tiles: handed back to the synchronous path
-    ok = v["kind"] != 0
+    done = v["pad"] == 1
+    # flagged tiles: the read is handed back to the synchronous path (kind 0) and the window
+    # parks itself behind that record
+    first = int(np.flatnonzero(done & (v["kind"] == 0))[0])
+    assert np.all(done[: first + 1])
+    ok = done & (v["kind"] != 0)
     for f in ("kind", "num_tiles", "num_assigned", "trim_start", "trim_end", "hits", "misses"):
         assert np.array_equal(v[f][ok], dec[f][ok]), f
     eng.stream_end(0)
