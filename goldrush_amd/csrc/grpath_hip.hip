@@ -1689,6 +1689,7 @@ grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first
     sc.abort_host = sl.dmap_abort;
     sc.next_tile = sl.d_abort + 32;
     sc.park = sl.d_abort + 48;
+    sc.early_park = getenv("GRP_NO_EARLY_PARK") ? 0u : 1u; // developer hook (the engine-level API contract assumes 1)
     sc.n_tiles = (uint32_t)n_mine;
     sc.dec = sl.dmap_sdec;
     sc.executed = sl.d_executed;
