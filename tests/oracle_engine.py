@@ -105,9 +105,12 @@ class OracleEngine:
             assert slot in (0, 1) and slot not in streams and slot not in slots, "slot busy"
             dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
             arr = (host.gr_read_decision * max(count, 1))()
+            parked = False
             for j in range(count):
                 if n_owners > 1 and (j // stripe) % n_owners != owner:
                     continue  # another rank's stripe: the record stays at pad = 0
+                if parked:
+                    continue  # the window parked itself behind an insert / hand-back record: never decided
                 self.n_stream_records = getattr(self, "n_stream_records", 0) + 1
                 if self.redo_every and self.n_stream_records % self.redo_every == 0:
                     arr[j] = host.gr_read_decision()  # kind 0
@@ -115,6 +118,7 @@ class OracleEngine:
                 else:
                     arr[j] = _decide(first + j, dp)
                 arr[j].pad = 1
+                parked = arr[j].kind in (0, 2, 4)
             self.n_queries += sum(1 for j in range(count) if arr[j].pad)
             self.n_streams += 1
             streams[slot] = (arr, count)
