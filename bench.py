@@ -159,6 +159,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and "OMP_NUM_THREADS" not in os.environ:
+        # the ranks share the node's cores (and its cgroup quota): every rank already keeps
+        # one core busy spinning on its records, the OpenMP regions of the host get the rest
+        cpus = len(os.sched_getaffinity(0))
+        try:
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+            if quota != "max":
+                cpus = min(cpus, max(1, int(quota) // int(period)))
+        except Exception:
+            pass
+        os.environ["OMP_NUM_THREADS"] = str(max(1, cpus // world - 1))
     import torch
     import torch.distributed as dist
 
