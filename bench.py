@@ -5,34 +5,45 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 th
 driver launches one rank per GPU with torch.distributed.run.  Rank 0 prints ONE
 JSON line.
 
-Workload (BASELINE.json configs[1], "C1"): 1 M synthetic ONT-like reads, mean
-25 kb, G = 100e6, k=22 w=16 h=3 tile=1000, o=0.1.  The reads are generated on the
-GPU (grp_synth_reads): all inputs are resident in HBM before the timed region.
+Workload (default): BASELINE.json configs[2] "C2" — 10 M synthetic ONT-like reads,
+mean 25 kb, G = 3e9, k=22 w=16 h=3 tile=1000, o=0.1 (m = 61 146 729 472 bits), golden
+path mode, explicit -P.  `--config C1` is configs[1] (1 M reads, G = 100e6); N > 1 on
+C2 is configs[3] "C3" (the same stream shared by the ranks: strong scaling).  The
+reads are generated on the GPU (grp_synth_reads): all inputs are resident in HBM
+before the timed region.
 
 Untimed setup (reported under "aux"): bit-vector fill of all reads + rank build
 (phase 1 of goldrush-path, goldrush_path.cpp:1199-1205).
 
-A step = the order-exact classification of the next `--batch` x N reads of the
-stream (phase 2, goldrush_path.cpp:1229-1256, golden-path mode): every tile frame
-is hashed and probed (hash + miBF query), the read decisions are taken in file
-order and the accepted reads are inserted into the miBF *before* any later read
-is decided — bit-identical to the reference's serial loop, with speculative GPU
-windows in between (goldrush_amd/csrc/host/gr_classifier.cpp).  Warm-up steps
-are the first W batches of the same stream (the insert-heavy start of the path).
+Timed region = phase 2 over the WHOLE stream from read 0 on the freshly built miBF
+(goldrush_path.cpp:1229-1256): the stream is cut into K steps of reads/K reads; a
+step is the order-exact classification of its reads — every tile frame hashed and
+probed (hash + miBF query), decisions taken in file order, accepted reads inserted
+into the miBF *before* any later read is decided — bit-identical to the reference's
+serial loop (goldrush_amd/csrc/host/gr_classifier.cpp).  The insert-heavy head of the
+path is inside the timed region; "phases" reports the head (until the insert rate of
+a 16 k-read slice drops below 1 %) and the steady state separately.
+Warm-up steps run on a throw-away engine of a small geometry (kernel code objects,
+LDS attributes, allocator): they never touch the measured stream.
 
 metric  : reads/s through hash + miBF query (whole job, all ranks)
-roofline: the query kernel, ALGORITHMIC bytes = 128 B per probe (two 64-B HBM
-          sectors: bit+rank block, then ID), probes = frames x h; duration from
-          HIP events recorded around every launch on the library's own stream.
-cpu_baseline: the CPU oracle (restatement of the reference) on a bounded sample
-          of the same workload, rank 0, N=1 only.
+roofline: the query kernel.  `achieved` = ALGORITHMIC bytes (128 B per
+          probe = two 64-B sectors in the reference's layout) / kernel time from HIP
+          events around every launch on the library's own stream.  Beside it: the
+          bytes that actually move (`moved_*`, from the committed rocprofv3 PMC pass:
+          one 64-B bucket per probe) and the probe rate against the measured
+          random-64-B-line ceiling of the memory system (profiles/*gather_ceiling.json).
+cpu_baseline: the CPU oracle (restatement of the reference) on bounded samples of the
+          same workload, rank 0, N=1 only.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -43,6 +54,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PRESET = "1011011110110111101101"  # bin/goldrush:70
+PHASE_SLICE = 16384  # reads per timing slice inside a step (head / steady-state split)
+
+CONFIGS = {
+    # BASELINE.json configs[1]
+    "C1": {"reads": 1_000_000, "genome": 100e6, "h": 3, "name": "C1: 1M synthetic ONT reads, mean 25 kb, G=100e6"},
+    # configs[2] (N = 1) / configs[3] (N = 8, the same stream)
+    "C2": {"reads": 10_000_000, "genome": 3e9, "h": 3, "name": "C2: 10M synthetic ONT reads, mean 25 kb, G=3e9 (human-scale)"},
+}
 
 
 class ShmAllgather:
@@ -98,13 +117,22 @@ class ShmAllgather:
                 pass
 
 
-def cpu_baseline(dr, n_sample: int, m: int, seeds, k: int, tile: int, budget_s: float = 25.0):
+def _newest_profile(pattern: str):
+    """newest profiles/<pattern> by the numbers in its name (r02_v10_... sorts after r02_v9_...)"""
+    def _ver(path):
+        return [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=_ver)
+    return files[-1] if files else None
+
+
+def cpu_baseline(dr, n_sample: int, m: int, seeds, k: int, tile: int, genome: int, budget_s: float = 20.0):
     """The oracle's own serial loop (orc_path_process_read: hash, query, decide,
     insert; OpenMP over tiles like the reference) over the first reads of the
     same synthetic set, same filter size; reads/s of its classification phase."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc  # test infrastructure: used here only as the timed CPU baseline
-    from goldrush_amd import synth
+    from goldrush_amd import host, synth
 
     orc.build()
     reads = dr.download(0, n_sample)
@@ -112,10 +140,8 @@ def cpu_baseline(dr, n_sample: int, m: int, seeds, k: int, tile: int, budget_s: 
     os.makedirs(tmp, exist_ok=True)
     fq = os.path.join(tmp, "sample.fq")
     synth.write_fastq(fq, [(b"r%d" % i, s, b"5" * len(s)) for i, s in enumerate(reads)])
-    from goldrush_amd import host
-
     cores = int(host.load().gr_effective_cpus())  # affinity mask and cgroup quota
-    args = ["-k", str(k), "-w16", "-t", str(tile), "-h", str(len(seeds)), "-s", PRESET, "-g", "100000000", "-P10", "-d50", "-m0",
+    args = ["-k", str(k), "-w16", "-t", str(tile), "-h", str(len(seeds)), "-s", PRESET, "-g", str(genome), "-P10", "-d50", "-m0",
             "-j", str(cores), "-i", fq, "-p", os.path.join(tmp, "o")]
     p = orc.Path(args)
     assert p.ok and p.filter_size() == m
@@ -133,28 +159,66 @@ def cpu_baseline(dr, n_sample: int, m: int, seeds, k: int, tile: int, budget_s: 
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
     return {"value": done / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {done} reads of the same synthetic stream (filter filled with {n_sample} reads, same m={m}); oracle process_read loop "
+            "sample": f"head of the stream: first {done} reads (filter filled with the first {n_sample} reads only, same m={m}); oracle process_read loop "
                       f"(hash + query + decide + insert), OpenMP over tiles, {cores} threads",
             "fill_reads_per_s": n_sample / fill_s if fill_s > 0 else None}
+
+
+def warm_up(native, host, steps: int, device: int, h: int):
+    """W untimed steps on a throw-away engine (small geometry): loads every kernel of the
+    path, sets the LDS attributes, warms the allocator.  Never touches the measured stream."""
+    if steps <= 0:
+        return
+    k, w, tile = 22, 16, 1000
+    G = 2_000_000
+    hl = host.load()
+    seeds = host.make_seed_pattern(PRESET, k, w, h)
+    m = hl.gr_calc_optimal_size(hl.gr_hash_universe(w, G, h), 1, 0.1)
+    per = 512
+    dr = native.synth_reads(per * steps, G, mean_len=25000, min_len=20000)
+    eng = native.Engine(k, h, tile, m, seeds, device=device)
+    rb = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+    eng.bv_insert(rb)
+    eng.finalize()
+    cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=10, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
+                          target_bases=int(0.9 * G), max_paths=1, silver_path=False, record=False)
+    lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
+    for i in range(steps):
+        cls.run_range(rb._h, lens, i * per, per)
+    eng.sync()
+    cls.close()
+    rb.free()
+    eng.close()
+    dr.free()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--reads", type=int, default=1_000_000)
-    ap.add_argument("--genome", type=float, default=100e6)
-    ap.add_argument("--batch", type=int, default=8192, help="reads per GPU per step")
-    ap.add_argument("--h", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS), help="BASELINE.json workload (default C2; with --gpus 8 that is C3)")
+    ap.add_argument("--reads", type=int, default=0, help="override the config's read count")
+    ap.add_argument("--genome", type=float, default=0.0, help="override the config's genome size")
+    ap.add_argument("--batch", type=int, default=0, help="reads per step for the whole job (default reads // steps: the K steps cover the stream exactly once)")
+    ap.add_argument("--h", type=int, default=0)
     ap.add_argument("--max-window", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--trace", action="store_true", help="per-step timing / speculation statistics on stderr")
+    ap.add_argument("--trace", action="store_true", help="per-slice timing / speculation statistics on stderr")
     ap.add_argument("--no-kernel-timing", action="store_true", help="developer: no HIP events around the launches (roofline fields become meaningless)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for single-GPU plumbing tests)")
     ap.add_argument("--verify-ranks", action="store_true", help="developer: N > 1, compare the classifier state of all ranks after the run")
     ap.add_argument("--share-gpu", action="store_true", help="developer: all ranks use GPU 0 (plumbing test on a 1-GPU box, use with --backend gloo)")
     a = ap.parse_args()
+
+    cfg = dict(CONFIGS[a.config])
+    if a.reads:
+        cfg["reads"] = a.reads
+    if a.genome:
+        cfg["genome"] = a.genome
+    if a.h:
+        cfg["h"] = a.h
+    n_reads = cfg["reads"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -189,14 +253,23 @@ def main():
     coll_dev = "cuda" if a.backend == "nccl" else "cpu"
     from goldrush_amd import host, native
 
-    G, k, w, tile, h, block = int(a.genome), 22, 16, 1000, a.h, 10
+    G, k, w, tile, h, block = int(cfg["genome"]), 22, 16, 1000, cfg["h"], 10
     hl = host.load()
     seeds = host.make_seed_pattern(PRESET, k, w, h)
     m = hl.gr_calc_optimal_size(hl.gr_hash_universe(w, G, h), 1, 0.1)
 
+    per_step = a.batch if a.batch else n_reads // a.steps
+    if per_step < 1 or per_step * a.steps > n_reads:
+        raise SystemExit("--reads %d too small for %d steps of %d reads (the stream is never wrapped)" % (n_reads, a.steps, per_step))
+
+    # ---- warm-up: W steps on a throw-away engine ---------------------------------
+    t0 = time.time()
+    warm_up(native, host, a.warmup, local_rank, h)
+    t_warm = time.time() - t0
+
     # ---- untimed setup: inputs resident in HBM, phase 1 -------------------------
     t0 = time.time()
-    dr = native.synth_reads(a.reads, G)
+    dr = native.synth_reads(n_reads, G)
     eng = native.Engine(k, h, tile, m, seeds, device=local_rank)
     rb = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
     t_synth = time.time() - t0
@@ -207,8 +280,8 @@ def main():
     else:
         # the fill shards by reads; the merge is a bitwise OR, done as an
         # all-gather of the plain bit vectors (RCCL has no OR reduction) + local ORs
-        shard = (a.reads + world - 1) // world
-        lo, hi = min(rank * shard, a.reads), min((rank + 1) * shard, a.reads)
+        shard = (n_reads + world - 1) // world
+        lo, hi = min(rank * shard, n_reads), min((rank + 1) * shard, n_reads)
         eng.bv_insert(rb, lo, hi - lo)
         eng.sync()
         nbytes = eng.bv_words() * 4
@@ -228,7 +301,9 @@ def main():
         del allbv, mine
     t_fill = time.time() - t0
     fill_stats = eng.kernel_stats()["fill"]
+    t0 = time.time()
     pop = eng.finalize()
+    t_finalize = time.time() - t0
 
     # ---- phase 2: order-exact classification, windows sharded over the ranks ----
     allgather = None
@@ -285,26 +360,29 @@ def main():
     cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
                           target_bases=int(0.9 * G), max_paths=1, silver_path=False, max_window=a.max_window, world=world, rank=rank,
                           allgather=allgather, record=False)
-    per_step = a.batch * world
-    n_steps_avail = a.reads // per_step
-    if n_steps_avail < 1:
-        raise SystemExit("--reads too small for --batch")
     lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
+    slices = []  # (reads, seconds, inserts) per timing slice, rank 0's clock
 
     def step(i: int):
-        # the stream wraps around once exhausted (all of it is then on the path)
-        ts = time.perf_counter()
-        s0 = cls.state() if a.trace else None
-        cls.run_range(rb._h, lens, (i % n_steps_avail) * per_step, per_step)
-        if a.trace and rank == 0:
+        # one step = the next per_step reads of the stream, run as slices of PHASE_SLICE reads
+        # so that the head of the path and the steady state can be told apart
+        first = i * per_step
+        done = 0
+        while done < per_step:
+            n = min(PHASE_SLICE, per_step - done)
+            s0 = cls.state()
+            ts = time.perf_counter()
+            cls.run_range(rb._h, lens, first + done, n)
+            te = time.perf_counter()
             s1 = cls.state()
-            sys.stderr.write("step %d: %.1f ms windows=%d queried=%d inserts=%d\n" % (
-                i, (time.perf_counter() - ts) * 1e3, s1["windows"] - s0["windows"], s1["reads_queried"] - s0["reads_queried"], s1["inserts"] - s0["inserts"]))
+            slices.append((n, te - ts, s1["inserts"] - s0["inserts"]))
+            if a.trace and rank == 0:
+                sys.stderr.write("reads %d..%d: %.2f ms windows=%d queried=%d inserts=%d\n" % (
+                    first + done, first + done + n, (te - ts) * 1e3, s1["windows"] - s0["windows"], s1["reads_queried"] - s0["reads_queried"], s1["inserts"] - s0["inserts"]))
+            done += n
 
     if a.no_kernel_timing:
         eng.set_timing(False)
-    for i in range(a.warmup):
-        step(i)
     eng.sync()
     eng.reset_kernel_stats()
     st0 = cls.state()
@@ -313,7 +391,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        step(a.warmup + i)
+        step(i)
     eng.sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -340,27 +418,41 @@ def main():
         reads_done = a.steps * per_step
         avg_ms = kq["ms"] / max(kq["launches"], 1)
         probes_per_launch = kq["units"] / max(kq["launches"], 1)
-        achieved = kq["units"] * 128 / (kq["ms"] * 1e-3) / 1e9 if kq["ms"] > 0 else 0.0
+        kq_s = kq["ms"] * 1e-3
+        achieved = kq["units"] * 128 / kq_s / 1e9 if kq_s > 0 else 0.0
+        gprobes = kq["units"] / kq_s / 1e9 if kq_s > 0 else 0.0
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the
         # per-probe figure comes from the committed rocprofv3 --pmc pass of the same kernel
         # (newest profiles/r*_pmc_summary.json, tools/pmc_round.sh: TCC_EA0_RDREQ x 64 B = FETCH_SIZE x 1024 B)
-        traffic = None
+        traffic = bytes_per_probe_moved = None
+        pmc_file = _newest_profile("r*_pmc_summary.json")
         try:
-            import glob
-
-            import re
-
-            def _ver(path):  # r01_v10_... sorts after r01_v9_...
-                return [int(x) for x in re.findall(r"\d+", os.path.basename(path))]
-
-            newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=_ver)[-1]
-            pmc = json.load(open(newest))
-            if "k_query_all_variants" in pmc:
-                traffic = pmc["k_query_all_variants"]["hbm_bytes_per_probe"] * probes_per_launch
-            else:
-                traffic = pmc["k_query<3, 2, 0>"]["hbm_bytes_per_probe"] * probes_per_launch
+            pmc = json.load(open(pmc_file))
+            key = "k_query_all_variants" if "k_query_all_variants" in pmc else "k_query<3, 2, 0>"
+            bytes_per_probe_moved = pmc[key]["hbm_bytes_per_probe"]
+            traffic = bytes_per_probe_moved * probes_per_launch
         except Exception:
             pass
+        # the measured random-64-B-line ceiling of this memory system (tools/gather_bench.hip,
+        # archived by tools/profile_round.sh); null until a profile round has stored it
+        ceiling = ceiling_file = None
+        try:
+            ceiling_file = _newest_profile("r*_gather_ceiling.json")
+            ceiling = json.load(open(ceiling_file))["quad_64B_lines_Gps"]
+        except Exception:
+            pass
+        # head of the path: slices up to the first one whose insert rate is below 1 %
+        head_n = len(slices)
+        for i, (n, _, ins) in enumerate(slices):
+            if ins < 0.01 * n:
+                head_n = i
+                break
+        head_reads = sum(s[0] for s in slices[:head_n])
+        head_s = sum(s[1] for s in slices[:head_n])
+        head_ins = sum(s[2] for s in slices[:head_n])
+        tail_reads = sum(s[0] for s in slices[head_n:])
+        tail_s = sum(s[1] for s in slices[head_n:])
+        tail_ins = sum(s[2] for s in slices[head_n:])
         out = {
             "metric": "reads/s through GoldRush-Path (hash + miBF query)",
             "value": reads_done / dt,
@@ -370,27 +462,40 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "C1: 1M synthetic ONT reads, mean 25 kb, G=100e6, k=22 w=16 h=%d tile=1000 o=0.1, golden-path mode, order-exact" % h,
-                       "reads": a.reads, "batch_reads_per_gpu": a.batch, "filter_bits": m, "pop": pop,
-                       "parallelism": ("one GPU, streaming windows" if world == 1 else "windows striped over %d GPUs (128-read stripes), replicated miBF, 32-B decisions all-gathered per stripe group" % world)},
+            "config": {"workload": "%s%s, k=22 w=16 h=%d tile=1000 o=0.1 -P10, golden-path mode, order-exact, whole stream from read 0 (insert-heavy head included)" % (
+                           cfg["name"], " [C3: stream shared by %d GPUs]" % world if (world > 1 and a.config == "C2") else "", h),
+                       "reads": n_reads, "reads_timed": reads_done, "reads_per_step": per_step, "genome": G, "filter_bits": m, "pop": pop,
+                       "parallelism": ("one GPU, streaming windows" if world == 1 else "windows striped over %d GPUs, replicated miBF, 32-B decisions all-gathered per stripe group" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC pass of the same kernel, scaled by probes)", "kernel": "k_query", "launches": kq["launches"], "avg_launch_ms": avg_ms,
-                         "probes_per_launch": probes_per_launch, "bytes_per_probe": 128},
-            "aux": {"fill_reads_per_s": a.reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill,
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC pass of the same kernel, %s, scaled by probes)" % (os.path.basename(pmc_file) if pmc_file else "none"),
+                         "kernel": "k_query", "launches": kq["launches"], "avg_launch_ms": avg_ms,
+                         "probes_per_launch": probes_per_launch, "bytes_per_probe": 128,
+                         "note": "achieved/frac use the ALGORITHMIC 128 B per probe of SURVEY 8(d) (the reference's two-sector probe); this layout moves one 64-B bucket per probe, see moved_*; the kernel's real bound is the random-line rate, see line_rate_*",
+                         "moved_bytes_per_probe": bytes_per_probe_moved,
+                         "moved_GBps": (bytes_per_probe_moved * gprobes if bytes_per_probe_moved else None),
+                         "moved_frac_of_peak": (bytes_per_probe_moved * gprobes / HBM_PEAK_GBPS if bytes_per_probe_moved else None),
+                         "line_rate_Gprobes_per_s": gprobes,
+                         "line_rate_ceiling_Gps": ceiling, "line_rate_ceiling_source": (os.path.basename(ceiling_file) if ceiling_file else None),
+                         "line_rate_frac": (gprobes / ceiling if ceiling else None)},
+            "phases": {"slice_reads": PHASE_SLICE,
+                       "head": {"reads": head_reads, "seconds": head_s, "reads_per_s": head_reads / head_s if head_s > 0 else None, "inserts": head_ins,
+                                "definition": "slices before the first %d-read slice with an insert rate < 1 %%" % PHASE_SLICE},
+                       "steady": {"reads": tail_reads, "seconds": tail_s, "reads_per_s": tail_reads / tail_s if tail_s > 0 else None, "inserts": tail_ins}},
+            "aux": {"fill_reads_per_s": n_reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill, "finalize_s": t_finalize,
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors all-gathered and OR-merged" % world, "synth_s": t_synth,
+                    "warmup_s": t_warm, "warmup_mode": "%d steps of 512 reads on a throw-away engine (G=2e6)" % a.warmup,
                     "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit")},
-                    "query_Gprobes_per_s": kq["units"] / (kq["ms"] * 1e-3) / 1e9 if kq["ms"] > 0 else 0.0,
-                    "random_64B_line_ceiling_Gps": 50.0,  # tools/gather_bench.hip on MI355X: 48-55 G random 64-byte lines/s (one line per probe)
-                    "query_kernel_s": kq["ms"] * 1e-3, "decide_kernel_s": ks["decide"]["ms"] * 1e-3, "decide_launches": ks["decide"]["launches"],
+                    "query_Gprobes_per_s": gprobes,
+                    "query_kernel_s": kq_s, "decide_kernel_s": ks["decide"]["ms"] * 1e-3, "decide_launches": ks["decide"]["launches"],
                     "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
                     "wall_s": dt},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dr, 1024, m, seeds, k, tile)
+            out["cpu_baseline"] = cpu_baseline(dr, 1024, m, seeds, k, tile, G)
         print(json.dumps(out), flush=True)
     if world > 1:
         if shm is not None:

@@ -38,11 +38,12 @@ k_synth(grp_synth_params p,
         uint32_t* __restrict__ out,
         uint32_t th_sub,
         uint32_t th_ins,
-        uint32_t th_del)
+        uint32_t th_del,
+        uint32_t r0)
 {
   __shared__ uint8_t sBuf[16 + 2 * T + 16];
   __shared__ uint32_t sScan[T];
-  const uint32_t r = blockIdx.x;
+  const uint32_t r = r0 + blockIdx.x;
   const uint32_t L = len[r];
   const uint64_t s0 = start[r] % p.genome_len;
   const bool rev = strand[r] != 0;
@@ -172,8 +173,12 @@ grp_synth_reads(const grp_synth_params* p,
   if ((e = hipMemcpy(d_len, len, (size_t)n * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
   if ((e = hipMemcpy(d_strand, strand, (size_t)n, hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy", e);
   const float sc = 1048576.0f; // 2^20
-  k_synth<<<dim3(n), dim3(T), 0, stream>>>(*p, d_start, d_len, d_strand, d_off, static_cast<uint32_t*>(d_out), (uint32_t)(p->p_sub * sc), (uint32_t)(p->p_ins * sc), (uint32_t)(p->p_del * sc));
-  if ((e = hipGetLastError()) != hipSuccess) return fail("k_synth launch", e);
+  // a grid holds fewer than 2^32 work-items: slices of 2^22 reads
+  for (uint32_t r0 = 0; r0 < n; r0 += (1u << 22)) {
+    const uint32_t nr = n - r0 < (1u << 22) ? n - r0 : (1u << 22);
+    k_synth<<<dim3(nr), dim3(T), 0, stream>>>(*p, d_start, d_len, d_strand, d_off, static_cast<uint32_t*>(d_out), (uint32_t)(p->p_sub * sc), (uint32_t)(p->p_ins * sc), (uint32_t)(p->p_del * sc), r0);
+    if ((e = hipGetLastError()) != hipSuccess) return fail("k_synth launch", e);
+  }
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail("k_synth", e);
   (void)hipFree(d_start);
   (void)hipFree(d_off);

@@ -208,6 +208,9 @@ constexpr uint64_t LIST_PREFIX = 8192; // list entries copied back together with
 constexpr uint32_t SMALL_TILES = 512;  // windows up to this many tiles use the direct (zero-copy) path
 constexpr uint32_t SMALL_STRIDE = 32;  // list entries per tile in the direct path
 constexpr int THREADS = 256;
+// A HIP grid holds fewer than 2^32 work-items per dimension (larger ones are truncated
+// modulo 2^32 without an error): no launch of 256-lane workgroups exceeds this many
+constexpr uint32_t MAX_GRID_WGS = 1u << 22;
 
 // ---- ntHash (btllib::SeedNtHash, restated; see DESIGN.md "Hash") -----------
 
@@ -888,9 +891,9 @@ grp_bv_insert(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count)
       }
     }
   }
-  // launch in slices of at most 2^30 workgroups
+  // launch in slices of at most MAX_GRID_WGS workgroups
   for (uint64_t b = ch0; b < ch1;) {
-    uint32_t nb = (uint32_t)std::min<uint64_t>(ch1 - b, 1u << 30);
+    uint32_t nb = (uint32_t)std::min<uint64_t>(ch1 - b, MAX_GRID_WGS);
     Timer t(c, GRP_K_FILL, b == ch0 ? probes : 0);
     DISPATCH_H(c->params.h, (k_fill<HH><<<dim3(nb), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, b)));
     HIP_TRY(c, hipGetLastError());
@@ -993,6 +996,10 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
   }
   c->n_chunks = (c->f.n_buckets + GRP_CHUNK_BUCKETS - 1) / GRP_CHUNK_BUCKETS;
   c->nsb = ((c->f.n_buckets - 1) >> GRP_SUPER_SHIFT) + 1;
+  if (c->n_chunks > MAX_GRID_WGS) {
+    delete t;
+    return set_err(c, GRP_ERR_INVALID, "filter of %llu buckets exceeds the rank builder's launch size", (unsigned long long)c->f.n_buckets);
+  }
   uint32_t* d_chunk_sum = nullptr;
   uint64_t* d_chunk_base = nullptr;
   hipError_t e = hipMalloc(&c->f.buckets, c->f.n_buckets * 64);
@@ -1183,8 +1190,8 @@ grp_query_tiles(grp_ctx* c,
   if (nt == 0) {
     return GRP_OK;
   }
-  if (nt > (1u << 30)) {
-    return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: %llu tiles in one call (limit 2^30)", (unsigned long long)nt);
+  if (nt > MAX_GRID_WGS) {
+    return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: %llu tiles in one call (limit 2^22)", (unsigned long long)nt);
   }
   if (!tiles_out) {
     return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: tiles_out is NULL");
@@ -1427,8 +1434,8 @@ classify_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, c
   }
   HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t nt = r->tile0[first + count] - r->tile0[first];
-  if (nt > (1u << 30)) {
-    return set_err(c, GRP_ERR_INVALID, "grp_classify_reads: %llu tiles in one call (limit 2^30)", (unsigned long long)nt);
+  if (nt > MAX_GRID_WGS) {
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_reads: %llu tiles in one call (limit 2^22)", (unsigned long long)nt);
   }
   sl.reads = r;
   sl.first = first;
@@ -1888,8 +1895,7 @@ grp_reset_ids(grp_ctx* c)
     return set_err(c, GRP_ERR_STATE, "grp_reset_ids before grp_finalize");
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  const uint64_t n4 = c->f.n_buckets * 4;
-  k_reset_bucket_ids<<<dim3((uint32_t)((n4 + THREADS - 1) / THREADS)), dim3(THREADS), 0, c->stream>>>(c->f.buckets, c->f.n_buckets);
+  k_reset_bucket_ids<<<dim3(65536), dim3(THREADS), 0, c->stream>>>(c->f.buckets, c->f.n_buckets);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemsetAsync(c->f.counts, 0, std::max<uint64_t>(c->f.pop, 1) * sizeof(uint32_t), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->f.ovf_keys, 0, (c->f.ovf_mask + 1) * sizeof(unsigned long long), c->stream));
@@ -1939,7 +1945,7 @@ grp_export_bits(grp_ctx* c, uint64_t* words, uint64_t n_words)
   uint32_t* d = nullptr;
   HIP_TRY(c, hipMalloc(&d, (n_words * 2 + 3) * 4));
   HIP_TRY(c, hipMemsetAsync(d, 0, (n_words * 2 + 3) * 4, c->stream));
-  k_export_bits<<<dim3((uint32_t)((c->f.n_buckets + 255) / 256)), dim3(256), 0, c->stream>>>(c->f.buckets, c->f.n_buckets, c->f.W, d);
+  k_export_bits<<<dim3((uint32_t)std::min<uint64_t>((c->f.n_buckets + 255) / 256, MAX_GRID_WGS)), dim3(256), 0, c->stream>>>(c->f.buckets, c->f.n_buckets, c->f.W, d);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(words, d, n_words * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1992,7 +1998,7 @@ grp_export_ids(grp_ctx* c, uint64_t first, uint64_t n, uint32_t* ids, uint32_t* 
   uint32_t *d_ids = nullptr, *d_cnt = nullptr;
   HIP_TRY(c, hipMalloc(&d_ids, n * 4));
   HIP_TRY(c, hipMalloc(&d_cnt, n * 4));
-  k_export_ids<<<dim3((uint32_t)((c->f.n_buckets + 255) / 256)), dim3(256), 0, c->stream>>>(c->f, first, n, d_ids, d_cnt);
+  k_export_ids<<<dim3((uint32_t)std::min<uint64_t>((c->f.n_buckets + 255) / 256, MAX_GRID_WGS)), dim3(256), 0, c->stream>>>(c->f, first, n, d_ids, d_cnt);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(ids, d_ids, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(counts, d_cnt, n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2021,7 +2027,7 @@ grp_import_ids(grp_ctx* c, uint64_t first, uint64_t n, const uint32_t* ids, cons
     HIP_TRY(c, hipMalloc(&d_cnt, n * 4));
     HIP_TRY(c, hipMemcpyAsync(d_cnt, counts, n * 4, hipMemcpyHostToDevice, c->stream));
   }
-  k_import_ids<<<dim3((uint32_t)((c->f.n_buckets + 255) / 256)), dim3(256), 0, c->stream>>>(c->f, first, n, d_ids, d_cnt);
+  k_import_ids<<<dim3((uint32_t)std::min<uint64_t>((c->f.n_buckets + 255) / 256, MAX_GRID_WGS)), dim3(256), 0, c->stream>>>(c->f, first, n, d_ids, d_cnt);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   (void)hipFree(d_ids);
@@ -2055,6 +2061,41 @@ grp_debug_tile_hashes(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_
   HIP_TRY(c, hipMemcpyAsync(out, d, nv * 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   (void)hipFree(d);
+  return GRP_OK;
+}
+
+int
+grp_debug_locate(grp_ctx* c, const uint64_t* x, uint64_t n, uint64_t m, uint32_t W, int on_device, uint64_t* mod_out, uint64_t* div_out)
+{
+  if (!x || !mod_out || !div_out || m == 0 || W < GRP_BUCKET_IDS || W > 64 || (on_device && !c)) {
+    return set_err(c, GRP_ERR_INVALID, "grp_debug_locate: bad argument");
+  }
+  const uint64_t m_inv = ~0ULL / m;                                               // as grp_create
+  const uint64_t w_magic = (uint64_t)((((unsigned __int128)1) << 64) / W) + 1;   // as grp_finalize
+  if (!on_device) {
+    for (uint64_t i = 0; i < n; ++i) {
+      mod_out[i] = grp_mod_m(x[i], m, m_inv);
+      div_out[i] = grp_div_w(mod_out[i], w_magic);
+    }
+    return GRP_OK;
+  }
+  if (n == 0) {
+    return GRP_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  uint64_t *d_x = nullptr, *d_mod = nullptr, *d_div = nullptr;
+  HIP_TRY(c, hipMalloc(&d_x, n * 8));
+  HIP_TRY(c, hipMalloc(&d_mod, n * 8));
+  HIP_TRY(c, hipMalloc(&d_div, n * 8));
+  HIP_TRY(c, hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, c->stream));
+  k_debug_locate<<<dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream>>>(d_x, n, m, m_inv, W, w_magic, d_mod, d_div);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(mod_out, d_mod, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(div_out, d_div, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_x);
+  (void)hipFree(d_mod);
+  (void)hipFree(d_div);
   return GRP_OK;
 }
 

@@ -104,6 +104,7 @@ SIGNATURES = {
     "grp_import_ids": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, _vp]),
     "grp_debug_tile_hashes": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "grp_debug_tile_states": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
+    "grp_debug_locate": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
     "grp_set_timing": (C.c_int, [_vp, C.c_int]),
     "grp_get_kernel_stats": (C.c_int, [_vp, C.POINTER(grp_kernel_stat)]),
     "grp_reset_kernel_stats": (C.c_int, [_vp]),
@@ -483,6 +484,10 @@ class Engine:
         self._check(self.lib.grp_debug_tile_hashes(self._h, batch._h, read_idx, tile_idx, _ptr(out), cap, C.byref(nv)))
         return out[: nv.value]
 
+    def debug_locate(self, x, m: int, W: int, on_device: bool = True):
+        """(x % m, (x % m) // W) through the kernels' reciprocal / magic-number shortcuts."""
+        return debug_locate(x, m, W, on_device, self)
+
     # -- measurement
     def kernel_stats(self) -> dict:
         arr = (grp_kernel_stat * GRP_K_COUNT)()
@@ -494,6 +499,18 @@ class Engine:
 
     def set_timing(self, on: bool):
         self._check(self.lib.grp_set_timing(self._h, 1 if on else 0))
+
+
+def debug_locate(x, m: int, W: int, on_device: bool = False, engine: "Engine | None" = None):
+    """grp_debug_locate: the host instantiation needs no engine (and no GPU)."""
+    lib = load()
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    mod = np.zeros(x.size, dtype=np.uint64)
+    div = np.zeros(x.size, dtype=np.uint64)
+    rc = lib.grp_debug_locate(engine._h if engine is not None else None, _ptr(x), x.size, m, W, 1 if on_device else 0, _ptr(mod), _ptr(div))
+    if rc != GRP_OK:
+        raise GrpError(rc, (lib.grp_last_error(engine._h if engine is not None else None) or b"").decode())
+    return mod, div
 
 
 # ---------------------------------------------------------------------------

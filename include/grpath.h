@@ -388,6 +388,14 @@ int grp_debug_tile_hashes(grp_ctx* ctx,
                           uint64_t cap,
                           uint64_t* n_values);
 
+/* The two exact-arithmetic shortcuts of a probe, for adversarial tests:
+ *   mod_out[i] = x[i] % m   through the reciprocal multiply the kernels use in place of
+ *                           MIBloomFilter.hpp:468 `hashes[i] % m_bv.size()`
+ *   div_out[i] = mod_out[i] / W   through the bucket-index magic multiply (W in [13,64])
+ * on_device = 0: the host instantiation of the same inline functions (ctx may be NULL);
+ * on_device = 1: a kernel on ctx's device (the __umul64hi instantiation). */
+int grp_debug_locate(grp_ctx* ctx, const uint64_t* x, uint64_t n, uint64_t m, uint32_t W, int on_device, uint64_t* mod_out, uint64_t* div_out);
+
 /* per-tile IDs / assigned flags after the smoothing passes of the LAST
  * grp_classify_reads window (tiles in window order); n_tiles = tiles of that window */
 int grp_debug_tile_states(grp_ctx* ctx, uint64_t n_tiles, uint32_t* ids, uint8_t* assigned);

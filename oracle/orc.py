@@ -97,6 +97,7 @@ def load():
         "orc_mibf_bit": (C.c_int, [vp, u64]), "orc_mibf_rank": (u64, [vp, u64]),
         "orc_mibf_reset_ids": (None, [vp]),
         "orcpy_bv_insert_read": (None, [vp, vp, C.c_uint, C.c_char_p, sz]),
+        "orcpy_bv_insert_reads": (None, [vp, vp, C.c_uint, vp, vp, sz]),
         "orcpy_insert_read_tiles": (None, [vp, vp, C.c_uint, C.c_char_p, sz, sz, sz, sz, sz, u32]),
         "orcpy_mibf_bv": (vp, [vp]), "orcpy_mibf_n_words": (u64, [vp]), "orcpy_mibf_pop": (u64, [vp]),
         "orcpy_mibf_data": (vp, [vp]), "orcpy_mibf_counts": (vp, [vp]), "orcpy_mibf_m": (u64, [vp]),
@@ -222,6 +223,13 @@ class MiBF:
 
     def bv_insert_read(self, seq: bytes):
         self.lib.orcpy_bv_insert_read(self._h, self.seeds._h, self.h, seq, len(seq))
+
+    def bv_insert_reads(self, seqs):
+        """insertBV of many reads, OpenMP over the reads (the reference's fill loop is parallel too)"""
+        n = len(seqs)
+        arr = (C.c_char_p * n)(*seqs)
+        lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+        self.lib.orcpy_bv_insert_reads(self._h, self.seeds._h, self.h, C.cast(arr, C.c_void_p), _p(lens), n)
 
     def finalize(self) -> int:
         self.lib.orc_mibf_finalize(self._h)

@@ -51,6 +51,19 @@ orcpy_bv_insert_read(orc_mibf* f, const orc_seed* seeds, unsigned h, const char*
   free(hv);
 }
 
+/* the same for n reads, OpenMP over the reads like the reference's fill loop
+ * (goldrush_path.cpp:257-305: insertBV is called from an `omp parallel` region) */
+void
+orcpy_bv_insert_reads(orc_mibf* f, const orc_seed* seeds, unsigned h, const char* const* seqs, const size_t* lens, size_t n)
+{
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+  for (size_t i = 0; i < n; ++i) {
+    orcpy_bv_insert_read(f, seeds, h, seqs[i], lens[i]);
+  }
+}
+
 /* insertMIBF for tiles [start,end) of one read (goldrush_path.cpp:988-989) */
 void
 orcpy_insert_read_tiles(orc_mibf* f, const orc_seed* seeds, unsigned h, const char* seq, size_t len, size_t tile_size, size_t k, size_t start, size_t end, uint32_t id)

@@ -12,21 +12,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_line_has_the_contract_fields():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--reads", "60000", "--batch", "4096"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C1", "--steps", "3", "--warmup", "2", "--reads", "60000", "--batch", "4096"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-                "roofline", "cpu_baseline"):
+                "roofline", "cpu_baseline", "phases"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "strong"
     assert d["unit"] == "reads/s" and d["value"] > 0 and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     assert abs(d["value"] - 3 * 4096 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1
     assert rf["traffic"] is None or rf["traffic"] > 0
+    assert rf["bytes_per_probe"] == 128 and rf["line_rate_Gprobes_per_s"] > 0
+    ph = d["phases"]
+    assert ph["head"]["reads"] + ph["steady"]["reads"] == 3 * 4096 and d["config"]["reads_timed"] == 3 * 4096
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "reads/s" and cb["sample"]
