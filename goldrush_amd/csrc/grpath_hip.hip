@@ -94,9 +94,39 @@ struct QuerySlot
   uint64_t t0 = 0, nt = 0, probes = 0;
 };
 
+// buffers of the ordered commit loop (grp_commit_loop_*)
+struct LoopRun
+{
+  bool busy = false;
+  uint32_t first = 0, count = 0;
+  hipEvent_t done = nullptr;
+  uint32_t* d_ctl = nullptr;
+  uint32_t* h_ctl_stage = nullptr; // pinned: [0..) initial control block, [LC_WORDS..) the final one
+  uint32_t* h_ctl = nullptr;       // mapped, coherent: committed count / status / stop request
+  uint32_t* dmap_ctl = nullptr;
+  uint32_t* d_tiles_done = nullptr;
+  uint64_t tiles_done_cap = 0;
+  uint32_t* d_ready = nullptr;
+  uint64_t ready_cap = 0;
+  grp_read_decision* d_rec = nullptr;
+  uint64_t rec_cap = 0;
+  grp_read_decision* h_rec = nullptr; // mapped, coherent
+  grp_read_decision* dmap_rec = nullptr;
+  uint64_t h_rec_cap = 0;
+  grp_tile_summary* d_tiles = nullptr;
+  uint64_t tiles_cap = 0;
+  grp_id_count* d_lists = nullptr;
+  uint64_t lists_cap = 0;
+  unsigned long long* d_trace = nullptr;
+  uint64_t trace_cap = 0;
+};
+
 struct grp_ctx
 {
   int device = 0;
+  std::string arch;
+  bool coherent_arch = false; // gfx942 / gfx950: agent-scope accesses are served by the memory side
+  LoopRun loop;
   hipStream_t stream = nullptr;
   // decision kernel + copy-back of a pipelined window run here, next to the following
   // window's query kernel on `stream`
@@ -234,6 +264,7 @@ const uint64_t BASE_SEED[4] = { 0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x
 } // namespace
 
 #include "grp_kernels.inc"
+#include "grp_loop.inc"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -571,6 +602,8 @@ grp_create(const grp_params* p, grp_ctx** out)
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, c->device));
     c->n_cus = prop.multiProcessorCount;
+    c->arch = prop.gcnArchName;
+    c->coherent_arch = c->arch.compare(0, 5, "gfx94") == 0 || c->arch.compare(0, 5, "gfx95") == 0;
   }
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -667,6 +700,28 @@ grp_destroy(grp_ctx* c)
     }
     (void)hipFree(sl.d_tiles_done);
     (void)hipFree(sl.d_executed);
+  }
+  {
+    LoopRun& lp = c->loop;
+    (void)hipFree(lp.d_ctl);
+    if (lp.h_ctl_stage) {
+      (void)hipHostFree(lp.h_ctl_stage);
+    }
+    if (lp.h_ctl) {
+      (void)hipHostFree(lp.h_ctl);
+    }
+    if (lp.h_rec) {
+      (void)hipHostFree(lp.h_rec);
+    }
+    if (lp.done) {
+      (void)hipEventDestroy(lp.done);
+    }
+    (void)hipFree(lp.d_tiles_done);
+    (void)hipFree(lp.d_ready);
+    (void)hipFree(lp.d_rec);
+    (void)hipFree(lp.d_tiles);
+    (void)hipFree(lp.d_lists);
+    (void)hipFree(lp.d_trace);
   }
   (void)hipFree(c->d_ntc);
   (void)hipFree(c->d_ntc_chunks);
@@ -2160,5 +2215,6 @@ grp_stream(grp_ctx* c)
 
 } // extern "C"
 
+#include "grp_loop_host.inc"
 #include "grp_ingest.inc"
 #include "grp_ntcard.inc"

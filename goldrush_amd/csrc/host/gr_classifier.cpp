@@ -457,7 +457,7 @@ Classifier::silver_path_check(int& rc)
 
 // returns true when the read changed the miBF (everything queried after it is stale)
 bool
-Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_decision& d, int& rc)
+Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_decision& d, int& rc, bool engine_inserted, uint32_t engine_first_id)
 {
   const uint32_t len = lens[r];
   const uint32_t tile = p_.tile_length, block = p_.block_size, k = p_.kmer_size;
@@ -481,7 +481,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
   bool inserted = false;
 
   auto insert_block = [&](uint32_t ts, uint32_t te, uint32_t id) {
-    if (rc != GRP_OK) {
+    if (rc != GRP_OK || engine_inserted) {
       return;
     }
     int e = vt_.insert_tiles(ctx_, reads, base_ + r, ts, te, id);
@@ -493,6 +493,14 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
 
   // all ID blocks of the read in one engine call (same result as the block loop)
   auto insert_read = [&](uint32_t ts, uint32_t te_excl, uint32_t id_offset) {
+    if (engine_inserted) {
+      // the commit loop on the device allocated the same ID from the same counter
+      if (engine_first_id != ids_inserted_) {
+        rc = GRP_ERR_STATE;
+        err_ = "commit loop: the device allocated block ID " + std::to_string(engine_first_id) + ", the host " + std::to_string(ids_inserted_);
+      }
+      return;
+    }
     int e = vt_.insert_read(ctx_, reads, base_ + r, ts, te_excl, block, ids_inserted_, id_offset);
     if (e != GRP_OK) {
       rc = e;
@@ -505,7 +513,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       // :978-1011
       ++ids_inserted_;
       ev.first_id = ids_inserted_;
-      if (vt_.insert_read) {
+      if (vt_.insert_read || engine_inserted) {
         insert_read(0, nt, 0);
       } else {
         for (uint32_t bs = 0; bs < nt; bs += block) {
@@ -537,7 +545,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       const uint32_t ts = d.trim_start, te = d.trim_end;
       ++ids_inserted_;
       ev.first_id = ids_inserted_;
-      if (vt_.insert_read) {
+      if (vt_.insert_read || engine_inserted) {
         insert_read(ts, te + 1, 1);
       } else {
         for (uint64_t bs = ts; bs <= te; bs += block) {
@@ -579,17 +587,22 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
 // one read of the current range: the reads filtered out before it only advance the
 // counter, then process_read's tail; keeps the insert-rate estimates up to date
 bool
-Classifier::commit_one(uint32_t r, const gr_read_decision& d, int& rc)
+Classifier::commit_one(uint32_t r, const gr_read_decision& d, int& rc, bool engine_inserted, uint32_t engine_first_id)
 {
   if (rg_.skipped_before) {
     skip_reads(rg_.skipped_before[r]);
   }
-  const bool ins = commit(rg_.reads, rg_.lens, r, d, rc);
+  const uint64_t path_before = curr_path_;
+  const bool ins = commit(rg_.reads, rg_.lens, r, d, rc, engine_inserted, engine_first_id);
   if (rc != GRP_OK) {
     return ins;
   }
   ++n_committed_;
   p_insert_ += (1.0 / 32.0) * ((ins ? 1.0 : 0.0) - p_insert_);
+  p_insert_mid_ += (1.0 / 256.0) * ((ins ? 1.0 : 0.0) - p_insert_mid_);
+  if (curr_path_ != path_before) {
+    p_insert_ = p_insert_mid_ = 1.0; // a new silver path starts on an empty ID array: every read inserts
+  }
   p_insert_slow_ += (1.0 / 8192.0) * ((ins ? 1.0 : 0.0) - p_insert_slow_);
   p_redo_ -= p_redo_ / 4096.0; // forgotten slowly where no streaming window measures it
   n_inserts_ += ins ? 1 : 0;
@@ -645,6 +658,166 @@ Classifier::stream_decision(uint32_t j, gr_read_decision& d)
   }
   d = stripe_recv_[j - group_base_];
   return GRP_OK;
+}
+
+bool
+Classifier::can_loop() const
+{
+  const char* e = getenv("GRP_LOOP");
+  return vt_.loop_begin && vt_.loop_stop && vt_.loop_poll && vt_.loop_end && !loop_disabled_ && !(e && !strcmp(e, "off"));
+}
+
+// The device-side commit loop pays ~25 us per inserting read and nothing per launch and
+// read beyond that; the streaming windows pay ~120 us per insert (abort, drain, relaunch)
+// but query at the full rate in between.  Enter the loop above ~4 % inserting reads,
+// leave it below ~1.5 % (measured on MI355X, C1 / C2 streams).
+bool
+Classifier::want_loop() const
+{
+  if (!can_loop()) {
+    return false;
+  }
+  const char* e = getenv("GRP_LOOP");
+  if (e && !strcmp(e, "force")) {
+    return true;
+  }
+  static const double p_in = [] {
+    const char* v = getenv("GRP_LOOP_ENTER");
+    return v ? atof(v) : 0.04;
+  }();
+  static const double p_out = [] {
+    const char* v = getenv("GRP_LOOP_LEAVE");
+    return v ? atof(v) : 0.015;
+  }();
+  return p_insert_mid_ >= (in_loop_ ? p_out : p_in);
+}
+
+// ---- commit loop on the device: the host only replays the records ---------------------
+int
+Classifier::loop_round(uint32_t& pos)
+{
+  const uint32_t n = rg_.n;
+  static const uint32_t max_range = [] { // reads per launch (developer hook)
+    const char* e = getenv("GRP_LOOP_RANGE");
+    return e ? (uint32_t)atol(e) : 65536u;
+  }();
+  const uint32_t S = std::min<uint32_t>(n - pos, std::max<uint32_t>(max_range, 1u));
+  grp_loop_params lp{};
+  lp.struct_size = sizeof(lp);
+  lp.decide = grp_decide_params{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
+  lp.block_tiles = p_.block_size;
+  lp.silver_path = p_.silver_path ? 1u : 0u;
+  lp.ids_inserted = ids_inserted_;
+  lp.max_depth = 0;
+  lp.target_bases = p_.target_bases;
+  lp.inserted_bases = inserted_bases_;
+  const gr_read_decision* rec = nullptr;
+  const volatile uint32_t* com = nullptr;
+  int rc = vt_.loop_begin(ctx_, rg_.reads, base_ + pos, S, &lp, &rec, &com);
+  if (rc != GRP_OK) {
+    err_ = std::string("loop_begin: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+    return rc;
+  }
+  ++n_windows_;
+  ++n_loops_;
+  in_loop_ = true;
+  const char* force_env = getenv("GRP_LOOP");
+  const bool forced = force_env && !strcmp(force_env, "force");
+  uint32_t consumed = 0, spins = 0;
+  bool stop_sent = false, ended = false, rolled = false;
+  while (rc == GRP_OK) {
+    const uint32_t status = __atomic_load_n(const_cast<const uint32_t*>(com) + 1, __ATOMIC_ACQUIRE);
+    const uint32_t c = __atomic_load_n(const_cast<const uint32_t*>(com), __ATOMIC_ACQUIRE);
+    while (consumed < c && rc == GRP_OK && !finished_) {
+      gr_read_decision d = rec[consumed];
+      const uint32_t first_id = d.pad;
+      d.pad = 0;
+      const uint64_t path_before = curr_path_;
+      commit_one(pos + consumed, d, rc, true, first_id);
+      ++consumed;
+      rolled = rolled || curr_path_ != path_before;
+      if (!stop_sent && !forced && !rolled && p_insert_mid_ < 0.015 && !want_loop()) {
+        (void)vt_.loop_stop(ctx_); // the insert-heavy stretch is over: the windows are faster from here
+        stop_sent = true;
+      }
+    }
+    if (rc != GRP_OK || finished_ || rolled) {
+      break; // a rollover ends the launch on the device as well (status ROLLOVER)
+    }
+    if (status != 0 && consumed == c) {
+      // the count is written before the status: nothing more will come
+      if (__atomic_load_n(const_cast<const uint32_t*>(com), __ATOMIC_ACQUIRE) == consumed) {
+        break;
+      }
+      continue;
+    }
+    if (consumed == c) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xFFFFu) == 0) {
+        const int st = vt_.loop_poll(ctx_);
+        if (st < 0) {
+          rc = st;
+          err_ = std::string("loop_poll: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+        } else if (st == 1) {
+          if (ended) { // the launch is over and a full round of spinning brought nothing new
+            break;
+          }
+          ended = true;
+        }
+      }
+    }
+  }
+  grp_loop_result res{};
+  const int erc = vt_.loop_end(ctx_, &res);
+  if (rc == GRP_OK && erc != GRP_OK) {
+    rc = erc;
+    err_ = std::string("loop_end: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+  }
+  n_loop_reads_ += consumed;
+  if (avg_probes_per_read_ > 0) {
+    n_queried_ += (uint64_t)((double)res.probes / avg_probes_per_read_ + 0.5);
+  }
+  if (rc == GRP_OK && !finished_ && !rolled) {
+    // records that arrived between the last look and the end of the launch
+    while (consumed < res.reads_committed && rc == GRP_OK && !finished_ && !rolled) {
+      gr_read_decision d = rec[consumed];
+      const uint32_t first_id = d.pad;
+      d.pad = 0;
+      const uint64_t path_before = curr_path_;
+      commit_one(pos + consumed, d, rc, true, first_id);
+      ++consumed;
+      rolled = curr_path_ != path_before;
+    }
+  }
+  if (rc == GRP_OK && consumed != res.reads_committed) {
+    rc = GRP_ERR_STATE;
+    err_ = "commit loop: the device committed " + std::to_string(res.reads_committed) + " reads, the host replayed " + std::to_string(consumed);
+  }
+  if (rc == GRP_OK && !rolled && !finished_ && res.status != GRP_LOOP_TIMEOUT && (res.ids_inserted != ids_inserted_ || res.inserted_bases != inserted_bases_)) {
+    rc = GRP_ERR_STATE;
+    err_ = "commit loop: device and host disagree on the ID / base counters";
+  }
+  if (rc == GRP_OK && (rolled || finished_) && res.status != GRP_LOOP_ROLLOVER) {
+    rc = GRP_ERR_STATE;
+    err_ = "commit loop: the host rolled the silver path over, the device did not";
+  }
+  pos += consumed;
+  if (rc != GRP_OK) {
+    return rc;
+  }
+  if (res.status == GRP_LOOP_TIMEOUT) {
+    loop_disabled_ = true; // the device is shared with another persistent launch: windows from here on
+    in_loop_ = false;
+  } else if (res.status == GRP_LOOP_HANDBACK && !finished_ && pos < n) {
+    // one read through the synchronous path (more tiles than the device decision holds, or
+    // the list arena was too small)
+    rc = query_window(rg_.reads, rg_.lens, pos, 1);
+    if (rc == GRP_OK) {
+      commit_one(pos, dec_all_[0], rc);
+      ++pos;
+    }
+  }
+  return rc;
 }
 
 // ---- streaming window: consume the decisions while the launch is running ----------
@@ -809,6 +982,13 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
   uint32_t pos = 0;
   int rc = GRP_OK;
   while (rc == GRP_OK && pos < n && !finished_) {
+    if (!next_.active && !snext_.active && want_loop()) {
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = loop_round(pos);
+      t_windows_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      continue;
+    }
+    in_loop_ = false;
     if (!next_.active && (snext_.active || window_plan().streaming)) {
       const auto t0 = std::chrono::steady_clock::now();
       rc = stream_round(pos);

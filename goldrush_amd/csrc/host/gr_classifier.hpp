@@ -35,7 +35,8 @@ public:
 
 private:
   int query_window(void* reads, const uint32_t* lens, uint32_t first, uint32_t count);
-  bool commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_decision& d, int& rc);
+  // engine_inserted: the engine has applied the read's ID blocks already (commit loop on the device)
+  bool commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_decision& d, int& rc, bool engine_inserted = false, uint32_t engine_first_id = 0);
   void silver_path_check(int& rc);
   void skip_reads(uint32_t n);
   void bump_id();
@@ -65,7 +66,10 @@ private:
   int end_stream(StreamFlight& f);
   int wait_record(const StreamFlight& f, uint32_t j);
   bool can_stream() const;
-  bool commit_one(uint32_t r, const gr_read_decision& d, int& rc);
+  bool commit_one(uint32_t r, const gr_read_decision& d, int& rc, bool engine_inserted = false, uint32_t engine_first_id = 0);
+  bool can_loop() const;
+  bool want_loop() const; // the insert rate calls for the device-side commit loop
+  int loop_round(uint32_t& pos);
   void drop_streams();
   int stream_decision(uint32_t j, gr_read_decision& d);
   int stream_round(uint32_t& pos);
@@ -93,6 +97,10 @@ private:
   // speculation control / statistics
   double p_insert_ = 1.0;        // EMA over ~32 reads
   double p_insert_slow_ = 0.0;   // EMA over ~8192 reads
+  double p_insert_mid_ = 1.0;    // EMA over ~256 reads: chooses between the device-side commit loop and the windows
+  bool in_loop_ = false;         // the last round ran as a commit loop (hysteresis of the choice)
+  bool loop_disabled_ = false;   // a loop launch could not become resident (shared device): windows only
+  uint64_t n_loops_ = 0, n_loop_reads_ = 0;
   double p_redo_ = 0.0;          // streaming records handed back to the synchronous path (EMA over ~64 reads)
   double avg_probes_per_read_ = 75000.0;
   uint64_t n_windows_ = 0, n_queried_ = 0, n_committed_ = 0, n_inserts_ = 0;

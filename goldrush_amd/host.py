@@ -63,6 +63,10 @@ VT_TYPES = [
     ("stream_abort", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("stream_poll", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("stream_end", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, _vp)),
+    ("loop_begin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp)),
+    ("loop_stop", C.CFUNCTYPE(C.c_int, _vp)),
+    ("loop_poll", C.CFUNCTYPE(C.c_int, _vp)),
+    ("loop_end", C.CFUNCTYPE(C.c_int, _vp, _vp)),
     ("ntcard_begin", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("ntcard_add", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp)),
     ("ntcard_finish", C.CFUNCTYPE(C.c_int, _vp, _vp)),
@@ -220,7 +224,8 @@ def hip_engine_vt() -> grp_engine_vt:
     lib = native.load()
     vt = grp_engine_vt()
     alias = {"classify_begin": "classify_reads_begin", "classify_end": "classify_reads_end", "stream_begin": "classify_stream_begin_striped",
-             "stream_abort": "classify_stream_abort", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end"}
+             "stream_abort": "classify_stream_abort", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end",
+             "loop_begin": "commit_loop_begin", "loop_stop": "commit_loop_stop", "loop_poll": "commit_loop_poll", "loop_end": "commit_loop_end"}
     for name, ftype in VT_TYPES:
         sym = getattr(lib, "grp_" + alias.get(name, name))
         setattr(vt, name, C.cast(sym, ftype))

@@ -21,8 +21,9 @@ LIB_PATH = os.path.join(LIB_DIR, "libgrpath_hip.so")
 
 GRP_OK = 0
 GRP_ERR_INVALID, GRP_ERR_NO_DEVICE, GRP_ERR_HIP, GRP_ERR_STATE, GRP_ERR_NOMEM = -1, -2, -3, -4, -5
-GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6
-KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard")
+GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_LOOP, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7
+KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard", "loop")
+GRP_LOOP_RUNNING, GRP_LOOP_DONE, GRP_LOOP_ROLLOVER, GRP_LOOP_HANDBACK, GRP_LOOP_STOPPED, GRP_LOOP_TIMEOUT = 0, 1, 2, 3, 4, 5
 
 
 class GrpError(RuntimeError):
@@ -54,6 +55,16 @@ class grp_decide_params(C.Structure):
 
 decision_dtype = np.dtype([("kind", "<u4"), ("num_tiles", "<u4"), ("num_assigned", "<u4"), ("trim_start", "<u4"), ("trim_end", "<u4"),
                            ("hits", "<u4"), ("misses", "<u4"), ("pad", "<u4")])
+
+
+class grp_loop_params(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("decide", grp_decide_params), ("block_tiles", C.c_uint32), ("silver_path", C.c_uint32), ("ids_inserted", C.c_uint32),
+                ("max_depth", C.c_uint32), ("target_bases", C.c_uint64), ("inserted_bases", C.c_uint64)]
+
+
+class grp_loop_result(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("reads_committed", C.c_uint32), ("inserts", C.c_uint32), ("ids_inserted", C.c_uint32), ("inserted_bases", C.c_uint64),
+                ("tiles_queried", C.c_uint64), ("probes", C.c_uint64)]
 
 
 class grp_query_stats(C.Structure):
@@ -92,6 +103,10 @@ SIGNATURES = {
     "grp_classify_stream_abort": (C.c_int, [_vp, C.c_uint32]),
     "grp_classify_stream_poll": (C.c_int, [_vp, C.c_uint32]),
     "grp_classify_stream_end": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "grp_commit_loop_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_loop_params), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "grp_commit_loop_stop": (C.c_int, [_vp]),
+    "grp_commit_loop_poll": (C.c_int, [_vp]),
+    "grp_commit_loop_end": (C.c_int, [_vp, C.POINTER(grp_loop_result)]),
     "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_insert_read": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_reset_ids": (C.c_int, [_vp]),
@@ -430,6 +445,21 @@ class Engine:
         n = C.c_uint32()
         self._check(self.lib.grp_classify_stream_end(self._h, slot, C.byref(n)))
         return n.value
+
+    def commit_loop(self, batch: ReadBatch, first: int, count: int, block: int = 10, threshold=10, unassigned_min=5, assigned_max=1, silver=False,
+                    target_bases: int = 0, ids_inserted: int = 0, inserted_bases: int = 0, max_depth: int = 0):
+        """Run the ordered commit loop over reads [first, first+count) to its end.
+        Returns (records[decision_dtype] of the committed reads, result dict)."""
+        p = grp_loop_params(C.sizeof(grp_loop_params), grp_decide_params(threshold, unassigned_min, assigned_max, 0), block, 1 if silver else 0, ids_inserted, max_depth,
+                            target_bases, inserted_bases)
+        rec_p, com_p = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.grp_commit_loop_begin(self._h, batch._h, first, count, C.byref(p), C.byref(rec_p), C.byref(com_p)))
+        res = grp_loop_result()
+        self._check(self.lib.grp_commit_loop_end(self._h, C.byref(res)))
+        n = res.reads_committed
+        buf = (C.c_uint8 * (max(n, 1) * decision_dtype.itemsize)).from_address(rec_p.value)
+        rec = np.frombuffer(buf, dtype=decision_dtype)[:n].copy()
+        return rec, {k: getattr(res, k) for k, _ in grp_loop_result._fields_}
 
     def tile_states(self, n_tiles: int):
         """(ids, assigned) per tile after the smoothing passes of the last classify_reads window."""

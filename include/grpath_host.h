@@ -43,6 +43,11 @@ typedef struct
   int (*stream_abort)(void* ctx, uint32_t slot);
   int (*stream_poll)(void* ctx, uint32_t slot);
   int (*stream_end)(void* ctx, uint32_t slot, uint32_t* reads_decided);
+  /* optional (all four or none): the ordered commit loop on the device, grp_commit_loop_* */
+  int (*loop_begin)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_loop_params* params, const grp_read_decision** records, const volatile uint32_t** committed);
+  int (*loop_stop)(void* ctx);
+  int (*loop_poll)(void* ctx);
+  int (*loop_end)(void* ctx, grp_loop_result* result);
   /* optional (all four or none): --ntcard on the device, grp_ntcard_* / grp_set_filter_size */
   int (*ntcard_begin)(void* ctx, uint32_t sbits);
   int (*ntcard_add)(void* ctx, const void* reads, uint32_t first, uint32_t count, const uint32_t* stale_extra);

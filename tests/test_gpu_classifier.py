@@ -14,13 +14,17 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("max_window,mode", [(1, "auto"), (5, "auto"), (4096, "auto"), (4096, "stream"), (48, "stream"), (4096, "pipeline"), (4096, "sync")])
+@pytest.mark.parametrize("max_window,mode", [(1, "auto"), (5, "auto"), (4096, "auto"), (4096, "loop"), (4096, "stream"), (48, "stream"), (4096, "pipeline"), (4096, "sync"),
+                                             (1, "windows"), (4096, "windows")])
 def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, monkeypatch):
     from goldrush_amd import host, synth
     from oracle_engine import serial_reference
 
-    env = {"auto": {}, "stream": {"GRP_STREAM": "force"}, "pipeline": {"GRP_STREAM": "off", "GRP_PIPELINE": "force"},
-           "sync": {"GRP_STREAM": "off", "GRP_PIPELINE": "off"}}[mode]
+    # auto: the product's own choice (device-side commit loop while inserts are frequent, windows after);
+    # loop: commit loop only; the others: windows only, one form forced
+    env = {"auto": {}, "loop": {"GRP_LOOP": "force"}, "windows": {"GRP_LOOP": "off"}, "stream": {"GRP_LOOP": "off", "GRP_STREAM": "force"},
+           "pipeline": {"GRP_LOOP": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "force"},
+           "sync": {"GRP_LOOP": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "off"}}[mode]
     for key, val in env.items():
         monkeypatch.setenv(key, val)
     tile, k, h, block = 500, 22, 3, 4
