@@ -238,6 +238,19 @@ def serial_reference(orc, m, seeds, tile, k, reads, block=10, threshold=10, u=5,
     return out, mf
 
 
+_REF_CACHE = {}
+
+
+def cached_serial_reference(key, orc, m, seeds, tile, k, reads, **kw):
+    """serial_reference once per test session and key (the parametrised GPU tests compare many
+    engine modes with the same expectation): returns (commits, ids, counts, pop)."""
+    if key not in _REF_CACHE:
+        exp, mf = serial_reference(orc, m, seeds, tile, k, reads, **kw)
+        _REF_CACHE[key] = (exp, mf.ids().copy(), mf.counts().copy(), mf.pop)
+        mf.close()
+    return _REF_CACHE[key]
+
+
 class OracleCliEngine:
     """A COMPLETE engine function table backed by the CPU oracle (create, read upload, fill,
     finalize, query, insert, reset), so that the product's whole host program

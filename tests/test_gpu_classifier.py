@@ -18,7 +18,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
                                              (1, "windows"), (4096, "windows")])
 def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, monkeypatch):
     from goldrush_amd import host, synth
-    from oracle_engine import serial_reference
+    from oracle_engine import cached_serial_reference
 
     # auto: the product's own choice (device-side commit loop while inserts are frequent, windows after);
     # loop: commit loop only; the others: windows only, one form forced
@@ -32,11 +32,11 @@ def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, mo
     g = synth.random_genome(150_000, 21)
     reads = [r[1] for r in synth.make_reads(g, 120, mean_len=5000, min_len=3500, seed=22, max_len=9000)]
     m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
-    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=120_000, max_paths=3)
+    exp, ref_ids, ref_counts, ref_pop = cached_serial_reference("classifier_modes", oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=120_000, max_paths=3)
     eng = native.Engine(k, h, tile, m, seeds)
     b = eng.upload(reads)
     eng.bv_insert(b)
-    assert eng.finalize() == mf_ref.pop
+    assert eng.finalize() == ref_pop
     cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, k=k, h=h, target_bases=120_000, max_paths=3, silver_path=True, max_window=max_window)
     cls.run(b._h, b.lens)
     eng.sync()
@@ -44,7 +44,7 @@ def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, mo
     # hits / misses per read agree with the oracle's per-tile counters (re-derived on the final state is not
     # possible, so compare the miBF end state instead)
     ids, counts = eng.export_ids()
-    assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
+    assert np.array_equal(ids, ref_ids) and np.array_equal(counts, ref_counts)
     st = cls.state()
     assert st["reads_committed"] == len(exp) and st["inserts"] == sum(1 for e in exp if e[1] in (2, 4))
 

@@ -27,7 +27,7 @@ def _records(rec):
 @pytest.mark.parametrize("depth,lt", [(0, 0), (1, 0), (3, 512), (64, 0)])
 def test_commit_loop_equals_serial_reference(oracle, native, depth, lt, monkeypatch):
     from goldrush_amd import synth
-    from oracle_engine import serial_reference
+    from oracle_engine import cached_serial_reference
 
     if lt:
         monkeypatch.setenv("GRP_LOOP_LT", str(lt))
@@ -36,14 +36,14 @@ def test_commit_loop_equals_serial_reference(oracle, native, depth, lt, monkeypa
     reads = [r[1] for r in synth.make_reads(g, 140, mean_len=5000, min_len=3500, seed=22, max_len=9000)]
     m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
     eng, b, seeds = _setup(oracle, native, reads, tile, k, h, m)
-    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block)
+    exp, ref_ids, ref_counts, _ = cached_serial_reference("loop_basic", oracle, m, seeds, tile, k, reads, block=block)
     rec, res = eng.commit_loop(b, 0, len(reads), block=block, max_depth=depth)
     assert res["status"] == native.GRP_LOOP_DONE and res["reads_committed"] == len(reads)
     assert _records(rec) == [(e[1], e[2], e[3], e[4], e[5], e[6]) for e in exp]
     assert res["inserts"] == sum(1 for e in exp if e[1] in (2, 4)) and res["inserts"] > 20
     assert {e[1] for e in exp} >= {2, 3, 5}  # the stream exercises the decision kinds
     ids, counts = eng.export_ids()
-    assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
+    assert np.array_equal(ids, ref_ids) and np.array_equal(counts, ref_counts)
     eng.close()
 
 
