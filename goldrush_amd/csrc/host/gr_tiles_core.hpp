@@ -80,6 +80,25 @@ struct PtrState
   GR_HD void set_asg(size_t i, uint32_t v) { flags[i] = (uint8_t)v; }
   GR_HD uint64_t scr(size_t i) const { return scratch[i]; }
   GR_HD void set_scr(size_t i, uint64_t v) { scratch[i] = v; }
+  // summaries of the state, used to skip passes that cannot change anything
+  GR_HD bool any_asg(size_t n) const
+  {
+    for (size_t i = 0; i < n; ++i) {
+      if (flags[i]) {
+        return true;
+      }
+    }
+    return false;
+  }
+  GR_HD bool any_list(size_t n) const
+  {
+    for (size_t i = 0; i < n; ++i) {
+      if (tiles[i].list_n) {
+        return true;
+      }
+    }
+    return false;
+  }
 };
 
 // P1 / P2 (:646-661, :667-682): tile i takes over its neighbour's ID when that
@@ -159,20 +178,30 @@ smooth(size_t n, size_t x, S& s)
     s.set_asg(i, (s.list_n(i) != 0 && s.top_count(i) > x) ? 1u : 0u);
   }
   if (n >= 3) {
-    for (size_t i = 1; i < n; ++i) { // P1
-      adopt_neighbour(i, i - 1, x, s);
+    // Passes that provably leave the state alone are skipped (the decision of a read is on
+    // the latency path of the device-side commit loop): P1 / P2 only act through a tile's
+    // count>2 list; P3 .. P7 only act next to / between / on ASSIGNED tiles; P9 / P10 only
+    // clear flags.  The start of every silver path — no hit anywhere — skips everything
+    // but P8.
+    if (s.any_list(n)) {
+      for (size_t i = 1; i < n; ++i) { // P1
+        adopt_neighbour(i, i - 1, x, s);
+      }
+      for (size_t i = n - 1; i-- > 0;) { // P2: i = n-2 .. 0
+        adopt_neighbour(i, i + 1, x, s);
+      }
     }
-    for (size_t i = n - 1; i-- > 0;) { // P2: i = n-2 .. 0
-      adopt_neighbour(i, i + 1, x, s);
-    }
+    const bool assigned_1_7 = s.any_asg(n);
+    if (assigned_1_7) {
     for (size_t i = 1; i + 1 < n; ++i) { // P3
       neighbour_fill(i, s);
     }
     for (size_t i = n - 2; i >= 1; --i) { // P4
       neighbour_fill(i, s);
     }
+    }
     // P5 (:739-766): interior unassigned runs whose flanking IDs differ by <= 1
-    size_t nr = collect_runs<false>(n, s);
+    size_t nr = assigned_1_7 ? collect_runs<false>(n, s) : 0;
     for (size_t r = 0; r < nr; ++r) {
       const uint64_t run = s.scr(r);
       const size_t first = (size_t)(run >> 32), second = (size_t)(run & 0xFFFFFFFFu);
@@ -189,6 +218,7 @@ smooth(size_t n, size_t x, S& s)
       }
     }
     // P6 (:771-793): isolated assigned tiles, forward then backward, 2..n-3
+    if (assigned_1_7) {
     for (size_t i = 2; i + 2 < n; ++i) {
       if (s.asg(i) && !s.asg(i - 1) && !s.asg(i + 1)) {
         s.set_asg(i, 0);
@@ -199,12 +229,13 @@ smooth(size_t n, size_t x, S& s)
         s.set_asg(i, 0);
       }
     }
+    }
     // P7 (:799-822): per ID in ascending order (std::map), between two
     // non-adjacent assigned occurrences every tile gets the ID found at the
     // earlier occurrence *at that moment* (earlier groups may have rewritten it).
     // scratch[e] = id<<32 | idx, insertion-sorted (indices arrive ascending).
     size_t ne = 0;
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t i = 0; assigned_1_7 && i < n; ++i) {
       if (s.asg(i)) {
         const uint64_t key = ((uint64_t)s.id(i) << 32) | (uint64_t)i;
         size_t j = ne++;
@@ -239,14 +270,15 @@ smooth(size_t n, size_t x, S& s)
       }
     }
     // P9 (:840-850): a tile unrelated (uint32_t +-1) to both neighbours
-    for (size_t i = 1; i + 1 < n; ++i) {
+    const bool assigned_9_10 = s.any_asg(n);
+    for (size_t i = 1; assigned_9_10 && i + 1 < n; ++i) {
       const uint32_t c = s.id(i), p = s.id(i - 1), q = s.id(i + 1);
       if (c != q && c != (uint32_t)(q - 1u) && c != (uint32_t)(q + 1u) && c != p && c != (uint32_t)(p - 1u) && c != (uint32_t)(p + 1u)) {
         s.set_asg(i, 0);
       }
     }
     // P10 (:856-877): assigned runs of length <= 5
-    nr = collect_runs<true>(n, s);
+    nr = assigned_9_10 ? collect_runs<true>(n, s) : 0;
     for (size_t r = 0; r < nr; ++r) {
       const uint64_t run = s.scr(r);
       const size_t first = (size_t)(run >> 32), second = (size_t)(run & 0xFFFFFFFFu);
