@@ -74,6 +74,8 @@ struct PtrState
   GR_HD uint32_t hits(size_t i) const { return tiles[i].hits; }
   GR_HD uint32_t misses(size_t i) const { return tiles[i].misses; }
   GR_HD grp_id_count list_entry(size_t k) const { return load_list_entry(lists + k); }
+  // entry j of tile i's count>2 list
+  GR_HD grp_id_count tile_list_entry(size_t i, uint32_t j) const { return load_list_entry(lists + tiles[i].list_off + j); }
   GR_HD uint32_t id(size_t i) const { return ids[i]; }
   GR_HD void set_id(size_t i, uint32_t v) { ids[i] = v; }
   GR_HD uint32_t asg(size_t i) const { return flags[i]; }
@@ -111,10 +113,9 @@ adopt_neighbour(size_t i, size_t nb, size_t x, S& s)
   if (s.id(i) == want) {
     return;
   }
-  const size_t off = s.list_off(i);
   const uint32_t ln = s.list_n(i);
   for (uint32_t j = 0; j < ln; ++j) {
-    const grp_id_count e = s.list_entry(off + j);
+    const grp_id_count e = s.tile_list_entry(i, j);
     if (e.id == want) {
       s.set_id(i, want);
       s.set_asg(i, e.count > x ? 1u : 0u);
