@@ -82,6 +82,34 @@ struct PtrState
   GR_HD void set_asg(size_t i, uint32_t v) { flags[i] = (uint8_t)v; }
   GR_HD uint64_t scr(size_t i) const { return scratch[i]; }
   GR_HD void set_scr(size_t i, uint64_t v) { scratch[i] = v; }
+  // whole-state operations (one loop here; a few cross-lane instructions in LaneState)
+  GR_HD void init_from_top(size_t n, size_t x)
+  {
+    for (size_t i = 0; i < n; ++i) {
+      ids[i] = tiles[i].top_id;
+      // :628-634 — the list is non-empty iff some count is > 2, and then its largest
+      // count (list[0] after the reference's sort) is the tile's top count; the
+      // device-side lists are unsorted, so top_count is used
+      flags[i] = (tiles[i].list_n != 0 && tiles[i].top_count > x) ? 1u : 0u;
+    }
+  }
+  GR_HD size_t count_asg(size_t n) const
+  {
+    size_t c = 0;
+    for (size_t i = 0; i < n; ++i) {
+      c += flags[i] ? 1 : 0;
+    }
+    return c;
+  }
+  GR_HD void sum_hits_misses(size_t n, uint32_t& h, uint32_t& m) const
+  {
+    h = 0;
+    m = 0;
+    for (size_t i = 0; i < n; ++i) {
+      h += tiles[i].hits;
+      m += tiles[i].misses;
+    }
+  }
   // summaries of the state, used to skip passes that cannot change anything
   GR_HD bool any_asg(size_t n) const
   {
@@ -171,13 +199,7 @@ template<class S>
 GR_HD inline size_t
 smooth(size_t n, size_t x, S& s)
 {
-  for (size_t i = 0; i < n; ++i) {
-    s.set_id(i, s.top_id(i));
-    // :628-634 — the list is non-empty iff some count is > 2, and then its largest
-    // count (list[0] after the reference's sort) is the tile's top count; the
-    // device-side lists are unsorted, so top_count is used
-    s.set_asg(i, (s.list_n(i) != 0 && s.top_count(i) > x) ? 1u : 0u);
-  }
+  s.init_from_top(n, x);
   if (n >= 3) {
     // Passes that provably leave the state alone are skipped (the decision of a read is on
     // the latency path of the device-side commit loop): P1 / P2 only act through a tile's
@@ -290,11 +312,7 @@ smooth(size_t n, size_t x, S& s)
       }
     }
   }
-  size_t n_assigned = 0;
-  for (size_t i = 0; i < n; ++i) {
-    n_assigned += s.asg(i) ? 1 : 0;
-  }
-  return n_assigned;
+  return s.count_asg(n);
 }
 
 // goldrush_path.cpp:195-233, branch for branch
@@ -458,10 +476,7 @@ decide(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t n, S
   out.hits = 0;
   out.misses = 0;
   out.pad = 0;
-  for (size_t i = 0; i < n; ++i) {
-    out.hits += s.hits(i);
-    out.misses += s.misses(i);
-  }
+  s.sum_hits_misses(n, out.hits, out.misses);
   const size_t na = smooth(n, threshold, s);
   out.num_assigned = (uint32_t)na;
   const size_t nu = n - na;

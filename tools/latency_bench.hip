@@ -75,6 +75,36 @@ __global__ void k_pingpong(uint32_t* flag, int iters, unsigned long long* out)
   out[blockIdx.x] = wall_clock64() - t0;
 }
 
+// burst: every lane of `wgs` x 1024-lane workgroups performs ONE random operation of the kind
+// on a table of n 8-byte words; the time until the slowest workgroup is done (phase latency)
+// kind 0 plain load, 1 sc1 load, 2 atomicCAS (with return), 3 atomicOr (no return) + wait,
+// 4 sc1 store + wait, 5 sc1 load then DEPENDENT sc1 load
+__global__ void __launch_bounds__(1024) k_burst(unsigned long long* table, unsigned long long n_mask, int kind, int lanes, unsigned long long* out, unsigned long long* sink)
+{
+  const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long x = gid * 0x9E3779B97F4A7C15ULL + 0x1234567ULL;
+  x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+  const unsigned long long idx = x & n_mask;
+  __syncthreads();
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long v = 0;
+  if ((int)threadIdx.x < lanes) {
+    if (kind == 0) v = table[idx];
+    else if (kind == 1) v = __hip_atomic_load(table + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (kind == 2) v = atomicCAS(table + idx, 0ull, gid + 1);
+    else if (kind == 3) atomicOr(table + idx, 1ull << (gid & 63));
+    else if (kind == 4) __hip_atomic_store(table + idx, gid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else {
+      v = __hip_atomic_load(table + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = __hip_atomic_load(table + ((v ^ x) & n_mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  if (v == 0xDEADBEEFCAFEull) sink[0] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = wall_clock64() - t0;
+}
+
 int main()
 {
   const uint32_t n = 1u << 28; // 1 GiB of uint32
@@ -108,6 +138,33 @@ int main()
       CK(hipMemset(word, 0, 4096));
       k_barrier<<<wgs, 64>>>(word, it + 1, sleep, out);
       report(sleep ? "barrier: no-return arrive + spin with s_sleep(1)" : "barrier: no-return arrive + spin", wgs, it);
+    }
+  }
+  {
+    unsigned long long* big; unsigned long long* sink;
+    const unsigned long long n_big = 1ull << 31; // 16 GiB of 8-byte words
+    CK(hipMalloc(&big, n_big * 8)); CK(hipMalloc(&sink, 64));
+    CK(hipMemset(big, 0, n_big * 8));
+    const char* kinds[6] = { "plain load", "sc1 load", "atomicCAS", "atomicOr (no return)", "sc1 store", "2 dependent sc1 loads" };
+    for (unsigned long long n_tab : { 1ull << 19, 1ull << 31 }) { // 4 MiB, 16 GiB
+      for (int kind = 0; kind < 6; ++kind) {
+        for (int wgs : { 32, 256 }) {
+          for (int lanes : { 128, 1024 }) {
+            double worst = 0, mean = 0;
+            for (int rep = 0; rep < 5; ++rep) {
+              CK(hipMemset(big, 0, (n_tab < (1ull << 24) ? n_tab : (1ull << 24)) * 8));
+              k_burst<<<wgs, 1024>>>(big, n_tab - 1, kind, lanes, out, sink);
+              CK(hipDeviceSynchronize());
+              CK(hipMemcpy(ho.data(), out, wgs * 8, hipMemcpyDeviceToHost));
+              if (rep == 0) continue;
+              double w = 0, m = 0;
+              for (int i = 0; i < wgs; ++i) { w = ho[i] > w ? (double)ho[i] : w; m += (double)ho[i]; }
+              worst += w / 4; mean += m / wgs / 4;
+            }
+            printf("burst %-24s table %6s  wgs=%3d lanes=%4d (%6d ops): slowest workgroup %7.2f us, mean %7.2f us\n", kinds[kind], n_tab == (1ull << 19) ? "4 MiB" : "16 GiB", wgs, lanes, wgs * lanes, worst / 100.0, mean / 100.0);
+          }
+        }
+      }
     }
   }
   CK(hipMemset(word, 0, 4096));
