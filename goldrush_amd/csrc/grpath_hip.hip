@@ -117,8 +117,16 @@ struct LoopRun
   uint64_t tiles_cap = 0;
   grp_id_count* d_lists = nullptr;
   uint64_t lists_cap = 0;
+  unsigned long long* d_unit_buf = nullptr;
+  uint64_t unit_buf_cap = 0;
+  uint32_t* d_tile_parts = nullptr;
+  uint64_t tile_parts_cap = 0;
   unsigned long long* d_trace = nullptr;
   uint64_t trace_cap = 0;
+  unsigned long long* d_tile_trace = nullptr;
+  uint64_t tile_trace_cap = 0;
+  uint64_t t0 = 0, nt = 0;
+  const grp_reads* reads_for_trace = nullptr;
 };
 
 struct grp_ctx
@@ -722,6 +730,9 @@ grp_destroy(grp_ctx* c)
     (void)hipFree(lp.d_tiles);
     (void)hipFree(lp.d_lists);
     (void)hipFree(lp.d_trace);
+    (void)hipFree(lp.d_tile_trace);
+    (void)hipFree(lp.d_unit_buf);
+    (void)hipFree(lp.d_tile_parts);
   }
   (void)hipFree(c->d_ntc);
   (void)hipFree(c->d_ntc_chunks);

@@ -709,6 +709,8 @@ Classifier::loop_round(uint32_t& pos)
   lp.silver_path = p_.silver_path ? 1u : 0u;
   lp.ids_inserted = ids_inserted_;
   lp.max_depth = 0;
+  // insert-heavy stretch: every read's probes spread over the device; otherwise a workgroup per tile
+  lp.whole_tiles = p_insert_mid_ < 0.3 ? 1u : 0u;
   lp.target_bases = p_.target_bases;
   lp.inserted_bases = inserted_bases_;
   const gr_read_decision* rec = nullptr;

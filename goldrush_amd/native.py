@@ -59,7 +59,7 @@ decision_dtype = np.dtype([("kind", "<u4"), ("num_tiles", "<u4"), ("num_assigned
 
 class grp_loop_params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("decide", grp_decide_params), ("block_tiles", C.c_uint32), ("silver_path", C.c_uint32), ("ids_inserted", C.c_uint32),
-                ("max_depth", C.c_uint32), ("target_bases", C.c_uint64), ("inserted_bases", C.c_uint64)]
+                ("max_depth", C.c_uint32), ("whole_tiles", C.c_uint32), ("target_bases", C.c_uint64), ("inserted_bases", C.c_uint64)]
 
 
 class grp_loop_result(C.Structure):
@@ -447,11 +447,11 @@ class Engine:
         return n.value
 
     def commit_loop(self, batch: ReadBatch, first: int, count: int, block: int = 10, threshold=10, unassigned_min=5, assigned_max=1, silver=False,
-                    target_bases: int = 0, ids_inserted: int = 0, inserted_bases: int = 0, max_depth: int = 0):
+                    target_bases: int = 0, ids_inserted: int = 0, inserted_bases: int = 0, max_depth: int = 0, whole_tiles: bool = False):
         """Run the ordered commit loop over reads [first, first+count) to its end.
         Returns (records[decision_dtype] of the committed reads, result dict)."""
         p = grp_loop_params(C.sizeof(grp_loop_params), grp_decide_params(threshold, unassigned_min, assigned_max, 0), block, 1 if silver else 0, ids_inserted, max_depth,
-                            target_bases, inserted_bases)
+                            1 if whole_tiles else 0, target_bases, inserted_bases)
         rec_p, com_p = C.c_void_p(), C.c_void_p()
         self._check(self.lib.grp_commit_loop_begin(self._h, batch._h, first, count, C.byref(p), C.byref(rec_p), C.byref(com_p)))
         res = grp_loop_result()

@@ -352,6 +352,8 @@ typedef struct
   uint32_t silver_path;     /* --silver_path: stop after the insert that passes target_bases */
   uint32_t ids_inserted;    /* state in front of the first read (goldrush_path.cpp:1226) */
   uint32_t max_depth;       /* reads the query may run ahead of the commit cursor; 0 = default */
+  uint32_t whole_tiles;     /* 0: a tile is queried by several workgroups (lowest latency per read: insert-heavy
+                               stretches); 1: one workgroup per tile (highest rate when inserts are rare) */
   uint64_t target_bases;    /* uint64(r * G) (:1223) */
   uint64_t inserted_bases;  /* state in front of the first read (:1222) */
 } grp_loop_params;

@@ -24,8 +24,8 @@ def _records(rec):
              int(r["pad"])) for r in rec]
 
 
-@pytest.mark.parametrize("depth,lt", [(0, 0), (1, 0), (3, 512), (64, 0)])
-def test_commit_loop_equals_serial_reference(oracle, native, depth, lt, monkeypatch):
+@pytest.mark.parametrize("depth,lt,whole", [(0, 0, False), (1, 0, False), (3, 512, False), (64, 0, False), (0, 0, True), (2, 512, True), (64, 0, True)])
+def test_commit_loop_equals_serial_reference(oracle, native, depth, lt, whole, monkeypatch):
     from goldrush_amd import synth
     from oracle_engine import cached_serial_reference
 
@@ -37,7 +37,7 @@ def test_commit_loop_equals_serial_reference(oracle, native, depth, lt, monkeypa
     m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
     eng, b, seeds = _setup(oracle, native, reads, tile, k, h, m)
     exp, ref_ids, ref_counts, _ = cached_serial_reference("loop_basic", oracle, m, seeds, tile, k, reads, block=block)
-    rec, res = eng.commit_loop(b, 0, len(reads), block=block, max_depth=depth)
+    rec, res = eng.commit_loop(b, 0, len(reads), block=block, max_depth=depth, whole_tiles=whole)
     assert res["status"] == native.GRP_LOOP_DONE and res["reads_committed"] == len(reads)
     assert _records(rec) == [(e[1], e[2], e[3], e[4], e[5], e[6]) for e in exp]
     assert res["inserts"] == sum(1 for e in exp if e[1] in (2, 4)) and res["inserts"] > 20
