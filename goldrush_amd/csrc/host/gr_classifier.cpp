@@ -667,10 +667,12 @@ Classifier::can_loop() const
   return vt_.loop_begin && vt_.loop_stop && vt_.loop_poll && vt_.loop_end && !loop_disabled_ && !(e && !strcmp(e, "off"));
 }
 
-// The device-side commit loop pays ~25 us per inserting read and nothing per launch and
-// read beyond that; the streaming windows pay ~120 us per insert (abort, drain, relaunch)
-// but query at the full rate in between.  Enter the loop above ~4 % inserting reads,
-// leave it below ~1.5 % (measured on MI355X, C1 / C2 streams).
+// Measured on MI355X (tools/loop_matrix.sh, profiles/r02_loop_matrix.txt): the device-side
+// commit loop costs ~75-80 us per inserting read (a chain of ~60 dependent memory-side steps
+// of 0.3-2 us each), the host-driven latency windows ~83 us per insert but they query
+// several reads per round, so the loop only wins where nearly every read inserts (the
+// start of a path on a genome-scale filter).  Enter above 80 % inserting reads, leave
+// below 60 %.
 bool
 Classifier::want_loop() const
 {
@@ -683,11 +685,11 @@ Classifier::want_loop() const
   }
   static const double p_in = [] {
     const char* v = getenv("GRP_LOOP_ENTER");
-    return v ? atof(v) : 0.04;
+    return v ? atof(v) : 0.8;
   }();
   static const double p_out = [] {
     const char* v = getenv("GRP_LOOP_LEAVE");
-    return v ? atof(v) : 0.015;
+    return v ? atof(v) : 0.6;
   }();
   return p_insert_mid_ >= (in_loop_ ? p_out : p_in);
 }
@@ -709,8 +711,8 @@ Classifier::loop_round(uint32_t& pos)
   lp.silver_path = p_.silver_path ? 1u : 0u;
   lp.ids_inserted = ids_inserted_;
   lp.max_depth = 0;
-  // insert-heavy stretch: every read's probes spread over the device; otherwise a workgroup per tile
-  lp.whole_tiles = p_insert_mid_ < 0.3 ? 1u : 0u;
+  // one workgroup per tile (the form that cuts tiles into units was not faster, measured)
+  lp.whole_tiles = 1u;
   lp.target_bases = p_.target_bases;
   lp.inserted_bases = inserted_bases_;
   const gr_read_decision* rec = nullptr;
@@ -738,7 +740,7 @@ Classifier::loop_round(uint32_t& pos)
       commit_one(pos + consumed, d, rc, true, first_id);
       ++consumed;
       rolled = rolled || curr_path_ != path_before;
-      if (!stop_sent && !forced && !rolled && p_insert_mid_ < 0.015 && !want_loop()) {
+      if (!stop_sent && !forced && !rolled && !want_loop()) {
         (void)vt_.loop_stop(ctx_); // the insert-heavy stretch is over: the windows are faster from here
         stop_sent = true;
       }
