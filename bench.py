@@ -64,59 +64,6 @@ CONFIGS = {
 }
 
 
-class ShmAllgather:
-    """All-gather of small host buffers between the ranks of ONE node through a file in
-    /dev/shm: every rank writes its block into the round's buffer, then publishes the round
-    number; readers spin on the round numbers.  Two buffers alternate, so a rank that is
-    one round ahead never overwrites what a slower rank still reads.  ~10 us per call
-    against a few hundred for a loopback gloo ring: the 32-byte decision records are
-    exchanged once per stripe group."""
-
-    SLOT = 1 << 20  # bytes per rank and buffer
-
-    def __init__(self, world: int, rank: int, key: str, barrier):
-        import mmap
-
-        self.world, self.rank, self.round = world, rank, 0
-        self.path = "/dev/shm/grp_bench_%s" % key
-        size = 4096 + 2 * world * self.SLOT
-        if rank == 0:
-            with open(self.path, "wb") as f:
-                f.truncate(size)
-        barrier()
-        self._f = open(self.path, "r+b")
-        self._mm = mmap.mmap(self._f.fileno(), size)
-        buf = np.frombuffer(self._mm, dtype=np.uint8)
-        self.seq = buf[:4096].view(np.uint64)[: world * 8 : 8]  # one 64-byte line per rank
-        self.data = buf[4096:].reshape(2, world, self.SLOT)
-        barrier()
-
-    def __call__(self, src: np.ndarray, dst: np.ndarray):
-        n = src.size
-        assert n <= self.SLOT
-        self.round += 1
-        b = self.round & 1
-        self.data[b, self.rank, :n] = src
-        self.seq[self.rank] = self.round  # published after the data (x86 store order)
-        for r in range(self.world):
-            spins = 0
-            while self.seq[r] < self.round:
-                spins += 1
-                if spins > 200000:
-                    time.sleep(0)  # a rank that is far behind (start-up): do not burn its core
-            dst[r * n:(r + 1) * n] = self.data[b, r, :n]
-
-    def close(self, barrier):
-        barrier()
-        self._mm = None
-        self._f.close()
-        if self.rank == 0:
-            try:
-                os.remove(self.path)
-            except OSError:
-                pass
-
-
 def _newest_profile(pattern: str):
     """newest profiles/<pattern> by the numbers in its name (r02_v10_... sorts after r02_v9_...)"""
     def _ver(path):
@@ -126,42 +73,74 @@ def _newest_profile(pattern: str):
     return files[-1] if files else None
 
 
-def cpu_baseline(dr, n_sample: int, m: int, seeds, k: int, tile: int, genome: int, budget_s: float = 20.0):
-    """The oracle's own serial loop (orc_path_process_read: hash, query, decide,
-    insert; OpenMP over tiles like the reference) over the first reads of the
-    same synthetic set, same filter size; reads/s of its classification phase."""
+def cpu_baseline(dr, eng, cls, phases, n_reads: int, m: int, pop: int, seeds, k: int, tile: int, genome: int, budget_s: float = 10.0):
+    """Like-for-like CPU baseline: the oracle's serial process_read loop (hash, query, decide,
+    insert; OpenMP over tiles like the reference, goldrush_path.cpp:1229-1256) on the SAME
+    filter as the measured run and on the same two regimes of the stream:
+      head    reads 0.. of the stream on the freshly built miBF (the bit vector of ALL reads,
+              exported from the GPU, empty ID arrays) — the insert-heavy start of the path;
+      steady  the last reads of the stream on the GPU's END state (ID and count arrays
+              exported from the GPU into the oracle's arrays).
+    `value` = whole-stream estimate: the measured run's head / steady read counts at the two
+    CPU rates."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc  # test infrastructure: used here only as the timed CPU baseline
     from goldrush_amd import host, synth
 
     orc.build()
-    reads = dr.download(0, n_sample)
+    n_s = 1024
+    head = dr.download(0, n_s)
+    s0 = n_reads - n_s
+    steady = dr.download(s0, n_s)
     tmp = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"grp_bench_cpu_{os.getpid()}")
     os.makedirs(tmp, exist_ok=True)
     fq = os.path.join(tmp, "sample.fq")
-    synth.write_fastq(fq, [(b"r%d" % i, s, b"5" * len(s)) for i, s in enumerate(reads)])
+    synth.write_fastq(fq, [(b"r%d" % i, s, b"5" * len(s)) for i, s in enumerate(head + steady)])
+    del head, steady
     cores = int(host.load().gr_effective_cpus())  # affinity mask and cgroup quota
+    bits = eng.export_bits()  # the filter of the whole data set
     args = ["-k", str(k), "-w16", "-t", str(tile), "-h", str(len(seeds)), "-s", PRESET, "-g", str(genome), "-P10", "-d50", "-m0",
             "-j", str(cores), "-i", fq, "-p", os.path.join(tmp, "o")]
-    p = orc.Path(args)
+    p = orc.Path(args, external_bits=bits)
     assert p.ok and p.filter_size() == m
-    t0 = time.time()
-    done = 0
-    for i in range(p.n_reads):
-        p.process(i)
-        done += 1
-        if time.time() - t0 > budget_s:
-            break
-    dt = time.time() - t0
-    fill_s, _ = p.timers()
+    del bits
+    lib = orc.load()
+    mh = p.mibf_handle()
+    assert lib.orcpy_mibf_pop(mh) == pop, "the oracle's rank build disagrees with the GPU's"
+
+    def timed(first, count):
+        t0 = time.time()
+        done = ins = 0
+        for i in range(first, first + count):
+            d = p.process(i)
+            done += 1
+            ins += 1 if d.decision in (2, 4) else 0
+            if time.time() - t0 > budget_s:
+                break
+        return done, ins, time.time() - t0
+
+    h_done, h_ins, h_dt = timed(0, n_s)
+    # the GPU's end state -> the oracle's arrays (chunks: the export stages through device memory)
+    ids_p, cnt_p = lib.orcpy_mibf_data(mh), lib.orcpy_mibf_counts(mh)
+    chunk = 1 << 28
+    for a0 in range(0, pop, chunk):
+        n = min(chunk, pop - a0)
+        eng._check(eng.lib.grp_export_ids(eng._h, a0, n, C.c_void_p(ids_p + 4 * a0), C.c_void_p(cnt_p + 4 * a0)))
+    st = cls.state()
+    p.set_state(st["ids_inserted"], st["inserted_bases"], st["id"])
+    s_done, s_ins, s_dt = timed(n_s, n_s)
     p.close()
     for f in os.listdir(tmp):
         os.remove(os.path.join(tmp, f))
     os.rmdir(tmp)
-    return {"value": done / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"head of the stream: first {done} reads (filter filled with the first {n_sample} reads only, same m={m}); oracle process_read loop "
-                      f"(hash + query + decide + insert), OpenMP over tiles, {cores} threads",
-            "fill_reads_per_s": n_sample / fill_s if fill_s > 0 else None}
+    h_rate, s_rate = h_done / h_dt, s_done / s_dt
+    hr, sr = phases["head"]["reads"], phases["steady"]["reads"]
+    whole = (hr + sr) / (hr / h_rate + sr / s_rate)
+    return {"value": whole, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": f"same filter (bit vector of all {n_reads} reads exported from the GPU, m={m}); head: reads 0..{h_done} on the empty ID arrays "
+                      f"({h_ins} inserts); steady: reads {s0}..{s0 + s_done} on the GPU's end state (IDs / counts exported, {s_ins} inserts); oracle process_read loop "
+                      f"(hash + query + decide + insert), OpenMP over tiles, {cores} threads; value = the run's {hr} head / {sr} steady reads at the two CPU rates",
+            "head_reads_per_s": h_rate, "steady_reads_per_s": s_rate, "head_sample_reads": h_done, "steady_sample_reads": s_done}
 
 
 def warm_up(native, host, steps: int, device: int, h: int):
@@ -316,18 +295,17 @@ def main():
         # device, and two PCIe copies per call; RCCL is used where bulk data moves (the
         # bit-vector all-gather above).
         if os.path.isdir("/dev/shm") and not os.environ.get("GRP_BENCH_NO_SHM"):
-            try:
-                shm = ShmAllgather(world, rank, "%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run")), dist.barrier)
-            except Exception as e:
-                if rank == 0:
-                    sys.stderr.write("bench: no /dev/shm exchange (%s), using a gloo group\n" % e)
-                shm = None
-        if shm is not None:
+            # libgrpath_host's node-local exchange (C++: no Python between the classifier and the other ranks)
+            key = "bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run"))
+            shm = hl.gr_shm_allgather_open(world, rank, key.encode(), 120.0)
+            if not shm and rank == 0:
+                sys.stderr.write("bench: no /dev/shm exchange, using a gloo group\n")
+        if shm:
             # the exchange costs tens of microseconds here, not hundreds: shorter stripes
             # (less speculative work lost per insert) still hide it behind the launches
             os.environ.setdefault("GRP_STRIPE", str(64 + 8 * world))
         ctrl, ctrl_dev = None, "cpu"
-        if shm is None and a.backend == "nccl":
+        if not shm and a.backend == "nccl":
             try:
                 ctrl = dist.new_group(backend="gloo")
             except Exception as e:  # no usable CPU transport: stay on RCCL, without persistent launches beside it
@@ -340,9 +318,6 @@ def main():
         def allgather(user, send, nbytes, recv):  # noqa: E306
             src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
             dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
-            if shm is not None:
-                shm(src, dst)
-                return 0
             b = bufs.get(nbytes)
             if b is None:
                 b = (torch.empty(nbytes, dtype=torch.uint8, device=ctrl_dev), torch.empty(nbytes * world, dtype=torch.uint8, device=ctrl_dev))
@@ -359,7 +334,9 @@ def main():
 
     cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
                           target_bases=int(0.9 * G), max_paths=1, silver_path=False, max_window=a.max_window, world=world, rank=rank,
-                          allgather=allgather, record=False)
+                          allgather=None if shm else allgather, record=False)
+    if shm:
+        hl.gr_classifier_set_allgather(cls._h, C.cast(hl.gr_shm_allgather, C.c_void_p), shm)
     lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
     slices = []  # (reads, seconds, inserts) per timing slice, rank 0's clock
 
@@ -495,11 +472,11 @@ def main():
                     "wall_s": dt},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dr, 1024, m, seeds, k, tile, G)
+            out["cpu_baseline"] = cpu_baseline(dr, eng, cls, out["phases"], n_reads, m, pop, seeds, k, tile, G)
         print(json.dumps(out), flush=True)
     if world > 1:
-        if shm is not None:
-            shm.close(dist.barrier)
+        if shm:
+            hl.gr_shm_allgather_close(shm)
         dist.barrier()
         dist.destroy_process_group()
 

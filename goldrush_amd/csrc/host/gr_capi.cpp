@@ -192,6 +192,14 @@ gr_classifier_destroy(gr_classifier* c)
 }
 
 void
+gr_classifier_set_allgather(gr_classifier* c, gr_allgather_fn allgather, void* allgather_user)
+{
+  if (c) {
+    c->impl.set_allgather(allgather, allgather_user);
+  }
+}
+
+void
 gr_classifier_set_callbacks(gr_classifier* c, gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user)
 {
   c->impl.set_callbacks(commit, rollover, allgather, user);

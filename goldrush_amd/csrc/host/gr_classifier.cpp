@@ -38,6 +38,14 @@ Classifier::set_callbacks(gr_commit_fn commit, gr_rollover_fn rollover, gr_allga
   rollover_cb_ = rollover;
   allgather_cb_ = allgather;
   user_ = user;
+  ag_user_ = user;
+}
+
+void
+Classifier::set_allgather(gr_allgather_fn allgather, void* allgather_user)
+{
+  allgather_cb_ = allgather;
+  ag_user_ = allgather_user;
 }
 
 void
@@ -297,7 +305,7 @@ Classifier::gather_decisions(uint32_t q)
       err_ = "world > 1 but no allgather callback";
       return GRP_ERR_INVALID;
     }
-    int rc = allgather_cb_(user_, dec_.data(), (uint64_t)q * sizeof(gr_read_decision), dec_all_.data());
+    int rc = allgather_cb_(ag_user_, dec_.data(), (uint64_t)q * sizeof(gr_read_decision), dec_all_.data());
     if (rc != 0) {
       err_ = "allgather callback failed";
       return GRP_ERR_INVALID;
@@ -651,7 +659,7 @@ Classifier::stream_decision(uint32_t j, gr_read_decision& d)
       }
     }
     stripe_recv_.resize(GW);
-    if (allgather_cb_(user_, stripe_send_.data(), (uint64_t)C * sizeof(gr_read_decision), stripe_recv_.data()) != 0) {
+    if (allgather_cb_(ag_user_, stripe_send_.data(), (uint64_t)C * sizeof(gr_read_decision), stripe_recv_.data()) != 0) {
       err_ = "allgather callback failed";
       return GRP_ERR_INVALID;
     }

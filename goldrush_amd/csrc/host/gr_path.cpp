@@ -20,6 +20,7 @@
 #include <iostream>
 #include <memory>
 #include <unordered_set>
+#include <unistd.h>
 #if defined(_OPENMP)
 #include <omp.h>
 #endif
@@ -67,6 +68,7 @@ struct PathRun
   std::vector<std::string> seeds;
   std::unordered_set<std::string> filter_out_reads;
   std::ofstream out;
+  uint32_t world = 1, rank = 0; // ranks sharing the classification windows (one process per GPU)
 
   int fail_engine(const char* what)
   {
@@ -601,7 +603,7 @@ rollover_sink(void* user, uint64_t new_path)
   // golden_path_vec.pop_back(); emplace_back(ofstream(prefix + "_" + path + ".fq"))  (:182-184)
   PathRun& run = *static_cast<SinkState*>(user)->run;
   run.out.close();
-  run.out.open(run.opt.prefix_file + "_" + std::to_string(new_path) + ".fq");
+  run.out.open(run.rank == 0 ? run.opt.prefix_file + "_" + std::to_string(new_path) + ".fq" : std::string("/dev/null"));
 }
 
 } // namespace
@@ -614,9 +616,59 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   PathRun run;
   run.vt = *vt;
   Opts& opt = run.opt;
+  // Several GPUs of one node: one process per GPU (GRP_WORLD / GRP_RANK, or the launcher's
+  // WORLD_SIZE / RANK; LOCAL_RANK picks the device).  Every rank runs the whole program on
+  // its own replica of the miBF — the same input, the same passes, every insert — and the
+  // ranks share the QUERY work of each classification window (gr_classifier: the window's
+  // reads are split / striped over the ranks, the 32-byte decisions all-gathered through
+  // /dev/shm).  Rank 0 writes the files and the log; the others are silent.
+  auto env_u32 = [](const char* a, const char* b, uint32_t dflt) {
+    const char* e = getenv(a);
+    if (!e || !*e) {
+      e = getenv(b);
+    }
+    return (e && *e) ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
+  };
+  run.world = std::max<uint32_t>(1, env_u32("GRP_WORLD", "WORLD_SIZE", 1));
+  run.rank = env_u32("GRP_RANK", "RANK", 0);
+  if (run.rank >= run.world) {
+    std::cerr << "goldrush-path: rank " << run.rank << " outside the world of " << run.world << std::endl;
+    return 1;
+  }
+  struct Quiet // ranks > 0: nothing on stdout / stderr
+  {
+    std::streambuf *cerr_buf = nullptr, *cout_buf = nullptr;
+    std::ofstream null;
+    ~Quiet()
+    {
+      if (cerr_buf) {
+        std::cerr.rdbuf(cerr_buf);
+        std::cout.rdbuf(cout_buf);
+      }
+    }
+  } quiet;
+  if (run.rank != 0) {
+    quiet.null.open("/dev/null");
+    quiet.cerr_buf = std::cerr.rdbuf(quiet.null.rdbuf());
+    quiet.cout_buf = std::cout.rdbuf(quiet.null.rdbuf());
+  }
   int ec = process_options(opt, argc, argv);
   if (ec >= 0) {
     return ec;
+  }
+  struct ShmGuard
+  {
+    void* h = nullptr;
+    ~ShmGuard() { gr_shm_allgather_close(h); }
+  } shm;
+  if (run.world > 1) {
+    const char* key = getenv("GRP_SHM_KEY");
+    std::string k = key && *key ? key : std::string("path_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + "_" + std::to_string((unsigned long)getppid());
+    shm.h = gr_shm_allgather_open(run.world, run.rank, k.c_str(), 120.0);
+    if (!shm.h) {
+      std::cerr << "goldrush-path: cannot set up the exchange between the " << run.world << " ranks (/dev/shm/grp_" << k << ")" << std::endl;
+      return 1;
+    }
   }
 #if defined(_OPENMP)
   // the reference uses -j for its OpenMP regions; here it only drives the host
@@ -649,7 +701,7 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     gp.tile = (uint32_t)opt.tile_length;
     gp.m = filter_size;
     gp.seeds = sp.data();
-    gp.device = -1;
+    gp.device = run.world > 1 ? (int32_t)env_u32("GRP_LOCAL_RANK", "LOCAL_RANK", run.rank) : -1;
     if (run.vt.create(&gp, &run.ctx) != GRP_OK) {
       std::cerr << "goldrush-path: cannot set up the MI355X engine: " << (run.vt.last_error ? run.vt.last_error(nullptr) : "") << std::endl;
       return 1;
@@ -703,7 +755,7 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
       run.filter_out_reads.insert(name);
     }
   }
-  run.out.open(opt.silver_path ? opt.prefix_file + "_1.fq" : opt.prefix_file + ".fa");
+  run.out.open(run.rank != 0 ? std::string("/dev/null") : opt.silver_path ? opt.prefix_file + "_1.fq" : opt.prefix_file + ".fa");
   double s_time = now_s();
   std::cerr << "allocating bit vector" << std::endl;
   std::cerr << "m_filterSize: " << filter_size << std::endl;
@@ -735,12 +787,15 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   cp.max_paths = opt.max_paths;
   cp.silver_path = opt.silver_path;
   cp.verbose = opt.verbose;
-  cp.world = 1;
-  cp.rank = 0;
+  cp.world = run.world;
+  cp.rank = run.rank;
   Classifier cls(cp, run.vt, run.ctx);
   SinkState sink;
   sink.run = &run;
   cls.set_callbacks(commit_sink, rollover_sink, nullptr, &sink);
+  if (run.world > 1) {
+    cls.set_allgather(gr_shm_allgather, shm.h);
+  }
 
   {
     auto src = open_source(run);

@@ -104,6 +104,10 @@ SIGNATURES = {
     "gr_eval_flanks": (C.c_int, [C.c_long, C.c_long, _vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "gr_classifier_create": (C.c_int, [C.POINTER(gr_classifier_params), C.POINTER(grp_engine_vt), _vp, C.POINTER(_vp)]),
     "gr_classifier_destroy": (None, [_vp]),
+    "gr_classifier_set_allgather": (None, [_vp, _vp, _vp]),
+    "gr_shm_allgather_open": (_vp, [C.c_uint32, C.c_uint32, C.c_char_p, C.c_double]),
+    "gr_shm_allgather": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "gr_shm_allgather_close": (None, [_vp]),
     "gr_classifier_set_callbacks": (None, [_vp, COMMIT_FN, ROLLOVER_FN, ALLGATHER_FN, _vp]),
     "gr_classifier_run": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_int)]),
     "gr_classifier_run_range": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_int)]),

@@ -135,11 +135,23 @@ typedef void (*gr_rollover_fn)(void* user, uint64_t new_path);
 /* all-gather of `bytes` per rank (rank r's block at recv + r*bytes); NULL for world==1 */
 typedef int (*gr_allgather_fn)(void* user, const void* send, uint64_t bytes, void* recv);
 
+/* ---- node-local all-gather through /dev/shm (what the ranks of a multi-GPU classification
+ * exchange: 32-byte decision records, a few KB per call) ---------------------------------
+ * _open   rank 0 creates /dev/shm/grp_<key>, the others attach; returns NULL on failure /
+ *         after timeout_s.  All `world` ranks of one node call it with the same key.
+ * gr_shm_allgather has the signature of gr_allgather_fn with user = the handle.
+ * _close  detaches; rank 0 removes the file. */
+void* gr_shm_allgather_open(uint32_t world, uint32_t rank, const char* key, double timeout_s);
+int gr_shm_allgather(void* handle, const void* send, uint64_t bytes, void* recv);
+void gr_shm_allgather_close(void* handle);
+
 typedef struct gr_classifier gr_classifier;
 
 int gr_classifier_create(const gr_classifier_params* p, const grp_engine_vt* vt, void* engine_ctx, gr_classifier** out);
 void gr_classifier_destroy(gr_classifier* c);
 void gr_classifier_set_callbacks(gr_classifier* c, gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user);
+/* the all-gather with its own user pointer (e.g. gr_shm_allgather + its handle) */
+void gr_classifier_set_allgather(gr_classifier* c, gr_allgather_fn allgather, void* allgather_user);
 /*
  * Classify reads [0, n_reads) of an uploaded batch, in order, exactly as the
  * reference's serial process_read loop would (goldrush_path.cpp:1229-1256):

@@ -116,6 +116,8 @@ def load():
         "orc_path_open": (vp, [C.POINTER(orc_opts), C.POINTER(orc_reads), vp, C.POINTER(C.c_int)]),
         "orc_path_process_read": (None, [vp, sz, C.POINTER(orc_decision)]),
         "orc_path_close": (None, [vp]),
+        "orc_path_use_external_bits": (None, [vp, u64]),
+        "orc_path_set_state": (None, [vp, u32, u64, u32]),
         "orc_path_mibf": (vp, [vp]), "orc_path_log_info": (C.POINTER(orc_log_info), [vp]),
         "orc_path_phred_min": (u32, [vp]), "orc_path_seed": (C.c_char_p, [vp, C.c_uint]),
         "orc_path_filter_size": (u64, [vp]), "orc_path_is_filtered": (C.c_int, [vp, sz]),
@@ -342,8 +344,10 @@ def parse_opts(argv):
 class Path:
     """orc_path: main() + process_read() of the reference, read by read."""
 
-    def __init__(self, argv, log_path: str | None = None):
+    def __init__(self, argv, log_path: str | None = None, external_bits=None):
         self.lib = load()
+        if external_bits is not None:  # uint64 words of the whole data set's bit vector, OR-ed in before the rank build
+            self.lib.orc_path_use_external_bits(_p(external_bits), external_bits.size)
         self.opts, rc = parse_opts(argv)
         if rc >= 0:
             raise SystemExit(rc)
@@ -381,6 +385,12 @@ class Path:
             if d.finished:
                 break
         return out
+
+    def set_state(self, ids_inserted: int, inserted_bases: int, id_: int):
+        self.lib.orc_path_set_state(self._h, ids_inserted, inserted_bases, id_)
+
+    def mibf_handle(self):
+        return self.lib.orc_path_mibf(self._h)
 
     def mibf(self, tile: int, k: int, seeds: Seeds) -> MiBF:
         h = self.lib.orc_path_mibf(self._h)

@@ -1409,6 +1409,29 @@ fill_bit_vector(orc_path* p)
   return -1;
 }
 
+/* bench.py's like-for-like CPU baseline: the bit vector of the whole data set (filled on
+ * the GPU from all reads) is OR-ed into the next path that is opened, so that a path opened
+ * on a SAMPLE of the reads probes the same filter as the measured run */
+static const uint64_t* g_external_bits = NULL;
+static uint64_t g_external_words = 0;
+
+void
+orc_path_use_external_bits(const uint64_t* words, uint64_t n_words)
+{
+  g_external_bits = words;
+  g_external_words = n_words;
+}
+
+/* the loop state in front of the next read (goldrush_path.cpp:1222-1227), for a path that
+ * continues from an imported miBF state */
+void
+orc_path_set_state(orc_path* p, uint32_t ids_inserted, uint64_t inserted_bases, uint32_t id)
+{
+  p->ids_inserted = ids_inserted;
+  p->inserted_bases = inserted_bases;
+  p->id = id;
+}
+
 orc_path*
 orc_path_open(const orc_opts* o, const orc_reads* reads, FILE* log, int* exit_code)
 {
@@ -1524,6 +1547,17 @@ orc_path_open(const orc_opts* o, const orc_reads* reads, FILE* log, int* exit_co
     *exit_code = ec;
     orc_path_close(p);
     return NULL;
+  }
+  if (g_external_bits) {
+    const uint64_t nw = g_external_words < p->mibf->n_words ? g_external_words : p->mibf->n_words;
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static)
+#endif
+    for (uint64_t i = 0; i < nw; ++i) {
+      p->mibf->bv[i] |= g_external_bits[i];
+    }
+    g_external_bits = NULL;
+    g_external_words = 0;
   }
   orc_mibf_finalize(p->mibf); /* :1203-1205 */
   LOGF(p, "assigning tiles\n");

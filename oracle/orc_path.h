@@ -202,6 +202,11 @@ typedef struct orc_path orc_path;
  * loaded reads.  Returns NULL and sets *exit_code when the reference would
  * have exited. log goes where std::cerr went (may be NULL). */
 orc_path* orc_path_open(const orc_opts* o, const orc_reads* reads, FILE* log, int* exit_code);
+/* bench.py (like-for-like CPU baseline): OR these words into the bit vector of the NEXT path
+ * that is opened (the filter of the whole data set, a path opened on a sample of the reads);
+ * and continue a path from an imported state */
+void orc_path_use_external_bits(const uint64_t* words, uint64_t n_words);
+void orc_path_set_state(orc_path* p, uint32_t ids_inserted, uint64_t inserted_bases, uint32_t id);
 /* process_read (:892-1094) for reads->rec[idx]; fills *dec */
 void orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec);
 /* tail of main() (:1257-1273) and cleanup */

@@ -68,3 +68,36 @@ def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_
             "\tminimum average phred", "num_", "Total reads skipped")
     pick = lambda text: [l for l in text.splitlines() if l.startswith(keep)]  # noqa: E731
     assert pick(rp.stderr) == pick(ro.stderr)
+
+
+@pytest.mark.parametrize("mode", ["silver", "golden"])
+def test_two_ranks_of_the_host_program_write_what_one_rank_writes(oracle, native, tmp_path, mode):
+    """goldrush-path as two processes (GRP_WORLD=2: one per GPU on a real node; here two
+    oracle-backed engines): the ranks share the query work of every window and exchange the
+    decisions through /dev/shm; rank 0 writes files identical to the oracle CLI's, rank 1
+    writes nothing."""
+    fq = os.path.join(GOLD, "tiny.fq")
+    common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-i", fq, "--verbose"]
+    args = common + (["-P0", "-r0.9", "--silver_path", "-M3", "-m1500"] if mode == "silver" else ["-P12", "-m0"])
+    d_o, d_p = tmp_path / "o", tmp_path / "p"
+    d_o.mkdir()
+    d_p.mkdir()
+    ro = oracle.run_cli(args + ["-p", str(d_o / "out")], timeout=600)
+    script = tmp_path / "runner.py"
+    script.write_text(RUNNER.format(root=ROOT))
+    key = "test_cli_%d_%s" % (os.getpid(), mode)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, GRP_HOST_INGEST="1", OMP_NUM_THREADS="2", GRP_WORLD="2", GRP_RANK=str(rank), GRP_SHM_KEY=key, GRP_BATCH_RECORDS="9")
+        procs.append(subprocess.Popen([sys.executable, str(script)] + args + ["-p", str(d_p / "out")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert [p.returncode for p in procs] == [ro.returncode, ro.returncode], [o[1][-2000:] for o in outs]
+    fo, fp = sorted(os.listdir(d_o)), sorted(os.listdir(d_p))
+    assert fo == fp and fo, (fo, fp)
+    for f in fo:
+        assert filecmp.cmp(d_o / f, d_p / f, shallow=False), f
+    keep = ("Visited", "Saw:", "Assigned:", "Unassigned:", "Total queries", "Total hits", "Total misses", "Num reads", "m_filterSize")
+    pick = lambda text: [l for l in text.splitlines() if l.startswith(keep)]  # noqa: E731
+    assert pick(outs[0][1]) == pick(ro.stderr)
+    assert outs[1][1].strip() == "" and outs[1][0].strip() == ""  # rank 1 is silent
+    assert not os.path.exists("/dev/shm/grp_" + key)
