@@ -257,27 +257,39 @@ def main():
         eng.bv_insert(rb)
         eng.sync()
     else:
-        # the fill shards by reads; the merge is a bitwise OR, done as an
-        # all-gather of the plain bit vectors (RCCL has no OR reduction) + local ORs
+        # the fill shards by reads and its merge is a bitwise OR.  RCCL has no OR
+        # reduction, so the OR "all-reduce" is spelled out as reduce-scatter + all-gather: slice r
+        # of every rank's vector goes to rank r (all-to-all), rank r ORs them (grp_words_or_device),
+        # the merged slices are all-gathered: 2 x (N-1)/N of one vector per rank over xGMI and one
+        # extra vector of HBM, instead of N-1 whole vectors each way.
         shard = (n_reads + world - 1) // world
         lo, hi = min(rank * shard, n_reads), min((rank + 1) * shard, n_reads)
         eng.bv_insert(rb, lo, hi - lo)
         eng.sync()
-        nbytes = eng.bv_words() * 4
-        mine = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        n_words = eng.bv_words()
+        slice_words = ((n_words + world - 1) // world + 3) // 4 * 4
+        mine = torch.zeros(slice_words * world * 4, dtype=torch.uint8, device="cuda")
         eng.bv_export_device(mine.data_ptr())
+        got = torch.empty_like(mine)  # slice `rank` of every rank's vector
         if coll_dev == "cuda":
-            allbv = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
-            dist.all_gather_into_tensor(allbv, mine)
+            dist.all_to_all_single(got, mine)
         else:
-            tmp = torch.empty(nbytes * world, dtype=torch.uint8)
-            dist.all_gather_into_tensor(tmp, mine.cpu())
-            allbv = tmp.cuda()
+            tmp = torch.empty(mine.numel(), dtype=torch.uint8)
+            dist.all_to_all_single(tmp, mine.cpu())
+            got.copy_(tmp)
         torch.cuda.synchronize()
-        for p in range(world):
-            if p != rank:
-                eng.bv_merge_device(allbv.data_ptr() + p * nbytes)
-        del allbv, mine
+        for p in range(1, world):
+            eng.words_or_device(got.data_ptr(), got.data_ptr() + p * slice_words * 4, slice_words)
+        merged = got[: slice_words * 4]
+        if coll_dev == "cuda":
+            dist.all_gather_into_tensor(mine, merged)
+        else:
+            tmp = torch.empty(mine.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(tmp, merged.cpu())
+            mine.copy_(tmp)
+        torch.cuda.synchronize()
+        eng.bv_import_device(mine.data_ptr())
+        del got, mine, merged
     t_fill = time.time() - t0
     fill_stats = eng.kernel_stats()["fill"]
     t0 = time.time()
@@ -463,7 +475,7 @@ def main():
                                 "definition": "slices before the first %d-read slice with an insert rate < 1 %%" % PHASE_SLICE},
                        "steady": {"reads": tail_reads, "seconds": tail_s, "reads_per_s": tail_reads / tail_s if tail_s > 0 else None, "inserts": tail_ins}},
             "aux": {"fill_reads_per_s": n_reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill, "finalize_s": t_finalize,
-                    "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors all-gathered and OR-merged" % world, "synth_s": t_synth,
+                    "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors OR-merged as reduce-scatter (all-to-all + OR) + all-gather" % world, "synth_s": t_synth,
                     "warmup_s": t_warm, "warmup_mode": "%d steps of 512 reads on a throw-away engine (G=2e6)" % a.warmup,
                     "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit")},
                     "query_Gprobes_per_s": gprobes,

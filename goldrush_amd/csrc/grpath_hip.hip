@@ -1018,6 +1018,39 @@ grp_bv_merge_device(grp_ctx* c, const void* d_src)
 }
 
 int
+grp_words_or_device(grp_ctx* c, void* d_dst, const void* d_src, uint64_t n_words32)
+{
+  if (!c || !d_dst || !d_src || ((reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(d_src)) & 15u) != 0) {
+    return set_err(c, GRP_ERR_INVALID, "grp_words_or_device: null or unaligned buffer");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t n4 = n_words32 / 4;
+  const uint32_t tail = (uint32_t)(n_words32 - n4 * 4);
+  k_bv_or<<<dim3(4096), dim3(THREADS), 0, c->stream>>>(static_cast<uint4*>(d_dst), static_cast<const uint4*>(d_src), n4, static_cast<uint32_t*>(d_dst) + n4 * 4, static_cast<const uint32_t*>(d_src) + n4 * 4, tail);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return GRP_OK;
+}
+
+int
+grp_bv_import_device(grp_ctx* c, const void* d_src)
+{
+  if (!c || !d_src) {
+    return GRP_ERR_INVALID;
+  }
+  if (c->finalized) {
+    return set_err(c, GRP_ERR_STATE, "grp_bv_import_device after grp_finalize: the bit vector is immutable");
+  }
+  if (c->f.m == 0) {
+    return set_err(c, GRP_ERR_STATE, "grp_bv_import_device: the filter size is not set (grp_set_filter_size)");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(c->f.bv, d_src, c->n_bv_words * 4, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return GRP_OK;
+}
+
+int
 grp_finalize(grp_ctx* c, uint64_t* pop)
 {
   if (!c) {

@@ -93,6 +93,8 @@ SIGNATURES = {
     "grp_bv_words": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "grp_bv_export_device": (C.c_int, [_vp, _vp]),
     "grp_bv_merge_device": (C.c_int, [_vp, _vp]),
+    "grp_words_or_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "grp_bv_import_device": (C.c_int, [_vp, _vp]),
     "grp_finalize": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "grp_query_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(grp_query_stats)]),
     "grp_classify_reads": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp]),
@@ -360,6 +362,12 @@ class Engine:
 
     def bv_merge_device(self, d_ptr: int):
         self._check(self.lib.grp_bv_merge_device(self._h, C.c_void_p(d_ptr)))
+
+    def words_or_device(self, d_dst: int, d_src: int, n_words32: int):
+        self._check(self.lib.grp_words_or_device(self._h, C.c_void_p(d_dst), C.c_void_p(d_src), n_words32))
+
+    def bv_import_device(self, d_ptr: int):
+        self._check(self.lib.grp_bv_import_device(self._h, C.c_void_p(d_ptr)))
 
     def finalize(self) -> int:
         pop = C.c_uint64()

@@ -167,6 +167,18 @@ int grp_bv_insert(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t
 int grp_bv_words(const grp_ctx* ctx, uint64_t* n_words32);
 int grp_bv_export_device(grp_ctx* ctx, void* d_dst);
 int grp_bv_merge_device(grp_ctx* ctx, const void* d_src);
+/*
+ * The bandwidth-optimal form of the same merge for N ranks (an OR "all-reduce" done as
+ * reduce-scatter + all-gather: every rank receives slice r of every other rank's vector
+ * (all-to-all), ORs them, and the merged slices are all-gathered — 2 x (N-1)/N of one
+ * vector per rank instead of N-1 whole vectors):
+ *   grp_words_or_device   dst |= src for n 32-bit words of DEVICE memory (16-byte aligned;
+ *                         any buffers of ctx's device, not the bit vector itself)
+ *   grp_bv_import_device  overwrite the bit vector with caller-provided DEVICE memory
+ *                         (grp_bv_words words; the merged vector)
+ */
+int grp_words_or_device(grp_ctx* ctx, void* d_dst, const void* d_src, uint64_t n_words32);
+int grp_bv_import_device(grp_ctx* ctx, const void* d_src);
 
 /*
  * Replaces: miBFCS.setup(); miBFCS.getEmptyMIBF()
