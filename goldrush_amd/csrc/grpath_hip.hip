@@ -482,6 +482,13 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
       if (sv == "1,16" && c->uniform_weight == 16) return go(k_query<HH, 1, 16, false>);
     }
   }
+  if constexpr (HH == 3) {
+    // latency windows (a few reads on an otherwise idle device): a wave's time is the chain of
+    // its own instructions; the unrolled care loop shortens it
+    if (c->uniform_weight == 16 && n_launch <= SMALL_TILES) {
+      return go(k_query<HH, 2, 16, false>);
+    }
+  }
   return go(k_query<HH, 2, 0, false>);
 }
 
@@ -1980,7 +1987,11 @@ grp_insert_read(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t tile
   const size_t lds = tab_bytes(c) + bases_bytes(c->params.tile + c->params.k + c->params.h);
   {
     Timer t(c, GRP_K_INSERT, max_ranks);
-    DISPATCH_H(c->params.h, (k_insert_collect<HH><<<dim3(nt * ((c->params.tile + THREADS - 1) / THREADS)), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, read_idx, tile_start, block_tiles, tb, parity)));
+    if (c->uniform_weight == 16) { // make_seed_pattern's default weight: care loop unrolled (the launch is latency-bound)
+      DISPATCH_H(c->params.h, (k_insert_collect<HH, 16><<<dim3(nt * ((c->params.tile + THREADS - 1) / THREADS)), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, read_idx, tile_start, block_tiles, tb, parity)));
+    } else {
+      DISPATCH_H(c->params.h, (k_insert_collect<HH, 0><<<dim3(nt * ((c->params.tile + THREADS - 1) / THREADS)), dim3(THREADS), lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, read_idx, tile_start, block_tiles, tb, parity)));
+    }
     k_insert_apply<<<dim3((uint32_t)((max_ranks + THREADS - 1) / THREADS)), dim3(THREADS), 0, c->stream>>>(c->f, tb, parity, block_tiles, first_id, id_offset);
   }
   HIP_TRY(c, hipGetLastError());
