@@ -461,7 +461,8 @@ def main():
                        "parallelism": ("one GPU, streaming windows" if world == 1 else "windows striped over %d GPUs, replicated miBF, 32-B decisions all-gathered per stripe group" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC pass of the same kernel, %s, scaled by probes)" % (os.path.basename(pmc_file) if pmc_file else "none"),
-                         "kernel": "k_query", "launches": kq["launches"], "avg_launch_ms": avg_ms,
+                         "kernel": "k_query, throughput forms (streaming windows k_query<h,1,0,true>, large windows k_query<h,2,0,false>); the latency windows of the insert-heavy head are in aux.query_latency",
+                         "launches": kq["launches"], "avg_launch_ms": avg_ms,
                          "probes_per_launch": probes_per_launch, "bytes_per_probe": 128,
                          "note": "achieved/frac use the ALGORITHMIC 128 B per probe of SURVEY 8(d) (the reference's two-sector probe); this layout moves one 64-B bucket per probe, see moved_*; the kernel's real bound is the random-line rate, see line_rate_*",
                          "moved_bytes_per_probe": bytes_per_probe_moved,
@@ -481,6 +482,9 @@ def main():
                     "query_Gprobes_per_s": gprobes,
                     "query_kernel_s": kq_s, "decide_kernel_s": ks["decide"]["ms"] * 1e-3, "decide_launches": ks["decide"]["launches"],
                     "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
+                    "query_latency": {"launches": ks["query_latency"]["launches"], "kernel_s": ks["query_latency"]["ms"] * 1e-3, "probes": ks["query_latency"]["units"],
+                                      "what": "k_query<h,2,16,false> on windows of a few reads, summaries written straight to host memory"},
+                    "commit_loop": {"launches": ks["loop"]["launches"], "kernel_s": ks["loop"]["ms"] * 1e-3, "probes": ks["loop"]["units"]},
                     "wall_s": dt},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -187,7 +187,7 @@ struct grp_ctx
   uint64_t ir_cap = 0;
   uint32_t ir_parity = 0;
   double* d_delog = nullptr; // 10^(-Q/10) table for the FASTQ ingest
-  uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE);
+  uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT);
   // timing
   bool timing = true;
   std::vector<EventPair> pending;
@@ -894,8 +894,20 @@ grp_reads_free(grp_reads* r)
   if (!r) {
     return;
   }
-  if (r->ctx && r->ctx->stream) {
-    (void)hipStreamSynchronize(r->ctx->stream);
+  if (r->ctx) {
+    // a pipelined window that was abandoned may still run its decision kernel and copy-back on
+    // the second stream; both read this batch's arrays
+    if (r->ctx->stream2) {
+      (void)hipStreamSynchronize(r->ctx->stream2);
+    }
+    if (r->ctx->stream) {
+      (void)hipStreamSynchronize(r->ctx->stream);
+    }
+    for (QuerySlot& sl : r->ctx->slot) {
+      if (sl.reads == r && !sl.busy) {
+        sl.reads = nullptr;
+      }
+    }
   }
   if (r->owns_packed) {
     (void)hipFree(r->d_packed);
@@ -1314,7 +1326,7 @@ grp_query_tiles(grp_ctx* c,
     }
     {
       const QueryGeom g = query_geom(c, false);
-      Timer t(c, GRP_K_QUERY, probes);
+      Timer t(c, GRP_K_QUERY_LAT, probes);
       int lrc = GRP_OK;
       DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, nt, t0, nullptr, g, (uint64_t)SMALL_TILES * SMALL_STRIDE, c->dmap_small_tiles, c->dmap_small_lists, SMALL_STRIDE));
       if (lrc != GRP_OK) {
@@ -1678,6 +1690,11 @@ grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first
   }
   if (!c->finalized) {
     return set_err(c, GRP_ERR_STATE, "grp_classify_stream_begin before grp_finalize");
+  }
+  if (!c->coherent_arch) {
+    // the hand-over between workgroups inside the launch relies on agent-scope accesses being
+    // served by the memory side, in issue order (gfx942 / gfx950); not a portable guarantee
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_stream_begin: streaming windows are only enabled on gfx942 / gfx950 (this device is %s)", c->arch.c_str());
   }
   QuerySlot& sl = c->slot[slot];
   if (sl.busy) {

@@ -125,7 +125,7 @@ bool
 FastqStream::next_batch(RecordBatch& out, size_t max_records, size_t max_bases)
 {
   out.clear();
-  while (out.rec.size() < max_records && out.bases < max_bases) {
+  while (!stopped_ && out.rec.size() < max_records && out.bases < max_bases) {
     const char* p;
     size_t n;
     // get_line pointers die at the next refill, so each line is copied at once
@@ -133,7 +133,8 @@ FastqStream::next_batch(RecordBatch& out, size_t max_records, size_t max_bases)
       break;
     }
     if (n == 0 || p[0] != '@') {
-      break; // not a FASTQ header: stop like a reader at end of input
+      stopped_ = true; // not a FASTQ header: stop like a reader at end of input, for good
+      break;           // (grp_fastq_parse latches the same state: both sources see the same records)
     }
     RecordRef r{};
     size_t idn = 0;

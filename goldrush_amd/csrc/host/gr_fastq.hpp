@@ -71,6 +71,7 @@ private:
   std::vector<char> buf_;
   size_t pos_ = 0, end_ = 0;
   bool eof_ = false;
+  bool stopped_ = false; // a line that is not a FASTQ header was met: end of input for good (as the GPU ingest)
   std::vector<char> carry_;
 };
 

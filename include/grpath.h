@@ -492,7 +492,9 @@ enum
   GRP_K_DECIDE = 4,   /* read decision kernel */
   GRP_K_NTCARD = 5,   /* --ntcard sampling kernel (units = hashes) */
   GRP_K_LOOP = 6,     /* ordered commit loop (query + decision + insert; units = probes queried) */
-  GRP_K_COUNT = 7
+  GRP_K_QUERY_LAT = 7, /* the query kernel in its latency form: windows of a few reads written straight to
+                          host memory (insert-heavy stretches); GRP_K_QUERY holds the throughput forms */
+  GRP_K_COUNT = 8
 };
 
 typedef struct

@@ -101,3 +101,27 @@ def test_two_ranks_of_the_host_program_write_what_one_rank_writes(oracle, native
     assert pick(outs[0][1]) == pick(ro.stderr)
     assert outs[1][1].strip() == "" and outs[1][0].strip() == ""  # rank 1 is silent
     assert not os.path.exists("/dev/shm/grp_" + key)
+
+
+def test_a_garbage_line_ends_the_input_for_good_whatever_the_batching(oracle, native, tmp_path):
+    """A line that is not a FASTQ header ends the input like an end of file — in every batching
+    of the host reader (the GPU ingest latches the same state, tests/test_gpu_ingest.py): the
+    run on the damaged file equals the run on the file cut in front of the damage."""
+    lines = open(os.path.join(GOLD, "tiny.fq"), "rb").read().split(b"\n")
+    n_ok = 20
+    cut = tmp_path / "cut.fq"
+    bad = tmp_path / "bad.fq"
+    cut.write_bytes(b"\n".join(lines[: 4 * n_ok]) + b"\n")
+    bad.write_bytes(b"\n".join(lines[: 4 * n_ok] + [b"garbage that is no header"] + lines[4 * n_ok:]))
+    common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-P12", "-m0"]
+    script = tmp_path / "runner.py"
+    script.write_text(RUNNER.format(root=ROOT))
+    outs = {}
+    for name, path, batch in (("cut", cut, 0), ("bad", bad, 0), ("bad3", bad, 3), ("bad20", bad, 20), ("bad21", bad, 21)):
+        d = tmp_path / name
+        d.mkdir()
+        rp = subprocess.run([sys.executable, str(script)] + common + ["-i", str(path), "-p", str(d / "out")], capture_output=True, text=True, timeout=900,
+                            env=dict(os.environ, GRP_HOST_INGEST="1", OMP_NUM_THREADS="2", **({"GRP_BATCH_RECORDS": str(batch)} if batch else {})))
+        assert rp.returncode == 0, rp.stderr[-2000:]
+        outs[name] = open(d / "out.fa", "rb").read()
+    assert outs["cut"] and all(v == outs["cut"] for v in outs.values())

@@ -348,3 +348,43 @@ def test_full_size_streaming_equals_synchronous_windows(native, monkeypatch, h, 
         assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert results[0][4] < results[2][4]  # the streaming run needs far fewer launches
     dr.free()
+
+
+def test_c1_stream_streaming_equals_synchronous_windows(native, monkeypatch):
+    """The race hunt of tools/stress_stream.py inside the suite: 200 000 reads of the C1 stream
+    (G = 100e6, 25 kb reads: the filter, bucket layout and insert rate of the benchmark) through
+    the streaming windows — one workgroup hands summaries to another inside a launch, the
+    launches are aborted and parked at every insert — and through the synchronous windows:
+    every commit and a 20 M-rank sample of the ID / count arrays must agree."""
+    from goldrush_amd import host
+
+    k, h, tile, block, G, n = 22, 3, 1000, 10, 100_000_000, 200_000
+    seeds = default_seeds(h)
+    hl = host.load()
+    m = hl.gr_calc_optimal_size(hl.gr_hash_universe(16, G, h), 1, 0.1)
+    dr = native.synth_reads(n, G)
+    lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
+    results = []
+    for mode in ({"GRP_STREAM": "force"}, {"GRP_STREAM": "off", "GRP_PIPELINE": "off"}):
+        for key in ("GRP_STREAM", "GRP_PIPELINE", "GRP_LOOP"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in mode.items():
+            monkeypatch.setenv(key, val)
+        eng = native.Engine(k, h, tile, m, seeds)
+        rb = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+        eng.bv_insert(rb)
+        pop = eng.finalize()
+        cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, k=k, h=h, target_bases=int(0.9 * G), max_paths=1, silver_path=False)
+        for first in range(0, n, 8192):
+            cls.run_range(rb._h, lens, first, min(8192, n - first))
+        eng.sync()
+        st = cls.state()
+        ids, counts = eng.export_ids(pop // 3, 20_000_000)
+        results.append(([c[:10] for c in cls.commits], ids, counts, {key: st[key] for key in ("inserts", "hits", "misses", "queries", "ids_inserted", "inserted_bases")}))
+        cls.close()
+        eng.close()
+    dr.free()
+    a, b = results
+    assert a[3] == b[3] and a[3]["inserts"] > 5000
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and int((a[1] != 0).sum()) > 100_000

@@ -116,3 +116,41 @@ def test_chunked_and_malformed(native):
     fq, rec5, used5, _ = eng.fastq_parse(b"@a\nACGT\n+\n", final_chunk=True)
     assert len(rec5) == 0
     eng.fastq_free(fq)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(lower=True, with_n=True), dict(no_final_nl=True)])
+def test_ingest_matches_the_oracle_reader(oracle, native, tmp_path, kw):
+    """The GPU ingest against the ORACLE's FASTQ reader (the restatement of btllib::SeqReader
+    the oracle CLI reads its input with) and the oracle's Phred arithmetic: ids, sequences
+    (case-folded), qualities, the ACGT filter and the raw Phred sums, record by record."""
+    import ctypes as C
+
+    text = _mk_text(21, n=60, **kw)
+    path = str(tmp_path / "in.fq")
+    with open(path, "wb") as f:
+        f.write(text)
+    lib = oracle.load()
+    reads = oracle.orc_reads()
+    assert lib.orc_reads_load(C.byref(reads), path.encode()) == 0 and reads.is_fastq
+    eng = native.Engine(22, 3, 1000, 1 << 20, default_seeds(3))
+    fq, rec, used, stopped = eng.fastq_parse(text)
+    assert not stopped and used == len(text) and len(rec) == reads.n == 60
+    for i, r in enumerate(rec):
+        o = reads.rec[i]
+        seq = text[int(r["seq_off"]): int(r["seq_off"]) + int(r["seq_len"])]
+        qual = text[int(r["qual_off"]): int(r["qual_off"]) + int(r["qual_len"])]
+        assert text[int(r["id_off"]): int(r["id_off"]) + int(r["id_len"])] == o.id
+        assert seq.upper() == o.seq and len(seq) == o.len
+        assert qual == o.qual and len(qual) == o.qlen
+        assert bool(r["flags"] & 1) == (len(o.seq.strip(b"ACGT")) != 0)  # goldrush_path.cpp:293-301
+        assert struct.pack("<d", float(r["phred_sum"])) == struct.pack("<d", lib.orc_sum_phred(o.qual, o.qlen))
+    # the packed bases of the ACGT records hash like the oracle's strings
+    sel = [i for i, r in enumerate(rec) if not (r["flags"] & 1) and r["seq_len"] >= 1000]
+    batch = eng.fastq_pack(fq, sel, rec["seq_len"][sel])
+    oseeds = oracle.Seeds(default_seeds(3))
+    for j, i in enumerate(sel[:8]):
+        for t in range(int(rec["seq_len"][i]) // 1000):
+            assert np.array_equal(eng.tile_hashes(batch, j, t), oseeds.tile_hashes(reads.rec[i].seq, 1000, 22, t))
+    eng.fastq_free(fq)
+    lib.orc_reads_free(C.byref(reads))
+    eng.close()

@@ -1,34 +1,40 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): refresh the judged evidence for the current build.
-#   tools/profile_round.sh <tag>      e.g. r01_v8
+#   tools/profile_round.sh <tag>      e.g. r02_v13
 # Writes gpurun_out/<tag>_*; copy what should be judged into profiles/.
 tag=${1:-rXX}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-python bench.py > $out/${tag}_bench_default_flags.json 2> $out/${tag}_bench_default_flags.err
-python bench.py --steps 112 --warmup 8 --no-cpu-baseline > $out/${tag}_bench_full_stream.json 2> /dev/null
-# kernel trace of the same default command (no CPU baseline leg: it only adds host time)
+# the random-line ceiling of this box's memory system (bench.py reads the newest one in profiles/)
+timeout 600 python3 tools/gather_ceiling.py $out/${tag}_gather_ceiling.json > /dev/null 2>&1
+cp $out/${tag}_gather_ceiling.json profiles/ 2>/dev/null
+# the driver's command: C2, whole stream, with the like-for-like CPU baseline
+python3 bench.py > $out/${tag}_bench_default_flags.json 2> $out/${tag}_bench_default_flags.err
+# C1 (BASELINE configs[1]), whole stream
+python3 bench.py --config C1 --no-cpu-baseline > $out/${tag}_bench_c1_full_stream.json 2> /dev/null
+# kernel trace of the default command (no CPU baseline leg: it only adds host time)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o ${tag} -- python3 bench.py --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof.err
 find $out/${tag}_prof -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
-# the stats above cover warm-up + timed steps; the bench line only the timed ones: average the
-# LAST <launches> dispatches of the query kernels from the per-dispatch trace as well
+# the bench line's roofline is over the throughput forms of k_query in the timed region: the same
+# dispatches from the per-dispatch trace (streaming + large windows; the warm-up engine's launches
+# come first and are cut off by taking the LAST <launches> of them)
 python3 - $out/${tag}_bench_under_rocprof.json $(find $out/${tag}_prof -name "*kernel_trace.csv" | head -1) $out/${tag}_kernel_trace_timed_region.json <<'PY'
 import csv, json, sys
 b = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
 n = int(b["roofline"]["launches"])
-rows = [r for r in csv.DictReader(open(sys.argv[2])) if "k_query" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[2])) if "k_query" in r["Kernel_Name"] and ("true>" in r["Kernel_Name"].split("(")[0] or "0, false>" in r["Kernel_Name"].split("(")[0])]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last = rows[-n:]
 dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
-json.dump({"note": "rocprofv3 --kernel-trace of `python3 bench.py --no-cpu-baseline`: the last <launches> k_query dispatches = the timed region of the bench line",
+json.dump({"note": "rocprofv3 --kernel-trace of `python3 bench.py --no-cpu-baseline`: the last <launches> dispatches of the throughput forms of k_query = the timed region of the bench line",
            "launches": n, "avg_launch_ms_rocprof": sum(dur) / len(dur) / 1e6, "avg_launch_ms_bench_hip_events": b["roofline"]["avg_launch_ms"],
            "total_ms_rocprof": sum(dur) / 1e6, "query_kernel_ms_bench": b["aux"]["query_kernel_s"] * 1e3}, open(sys.argv[3], "w"), indent=1)
 print(open(sys.argv[3]).read())
 PY
 rm -rf $out/${tag}_prof
-# two ranks on the one GPU (gloo): plumbing of the N > 1 path
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 12 --warmup 4 --no-cpu-baseline --backend gloo --share-gpu --reads 400000 --verify-ranks > $out/${tag}_bench_2ranks_one_gpu_gloo_plumbing.json 2> $out/${tag}_2ranks.err
-grep verify-ranks $out/${tag}_2ranks.err; tail -2 $out/${tag}_2ranks.err
-cat $out/${tag}_bench_default_flags.json $out/${tag}_bench_full_stream.json $out/${tag}_bench_under_rocprof.json $out/${tag}_bench_2ranks_one_gpu_gloo_plumbing.json
-head -8 $out/${tag}_kernel_stats.csv
+# two ranks on the one GPU (gloo): plumbing of the N > 1 path (fill merge, striped windows, shm exchange)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --config C1 --steps 6 --no-cpu-baseline --backend gloo --share-gpu --reads 300000 --verify-ranks > $out/${tag}_bench_2ranks_one_gpu_gloo_plumbing.json 2> $out/${tag}_2ranks.err
+grep verify-ranks $out/${tag}_2ranks.err | head -1
+cat $out/${tag}_bench_default_flags.json $out/${tag}_bench_c1_full_stream.json $out/${tag}_bench_under_rocprof.json
+head -12 $out/${tag}_kernel_stats.csv
