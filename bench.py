@@ -61,7 +61,64 @@ CONFIGS = {
     "C1": {"reads": 1_000_000, "genome": 100e6, "h": 3, "name": "C1: 1M synthetic ONT reads, mean 25 kb, G=100e6"},
     # configs[2] (N = 1) / configs[3] (N = 8, the same stream)
     "C2": {"reads": 10_000_000, "genome": 3e9, "h": 3, "name": "C2: 10M synthetic ONT reads, mean 25 kb, G=3e9 (human-scale)"},
+    # configs[4]: silver mode, 5 paths, 5 seed patterns; 312 GB of packed reads: streamed through HBM in batches
+    "C4": {"reads": 50_000_000, "genome": 3e9, "h": 5, "silver": True, "max_paths": 5, "name": "C4: 50M synthetic ONT reads, mean 25 kb, G=3e9, h=5, M=5 silver paths"},
 }
+
+
+class ReadStream:
+    """The synthetic read set as consecutive batches generated on the GPU (grp_synth_reads).
+    One batch when the packed reads fit beside the miBF (everything resident before the timed
+    region); otherwise batches of `batch` reads generated on demand, one resident at a time
+    (C4: 50 M reads = 312 GB of 2-bit bases do not fit 288 GB of HBM)."""
+
+    def __init__(self, native, n_reads: int, genome: int, batch: int):
+        self.native, self.n, self.G = native, n_reads, genome
+        self.plan = native.synth_read_plan(n_reads, genome)
+        self.batch = batch if batch else n_reads
+        self.n_batches = (n_reads + self.batch - 1) // self.batch
+        self.cur = None  # (index, DeviceReads, ReadBatch, lens)
+        self.eng = None
+        self.synth_s = 0.0
+
+    def bounds(self, b):
+        return b * self.batch, min((b + 1) * self.batch, self.n)
+
+    def get(self, b):
+        """(first read, ReadBatch, lens) of batch b, resident in HBM"""
+        if self.cur is None or self.cur[0] != b:
+            self.drop()
+            lo, hi = self.bounds(b)
+            t0 = time.perf_counter()
+            dr = self.native.synth_reads_range(self.plan, lo, hi, self.G)
+            rb = self.eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+            self.synth_s += time.perf_counter() - t0
+            self.cur = (b, dr, rb, np.ascontiguousarray(dr.lens, dtype=np.uint32))
+        return self.bounds(b)[0], self.cur[2], self.cur[3]
+
+    def pieces(self, first, count):
+        """the range [first, first+count) of the stream as (ReadBatch, lens, first inside the batch, count) pieces"""
+        pos, end = first, first + count
+        while pos < end:
+            b = pos // self.batch
+            lo, rb, lens = self.get(b)
+            hi = self.bounds(b)[1]
+            n = min(end, hi) - pos
+            yield rb, lens, pos - lo, n
+            pos += n
+
+    def download(self, first, count):
+        out = []
+        for rb, lens, lo, n in self.pieces(first, count):
+            out += self.cur[1].download(lo, n)
+        return out
+
+    def drop(self):
+        if self.cur is not None:
+            self.eng.sync()
+            self.cur[2].free()
+            self.cur[1].free()
+            self.cur = None
 
 
 def _newest_profile(pattern: str):
@@ -73,7 +130,7 @@ def _newest_profile(pattern: str):
     return files[-1] if files else None
 
 
-def cpu_baseline(dr, eng, cls, phases, n_reads: int, m: int, pop: int, seeds, k: int, tile: int, genome: int, budget_s: float = 10.0):
+def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, seeds, k: int, tile: int, genome: int, budget_s: float = 10.0):
     """Like-for-like CPU baseline: the oracle's serial process_read loop (hash, query, decide,
     insert; OpenMP over tiles like the reference, goldrush_path.cpp:1229-1256) on the SAME
     filter as the measured run and on the same two regimes of the stream:
@@ -120,6 +177,14 @@ def cpu_baseline(dr, eng, cls, phases, n_reads: int, m: int, pop: int, seeds, k:
         return done, ins, time.time() - t0
 
     h_done, h_ins, h_dt = timed(0, n_s)
+    if silver:  # every silver path is an insert-heavy head: no steady state to compare
+        p.close()
+        for f in os.listdir(tmp):
+            os.remove(os.path.join(tmp, f))
+        os.rmdir(tmp)
+        return {"value": h_done / h_dt, "unit": "reads/s", "cores": cores, "kind": "port",
+                "sample": f"same filter (bit vector of all {n_reads} reads exported from the GPU, m={m}); reads 0..{h_done} of the stream on the empty ID arrays ({h_ins} inserts): "
+                          f"the regime of every silver path; oracle process_read loop (hash + query + decide + insert), OpenMP over tiles, {cores} threads"}
     # the GPU's end state -> the oracle's arrays (chunks: the export stages through device memory)
     ids_p, cnt_p = lib.orcpy_mibf_data(mh), lib.orcpy_mibf_counts(mh)
     chunk = 1 << 28
@@ -181,6 +246,8 @@ def main():
     ap.add_argument("--genome", type=float, default=0.0, help="override the config's genome size")
     ap.add_argument("--batch", type=int, default=0, help="reads per step for the whole job (default reads // steps: the K steps cover the stream exactly once)")
     ap.add_argument("--h", type=int, default=0)
+    ap.add_argument("--silver", type=int, default=-1, help="silver-path mode with this many paths (-M); default: the config's")
+    ap.add_argument("--stream-batch", type=int, default=-1, help="reads per resident batch (0: all resident; default: 2 M when the packed reads exceed 100 GB)")
     ap.add_argument("--max-window", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--trace", action="store_true", help="per-slice timing / speculation statistics on stderr")
@@ -197,6 +264,9 @@ def main():
         cfg["genome"] = a.genome
     if a.h:
         cfg["h"] = a.h
+    if a.silver >= 0:
+        cfg["silver"], cfg["max_paths"] = a.silver > 0, max(a.silver, 1)
+    silver, max_paths = bool(cfg.get("silver")), int(cfg.get("max_paths", 1))
     n_reads = cfg["reads"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -248,13 +318,16 @@ def main():
 
     # ---- untimed setup: inputs resident in HBM, phase 1 -------------------------
     t0 = time.time()
-    dr = native.synth_reads(n_reads, G)
+    stream_batch = a.stream_batch if a.stream_batch >= 0 else (2_000_000 if n_reads * 6400 > 100e9 else 0)
+    rs = ReadStream(native, n_reads, G, stream_batch)
     eng = native.Engine(k, h, tile, m, seeds, device=local_rank)
-    rb = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+    rs.eng = eng
+    rs.get(0)
     t_synth = time.time() - t0
     t0 = time.time()
     if world == 1:
-        eng.bv_insert(rb)
+        for rb_, _, lo_, n_ in rs.pieces(0, n_reads):
+            eng.bv_insert(rb_, lo_, n_)
         eng.sync()
     else:
         # the fill shards by reads and its merge is a bitwise OR.  RCCL has no OR
@@ -264,7 +337,8 @@ def main():
         # extra vector of HBM, instead of N-1 whole vectors each way.
         shard = (n_reads + world - 1) // world
         lo, hi = min(rank * shard, n_reads), min((rank + 1) * shard, n_reads)
-        eng.bv_insert(rb, lo, hi - lo)
+        for rb_, _, lo_, n_ in rs.pieces(lo, hi - lo):
+            eng.bv_insert(rb_, lo_, n_)
         eng.sync()
         n_words = eng.bv_words()
         slice_words = ((n_words + world - 1) // world + 3) // 4 * 4
@@ -345,26 +419,29 @@ def main():
             return 0
 
     cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
-                          target_bases=int(0.9 * G), max_paths=1, silver_path=False, max_window=a.max_window, world=world, rank=rank,
+                          target_bases=int(0.9 * G), max_paths=max_paths, silver_path=silver, max_window=a.max_window, world=world, rank=rank,
                           allgather=None if shm else allgather, record=False)
     if shm:
         hl.gr_classifier_set_allgather(cls._h, C.cast(hl.gr_shm_allgather, C.c_void_p), shm)
-    lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
     slices = []  # (reads, seconds, inserts) per timing slice, rank 0's clock
+    finished = [False]  # silver mode: the last path is complete (the reference exits there)
+    synth_before = rs.synth_s
 
     def step(i: int):
         # one step = the next per_step reads of the stream, run as slices of PHASE_SLICE reads
         # so that the head of the path and the steady state can be told apart
         first = i * per_step
         done = 0
-        while done < per_step:
+        while done < per_step and not finished[0]:
             n = min(PHASE_SLICE, per_step - done)
             s0 = cls.state()
             ts = time.perf_counter()
-            cls.run_range(rb._h, lens, first + done, n)
+            for rb_, lens_, lo_, n_ in rs.pieces(first + done, n):
+                if not finished[0]:
+                    finished[0] = cls.run_range(rb_._h, lens_, lo_, n_)
             te = time.perf_counter()
             s1 = cls.state()
-            slices.append((n, te - ts, s1["inserts"] - s0["inserts"]))
+            slices.append((s1["reads_committed"] - s0["reads_committed"], te - ts, s1["inserts"] - s0["inserts"]))
             if a.trace and rank == 0:
                 sys.stderr.write("reads %d..%d: %.2f ms windows=%d queried=%d inserts=%d\n" % (
                     first + done, first + done + n, (te - ts) * 1e3, s1["windows"] - s0["windows"], s1["reads_queried"] - s0["reads_queried"], s1["inserts"] - s0["inserts"]))
@@ -404,7 +481,7 @@ def main():
 
     if rank == 0:
         kq = ks["query"]
-        reads_done = a.steps * per_step
+        reads_done = st1["reads_committed"] - st0["reads_committed"]  # silver mode stops behind the last path
         avg_ms = kq["ms"] / max(kq["launches"], 1)
         probes_per_launch = kq["units"] / max(kq["launches"], 1)
         kq_s = kq["ms"] * 1e-3
@@ -455,8 +532,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "%s%s, k=22 w=16 h=%d tile=1000 o=0.1 -P10, golden-path mode, order-exact, whole stream from read 0 (insert-heavy head included)" % (
-                           cfg["name"], " [C3: stream shared by %d GPUs]" % world if (world > 1 and a.config == "C2") else "", h),
+            "config": {"workload": "%s%s, k=22 w=16 h=%d tile=1000 o=0.1 -P10, %s, order-exact, whole stream from read 0 (insert-heavy head included)" % (
+                           cfg["name"], " [C3: stream shared by %d GPUs]" % world if (world > 1 and a.config == "C2") else "", h,
+                           "silver-path mode, %d paths (the run ends behind the last path: reads_timed = reads consumed)" % max_paths if silver else "golden-path mode"),
                        "reads": n_reads, "reads_timed": reads_done, "reads_per_step": per_step, "genome": G, "filter_bits": m, "pop": pop,
                        "parallelism": ("one GPU, streaming windows" if world == 1 else "windows striped over %d GPUs, replicated miBF, 32-B decisions all-gathered per stripe group" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -477,6 +555,7 @@ def main():
                        "steady": {"reads": tail_reads, "seconds": tail_s, "reads_per_s": tail_reads / tail_s if tail_s > 0 else None, "inserts": tail_ins}},
             "aux": {"fill_reads_per_s": n_reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill, "finalize_s": t_finalize,
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors OR-merged as reduce-scatter (all-to-all + OR) + all-gather" % world, "synth_s": t_synth,
+                    "read_batches": rs.n_batches, "synth_in_timed_region_s": rs.synth_s - synth_before,
                     "warmup_s": t_warm, "warmup_mode": "%d steps of 512 reads on a throw-away engine (G=2e6)" % a.warmup,
                     "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit")},
                     "query_Gprobes_per_s": gprobes,
@@ -488,7 +567,7 @@ def main():
                     "wall_s": dt},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dr, eng, cls, out["phases"], n_reads, m, pop, seeds, k, tile, G)
+            out["cpu_baseline"] = cpu_baseline(rs, eng, cls, out["phases"], silver, n_reads, m, pop, seeds, k, tile, G)
         print(json.dumps(out), flush=True)
     if world > 1:
         if shm:

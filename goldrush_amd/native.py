@@ -600,6 +600,27 @@ def synth_read_plan(n_reads: int, genome_len: int, mean_len: int = 25000, min_le
     return start, lens, strand, word_off
 
 
+def synth_reads_range(plan, lo: int, hi: int, genome_len: int, genome_seed: int = 1, error_seed: int = 3, p_sub=0.03, p_ins=0.01, p_del=0.01, stream: int = 0) -> DeviceReads:
+    """Reads [lo, hi) of a plan (synth_read_plan) generated into their own device buffer: a read
+    set larger than HBM is streamed through it batch by batch.  The error pattern of a read
+    depends on its index INSIDE the call, so the passes of one run must use the same batches."""
+    lib = load()
+    start, lens, strand, word_off = plan
+    n = hi - lo
+    wo = np.ascontiguousarray(word_off[lo:hi + 1] - word_off[lo], dtype=np.uint64)
+    st = np.ascontiguousarray(start[lo:hi])
+    ln = np.ascontiguousarray(lens[lo:hi])
+    sd = np.ascontiguousarray(strand[lo:hi])
+    d = lib.grp_synth_alloc(int(wo[-1]) * 4 + 64)
+    if not d:
+        raise GrpError(GRP_ERR_NOMEM, lib.grp_synth_last_error().decode())
+    p = grp_synth_params(genome_len, genome_seed, error_seed, p_sub, p_ins, p_del)
+    rc = lib.grp_synth_reads(C.byref(p), _ptr(st), _ptr(ln), _ptr(sd), _ptr(wo), n, C.c_void_p(d), C.c_void_p(stream))
+    if rc != 0:
+        raise GrpError(rc, lib.grp_synth_last_error().decode())
+    return DeviceReads(d, wo, ln)
+
+
 def synth_reads(n_reads: int, genome_len: int, genome_seed: int = 1, error_seed: int = 3, p_sub=0.03, p_ins=0.01, p_del=0.01,
                 stream: int = 0, **plan_kw) -> DeviceReads:
     lib = load()

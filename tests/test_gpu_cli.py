@@ -240,3 +240,16 @@ def test_crlf_and_missing_final_newline(oracle, host, tmp_path):
     for env in ({}, {"GRP_HOST_INGEST": "1"}):
         ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "crlf" + str(len(env)), env=env)
         assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+
+
+def test_c4_geometry_on_a_subsample(oracle, host, tmp_path):
+    """BASELINE configs[4]'s parameters — defaults (k=22 w=16 tile 1000, blocks of 10 tiles) with
+    -h 5 seed patterns and -M 5 silver paths — on a sub-sample: 25 kb reads of a 1.2 Mbp genome,
+    enough for all five paths (the run ends behind the fifth one, goldrush_path.cpp:173-176)."""
+    fq = str(tmp_path / "reads.fq")
+    _mk_fastq(fq, 1_200_000, 700, 25000, 20000, seed=31)
+    args = ["-k22", "-w16", "-h5", "-s1011011110110111101101", "-g1200000", "-P10", "-j8", "--silver_path", "-M5", "-i", fq, "--verbose"]
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "c4")
+    assert files == ["out_%d.fq" % i for i in range(1, 6)] and all(os.path.getsize(d_p / f) > 0 for f in files)
+    assert "WARNING: Expected" not in rp.stderr  # all five paths were generated
+    assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
