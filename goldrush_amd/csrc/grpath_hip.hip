@@ -23,6 +23,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -155,6 +156,7 @@ struct grp_ctx
   uint64_t* d_super = nullptr;
   bool finalized = false;
   int n_cus = 0;
+  std::mutex fill_mutex; // grp_bv_insert may be called from several host threads (the reference calls insertBV under `omp parallel`)
   // --ntcard pass (grp_ntcard.inc)
   uint32_t* d_ntc = nullptr;
   uint32_t ntc_sbits = 0;
@@ -961,6 +963,9 @@ grp_bv_insert(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count)
   if (c->f.m == 0) {
     return set_err(c, GRP_ERR_STATE, "grp_bv_insert: the filter size is not set (grp_set_filter_size)");
   }
+  // re-entrant: the enqueue (stream, event bookkeeping) is serialised here; the launches of
+  // different callers may interleave on the stream in any order — the fill is order-free
+  std::lock_guard<std::mutex> lock(c->fill_mutex);
   HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t ch0 = r->chunk0[first], ch1 = r->chunk0[first + count];
   if (ch1 == ch0) {

@@ -192,6 +192,14 @@ gr_classifier_destroy(gr_classifier* c)
 }
 
 void
+gr_classifier_set_debug(gr_classifier* c, gr_debug_fn fn)
+{
+  if (c) {
+    c->impl.set_debug(fn);
+  }
+}
+
+void
 gr_classifier_set_allgather(gr_classifier* c, gr_allgather_fn allgather, void* allgather_user)
 {
   if (c) {

@@ -111,6 +111,9 @@ Classifier::skip_reads(uint32_t n)
 Classifier::Plan
 Classifier::window_plan() const
 {
+  if (p_.debug) {
+    return Plan{ p_.world, false, false }; // one read per rank and round, decided on the host (the dumps are per read, in file order)
+  }
   // Choose the speculation window S that maximises committed reads per second
   // under a cost model of one round.  p = insert probability per read, estimated
   // on two time scales (a burst of inserts shrinks the window at once; the long
@@ -426,7 +429,20 @@ Classifier::query_window(void* reads, const uint32_t* lens, uint32_t first, uint
       const uint64_t a = tile0_[my_first + j] - t_base;
       const uint64_t b = tile0_[my_first + j + 1] - t_base;
       ReadDecision rd;
-      decide_read(dp, (size_t)(b - a), tiles_.data() + a, lists_.data(), ws, rd);
+      if (p_.debug) { // single-threaded here (windows of one read): the dumps are kept until the read is committed
+        char* buf = nullptr;
+        size_t len = 0;
+        FILE* mem = open_memstream(&buf, &len);
+        decide_read(dp, (size_t)(b - a), tiles_.data() + a, lists_.data(), ws, rd, mem);
+        fclose(mem);
+        if (debug_text_.size() <= j) {
+          debug_text_.resize((size_t)j + 1);
+        }
+        debug_text_[j].assign(buf ? buf : "", len);
+        free(buf);
+      } else {
+        decide_read(dp, (size_t)(b - a), tiles_.data() + a, lists_.data(), ws, rd);
+      }
       static_assert(sizeof(ReadDecision) == sizeof(gr_read_decision), "decision layout");
       std::memcpy(&dec_[j], &rd, sizeof(rd));
     }
@@ -516,6 +532,9 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
     }
   };
 
+  if (p_.debug && p_.rank == 0) { // :979, :1016, :1037, :1084
+    std::cerr << (d.kind == DEC_INSERT_WHOLE ? "unassigned" : d.kind == DEC_ASSIGNED_ALL ? "complete assignment" : d.kind == DEC_INSERT_TRIMMED ? "trimmed" : "assigned") << std::endl;
+  }
   switch (d.kind) {
     case DEC_INSERT_WHOLE: {
       // :978-1011
@@ -599,6 +618,16 @@ Classifier::commit_one(uint32_t r, const gr_read_decision& d, int& rc, bool engi
 {
   if (rg_.skipped_before) {
     skip_reads(rg_.skipped_before[r]);
+  }
+  if (p_.debug && p_.rank == 0) {
+    if (debug_cb_) {
+      debug_cb_(user_, base_ + r); // skipped records in front of it, "name:", "num tiles:" (:907-941)
+    }
+    if (debug_window_pos_ <= r && r - debug_window_pos_ < debug_text_.size()) {
+      std::cerr << debug_text_[r - debug_window_pos_];
+    }
+    std::cerr << "num assigned tiles: " << d.num_assigned << "\n"
+              << "num unassigned tiles: " << d.num_tiles - d.num_assigned << std::endl; // :957-964
   }
   const uint64_t path_before = curr_path_;
   const bool ins = commit(rg_.reads, rg_.lens, r, d, rc, engine_inserted, engine_first_id);
@@ -686,7 +715,7 @@ Classifier::can_loop() const
 bool
 Classifier::want_loop() const
 {
-  if (!can_loop()) {
+  if (!can_loop() || p_.debug) {
     return false;
   }
   const char* e = getenv("GRP_LOOP");
@@ -931,6 +960,7 @@ Classifier::window_round(uint32_t& pos)
   } else {
     const Plan plan = window_plan();
     S = std::min<uint32_t>(plan.S, n - pos);
+    debug_window_pos_ = pos;
     rc = plan.pipelined ? launch_window(rg_.reads, pos, S, 0, cur) : query_window(rg_.reads, rg_.lens, pos, S);
     if (rc != GRP_OK) {
       return rc;

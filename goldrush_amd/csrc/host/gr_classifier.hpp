@@ -25,6 +25,7 @@ public:
   Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, void* ctx);
   void set_callbacks(gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user);
   void set_allgather(gr_allgather_fn allgather, void* allgather_user);
+  void set_debug(gr_debug_fn fn) { debug_cb_ = fn; }
   // classifies reads [first, first+n) of the batch; lens / skipped_before are indexed by absolute read number
   int run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, const uint32_t* skipped_before, uint32_t skipped_after, bool& finished);
   void get_state(gr_classifier_state& s) const;
@@ -85,6 +86,9 @@ private:
   gr_allgather_fn allgather_cb_ = nullptr;
   void* user_ = nullptr;
   void* ag_user_ = nullptr;
+  gr_debug_fn debug_cb_ = nullptr;
+  std::vector<std::string> debug_text_; // --debug: the tile-state dumps of the window's reads
+  uint32_t debug_window_pos_ = 0;       // ... and the window's first read
 
   // main()'s loop state (goldrush_path.cpp:1222-1227) + log_info_struct (:41-51)
   uint64_t inserted_bases_ = 0;

@@ -445,8 +445,13 @@ calc_min_phred_threshold(PathRun& run)
   const size_t n = taken + over;
   std::sort(scores.begin(), scores.end(), std::greater<uint32_t>());
   opt.phred_min = std::max(MINIMUM_PHRED_THRESHOLD, scores[n / 2]);
-  if (opt.debug) {
+  if (opt.debug) { // log_phred_calculations (:60-70)
     std::cerr << "Number of reads used to calculate median: " << n << std::endl;
+    std::cerr << "Median array: ";
+    for (const uint32_t v : scores) {
+      std::cerr << v << " ";
+    }
+    std::cerr << std::endl;
   }
   if (opt.verbose) {
     std::cerr << "Minimum phred score calculated with median: " << opt.phred_min << std::endl;
@@ -478,6 +483,10 @@ fill_bit_vector(PathRun& run)
       if (b.rec[i].seq_len < opt.min_length) { // :261-265
         ++by_length;
         continue;
+      }
+      if (opt.debug) { // :267-273 (file order here; the reference prints from an OpenMP region)
+        std::cerr << "phred avg: " << b.avg[i] << "\n"
+                  << "phred delta: " << b.delta[i] << std::endl;
       }
       const bool low = b.avg[i] < opt.phred_min, hairpin = b.delta[i] >= opt.phred_delta;
       if (low || hairpin) { // :275-292
@@ -546,7 +555,38 @@ struct SinkState
   const Batch* batch = nullptr;
   const std::vector<uint32_t>* sel = nullptr;
   std::string upper;
+  // --debug: the records that are not classified, in file order ({record, 1 = too short / 2 = filtered}),
+  // and for every classified read the number of them in front of it
+  const std::vector<std::pair<uint32_t, uint8_t>>* skipped = nullptr;
+  const std::vector<uint32_t>* skipped_before = nullptr;
+  size_t skipped_done = 0;
 };
+
+// --debug: what process_read prints for the records it skips (goldrush_path.cpp:907-932)
+void
+debug_skipped(const SinkState& st, size_t from, size_t to)
+{
+  const Batch& b = *st.batch;
+  for (size_t i = from; i < to; ++i) {
+    const auto& sk = (*st.skipped)[i];
+    std::cerr << (sk.second == 1 ? "too short" : "hairpin or quality too low or invalid bases") << std::endl;
+    std::cerr << "skipping: " << b.id_str(sk.first) << std::endl;
+  }
+}
+
+// --debug: in front of a classified read (:907-941)
+void
+debug_sink(void* user, uint32_t read)
+{
+  SinkState& st = *static_cast<SinkState*>(user);
+  const size_t n = (*st.skipped_before)[read];
+  debug_skipped(st, st.skipped_done, st.skipped_done + n);
+  st.skipped_done += n;
+  const Batch& b = *st.batch;
+  const uint32_t i = (*st.sel)[read];
+  std::cerr << "name: " << b.id_str(i) << std::endl;
+  std::cerr << "num tiles: " << b.rec[i].seq_len / st.run->opt.tile_length << std::endl;
+}
 
 double
 commit_sink(void* user, const gr_commit* c)
@@ -789,6 +829,11 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   cp.verbose = opt.verbose;
   cp.world = run.world;
   cp.rank = run.rank;
+  cp.debug = opt.debug;
+  if (opt.debug && run.world > 1) {
+    std::cerr << "goldrush-path: --debug runs on one rank" << std::endl;
+    return 1;
+  }
   Classifier cls(cp, run.vt, run.ctx);
   SinkState sink;
   sink.run = &run;
@@ -796,22 +841,32 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   if (run.world > 1) {
     cls.set_allgather(gr_shm_allgather, shm.h);
   }
+  if (opt.debug) {
+    cls.set_debug(debug_sink);
+  }
 
   {
     auto src = open_source(run);
     Batch b;
     std::vector<uint32_t> sel, skipped_before, lens;
+    std::vector<std::pair<uint32_t, uint8_t>> skipped_recs;
     bool finished = false;
     while (!finished && src->ok() && src->next(b)) {
       // read_hashing.cpp:35-42 / goldrush_path.cpp:907-932: a read is classified
       // iff it is long enough and not in filter_out_reads
       sel.clear();
       skipped_before.clear();
+      skipped_recs.clear();
       uint32_t skipped = 0;
       for (size_t i = 0; i < b.rec.size(); ++i) {
         bool eligible = b.rec[i].seq_len >= opt.min_length;
+        uint8_t why = eligible ? 0 : 1;
         if (eligible && !run.filter_out_reads.empty() && run.filter_out_reads.count(b.id_str(i))) {
           eligible = false;
+          why = 2;
+        }
+        if (!eligible && opt.debug) {
+          skipped_recs.emplace_back((uint32_t)i, why);
         }
         if (eligible) {
           sel.push_back((uint32_t)i);
@@ -827,7 +882,13 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
       }
       sink.batch = &b;
       sink.sel = &sel;
+      sink.skipped = &skipped_recs;
+      sink.skipped_before = &skipped_before;
+      sink.skipped_done = 0;
       const int rc = cls.run(h, lens.data(), 0, (uint32_t)sel.size(), skipped_before.data(), skipped, finished);
+      if (opt.debug && rc == GRP_OK && !finished) {
+        debug_skipped(sink, sink.skipped_done, skipped_recs.size()); // the records behind the batch's last classified read
+      }
       run.vt.reads_free(h);
       if (rc != GRP_OK) {
         std::cerr << "goldrush-path: " << cls.error() << std::endl;

@@ -22,11 +22,28 @@ reserve(TileWorkspace& ws, size_t n)
   }
 }
 
+// log_tile_states (goldrush_path.cpp:109-124): IDs, then flags, tab-separated
+static void
+print_tile_states(void* out, const uint32_t* ids, const uint8_t* flags, size_t n)
+{
+  FILE* f = static_cast<FILE*>(out);
+  for (size_t i = 0; i < n; ++i) {
+    fprintf(f, "%u\t", ids[i]);
+  }
+  fprintf(f, "\n");
+  for (size_t i = 0; i < n; ++i) {
+    fprintf(f, "%u\t", (unsigned)flags[i]);
+  }
+  fprintf(f, "\n");
+}
+
 size_t
-smooth_tiles(size_t n, const grp_tile_summary* tiles, const grp_id_count* lists, size_t x, TileWorkspace& ws, FILE*)
+smooth_tiles(size_t n, const grp_tile_summary* tiles, const grp_id_count* lists, size_t x, TileWorkspace& ws, FILE* dbg)
 {
   reserve(ws, n);
-  core::PtrState s;
+  core::DebugPtrState s;
+  s.out = dbg;
+  s.print = dbg ? print_tile_states : nullptr;
   s.tiles = tiles;
   s.lists = lists;
   s.ids = ws.ids.data();
@@ -54,11 +71,23 @@ eval_flanks(long ls, long le, const uint32_t* ids, size_t n, size_t& trim_start,
 }
 
 void
-decide_read(const DecideParams& p, size_t n, const grp_tile_summary* tiles, const grp_id_count* lists, TileWorkspace& ws, ReadDecision& out, FILE*)
+decide_read(const DecideParams& p, size_t n, const grp_tile_summary* tiles, const grp_id_count* lists, TileWorkspace& ws, ReadDecision& out, FILE* dbg)
 {
   reserve(ws, n);
   gr_read_decision d;
-  core::decide(p.threshold, p.unassigned_min, p.assigned_max, n, tiles, lists, ws.ids.data(), ws.asg.data(), ws.scratch.data(), d);
+  if (dbg) {
+    core::DebugPtrState s;
+    s.tiles = tiles;
+    s.lists = lists;
+    s.ids = ws.ids.data();
+    s.flags = ws.asg.data();
+    s.scratch = ws.scratch.data();
+    s.out = dbg;
+    s.print = print_tile_states;
+    core::decide(p.threshold, p.unassigned_min, p.assigned_max, n, s, d);
+  } else {
+    core::decide(p.threshold, p.unassigned_min, p.assigned_max, n, tiles, lists, ws.ids.data(), ws.asg.data(), ws.scratch.data(), d);
+  }
   static_assert(sizeof(ReadDecision) == sizeof(gr_read_decision), "decision layout");
   std::memcpy(&out, &d, sizeof(d));
 }

@@ -82,6 +82,9 @@ struct PtrState
   GR_HD void set_asg(size_t i, uint32_t v) { flags[i] = (uint8_t)v; }
   GR_HD uint64_t scr(size_t i) const { return scratch[i]; }
   GR_HD void set_scr(size_t i, uint64_t v) { scratch[i] = v; }
+  // --debug's dump of the tile states after a pass (log_tile_states, goldrush_path.cpp:109-124):
+  // nothing here; DebugPtrState (gr_tiles.cpp) prints
+  GR_HD void log_pass(size_t) const {}
   // whole-state operations (one loop here; a few cross-lane instructions in LaneState)
   GR_HD void init_from_top(size_t n, size_t x)
   {
@@ -201,28 +204,35 @@ smooth(size_t n, size_t x, S& s)
 {
   s.init_from_top(n, x);
   if (n >= 3) {
+    s.log_pass(n); // :636
     // Passes that provably leave the state alone are skipped (the decision of a read is on
     // the latency path of the device-side commit loop): P1 / P2 only act through a tile's
     // count>2 list; P3 .. P7 only act next to / between / on ASSIGNED tiles; P9 / P10 only
     // clear flags.  The start of every silver path — no hit anywhere — skips everything
     // but P8.
-    if (s.any_list(n)) {
+    const bool lists = s.any_list(n);
+    if (lists) {
       for (size_t i = 1; i < n; ++i) { // P1
         adopt_neighbour(i, i - 1, x, s);
       }
+    }
+    s.log_pass(n); // :663
+    if (lists) {
       for (size_t i = n - 1; i-- > 0;) { // P2: i = n-2 .. 0
         adopt_neighbour(i, i + 1, x, s);
       }
     }
+    s.log_pass(n); // :684
     const bool assigned_1_7 = s.any_asg(n);
     if (assigned_1_7) {
-    for (size_t i = 1; i + 1 < n; ++i) { // P3
-      neighbour_fill(i, s);
+      for (size_t i = 1; i + 1 < n; ++i) { // P3
+        neighbour_fill(i, s);
+      }
+      for (size_t i = n - 2; i >= 1; --i) { // P4
+        neighbour_fill(i, s);
+      }
     }
-    for (size_t i = n - 2; i >= 1; --i) { // P4
-      neighbour_fill(i, s);
-    }
-    }
+    s.log_pass(n); // :736
     // P5 (:739-766): interior unassigned runs whose flanking IDs differ by <= 1
     size_t nr = assigned_1_7 ? collect_runs<false>(n, s) : 0;
     for (size_t r = 0; r < nr; ++r) {
@@ -240,19 +250,21 @@ smooth(size_t n, size_t x, S& s)
         }
       }
     }
+    s.log_pass(n); // :768
     // P6 (:771-793): isolated assigned tiles, forward then backward, 2..n-3
     if (assigned_1_7) {
-    for (size_t i = 2; i + 2 < n; ++i) {
-      if (s.asg(i) && !s.asg(i - 1) && !s.asg(i + 1)) {
-        s.set_asg(i, 0);
+      for (size_t i = 2; i + 2 < n; ++i) {
+        if (s.asg(i) && !s.asg(i - 1) && !s.asg(i + 1)) {
+          s.set_asg(i, 0);
+        }
+      }
+      for (size_t i = n - 3; i >= 2; --i) {
+        if (s.asg(i) && !s.asg(i - 1) && !s.asg(i + 1)) {
+          s.set_asg(i, 0);
+        }
       }
     }
-    for (size_t i = n - 3; i >= 2; --i) {
-      if (s.asg(i) && !s.asg(i - 1) && !s.asg(i + 1)) {
-        s.set_asg(i, 0);
-      }
-    }
-    }
+    s.log_pass(n); // :795
     // P7 (:799-822): per ID in ascending order (std::map), between two
     // non-adjacent assigned occurrences every tile gets the ID found at the
     // earlier occurrence *at that moment* (earlier groups may have rewritten it).
@@ -282,6 +294,7 @@ smooth(size_t n, size_t x, S& s)
         }
       }
     }
+    s.log_pass(n); // :823
     // P8 (:827-838): end tiles, compared in size_t (no 32-bit wrap)
     {
       const size_t last = s.id(n - 1), last2 = s.id(n - 2), first = s.id(0), second = s.id(1);
@@ -300,6 +313,7 @@ smooth(size_t n, size_t x, S& s)
         s.set_asg(i, 0);
       }
     }
+    s.log_pass(n); // :852
     // P10 (:856-877): assigned runs of length <= 5
     nr = assigned_9_10 ? collect_runs<true>(n, s) : 0;
     for (size_t r = 0; r < nr; ++r) {
@@ -311,6 +325,7 @@ smooth(size_t n, size_t x, S& s)
         }
       }
     }
+    s.log_pass(n); // :879
   }
   return s.count_asg(n);
 }
@@ -499,6 +514,19 @@ decide(size_t threshold, size_t unassigned_min, size_t assigned_max, size_t n, S
     out.kind = KIND_ASSIGNED;
   }
 }
+
+// PtrState that prints --debug's dumps (host only; `out` is a FILE*)
+struct DebugPtrState : PtrState
+{
+  void* out = nullptr;
+  void (*print)(void* out, const uint32_t* ids, const uint8_t* flags, size_t n) = nullptr;
+  void log_pass(size_t n) const
+  {
+    if (print) {
+      print(out, ids, flags, n);
+    }
+  }
+};
 
 // pointer form (ids / flags hold n entries, scratch max(n, GR_MIN_SCRATCH))
 GR_HD inline void

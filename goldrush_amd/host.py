@@ -32,7 +32,7 @@ class gr_classifier_params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("tile_length", C.c_uint32), ("block_size", C.c_uint32), ("threshold", C.c_uint32),
                 ("unassigned_min", C.c_uint32), ("assigned_max", C.c_uint32), ("kmer_size", C.c_uint32), ("hash_num", C.c_uint32),
                 ("target_bases", C.c_uint64), ("max_paths", C.c_uint64), ("silver_path", C.c_int32), ("verbose", C.c_int32),
-                ("max_window", C.c_uint32), ("world", C.c_uint32), ("rank", C.c_uint32)]
+                ("max_window", C.c_uint32), ("world", C.c_uint32), ("rank", C.c_uint32), ("debug", C.c_int32)]
 
 
 class gr_classifier_state(C.Structure):
@@ -105,6 +105,7 @@ SIGNATURES = {
     "gr_classifier_create": (C.c_int, [C.POINTER(gr_classifier_params), C.POINTER(grp_engine_vt), _vp, C.POINTER(_vp)]),
     "gr_classifier_destroy": (None, [_vp]),
     "gr_classifier_set_allgather": (None, [_vp, _vp, _vp]),
+    "gr_classifier_set_debug": (None, [_vp, _vp]),
     "gr_shm_allgather_open": (_vp, [C.c_uint32, C.c_uint32, C.c_char_p, C.c_double]),
     "gr_shm_allgather": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "gr_shm_allgather_close": (None, [_vp]),
@@ -244,7 +245,7 @@ class Classifier:
         self.lib = load()
         self.vt = vt
         p = gr_classifier_params(C.sizeof(gr_classifier_params), tile, block, threshold, unassigned_min, assigned_max, k, h, target_bases, max_paths,
-                                 1 if silver_path else 0, 1 if verbose else 0, max_window, world, rank)
+                                 1 if silver_path else 0, 1 if verbose else 0, max_window, world, rank, 0)
         out = _vp()
         rc = self.lib.gr_classifier_create(C.byref(p), C.byref(vt), engine_handle, C.byref(out))
         if rc != 0:

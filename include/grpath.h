@@ -18,9 +18,10 @@
  *   - there is NO CPU fallback: if no HIP device is usable, grp_create fails
  *     with GRP_ERR_NO_DEVICE.
  *   - threading: one host thread per grp_ctx (the reference's consumer side is
- *     single-threaded too, goldrush_path.cpp:1229-1256).  grp_bv_insert may
- *     be called repeatedly, in any order of reads (idempotent, order-free,
- *     like MIBFConstructSupport::insertBV under `omp parallel`).
+ *     single-threaded too, goldrush_path.cpp:1229-1256) — except grp_bv_insert,
+ *     which is re-entrant like MIBFConstructSupport::insertBV under `omp parallel`
+ *     (goldrush_path.cpp:257-305): any number of host threads, any order of reads,
+ *     idempotent (the enqueue is serialised inside the library).
  *   - ownership: the library owns all device memory; caller-provided host
  *     buffers are only read/written during the call.
  *

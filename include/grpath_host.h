@@ -116,6 +116,8 @@ typedef struct
   int32_t verbose;
   uint32_t max_window;    /* speculation window cap (reads); 0 = default */
   uint32_t world, rank;   /* ranks sharing each window (1, 0 = single GPU) */
+  int32_t debug;          /* --debug: reads are decided one by one on the host and the reference's per-read
+                             lines and per-pass tile-state dumps go to stderr (goldrush_path.cpp:109-124, 938-1086) */
 } gr_classifier_params;
 
 /* one committed read, in file order */
@@ -150,6 +152,10 @@ typedef struct gr_classifier gr_classifier;
 int gr_classifier_create(const gr_classifier_params* p, const grp_engine_vt* vt, void* engine_ctx, gr_classifier** out);
 void gr_classifier_destroy(gr_classifier* c);
 void gr_classifier_set_callbacks(gr_classifier* c, gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user);
+/* --debug: called (with the commit callbacks' user pointer) in front of every read that is classified:
+ * the host prints what the reference prints there — the skipped records before it, "name:", "num tiles:" */
+typedef void (*gr_debug_fn)(void* user, uint32_t read);
+void gr_classifier_set_debug(gr_classifier* c, gr_debug_fn fn);
 /* the all-gather with its own user pointer (e.g. gr_shm_allgather + its handle) */
 void gr_classifier_set_allgather(gr_classifier* c, gr_allgather_fn allgather, void* allgather_user);
 /*

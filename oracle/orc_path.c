@@ -1299,6 +1299,13 @@ calc_min_phred_threshold(orc_path* p)
   qsort(phred_scores, MEDIAN_SAMPLES_NEEDED, sizeof(uint32_t), cmp_u32_desc);
   uint32_t med = phred_scores[n / 2]; /* calc_median :54-59 */
   p->opt.phred_min = med > MINIMUM_PHRED_THRESHOLD ? med : MINIMUM_PHRED_THRESHOLD;
+  if (p->opt.debug) { /* log_phred_calculations :60-70 */
+    LOGF(p, "Number of reads used to calculate median: %zu\nMedian array: ", n);
+    for (size_t i = 0; i < MEDIAN_SAMPLES_NEEDED; ++i) {
+      LOGF(p, "%u ", phred_scores[i]);
+    }
+    LOGF(p, "\n");
+  }
   if (p->opt.verbose) {
     LOGF(p, "Minimum phred score calculated with median: %u\n", p->opt.phred_min);
   }
@@ -1640,6 +1647,9 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
     return;
   }
   if (record->len < opt->min_length) { /* :907-918 */
+    if (opt->debug) {
+      LOGF(p, "too short\nskipping: %s\n", record->id);
+    }
     dec->decision = ORC_DEC_SKIP_SHORT;
     ++p->id;
     progress(p);
@@ -1647,6 +1657,9 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
   }
   if (p->filter_out_reads.n != 0) { /* :919-932 */
     if (strset_has(&p->filter_out_reads, record->id)) {
+      if (opt->debug) {
+        LOGF(p, "hairpin or quality too low or invalid bases\nskipping: %s\n", record->id);
+      }
       dec->decision = ORC_DEC_SKIP_FILTERED;
       ++p->id;
       progress(p);
@@ -1657,6 +1670,9 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
   size_t num_tiles = len / opt->tile_length;
   p->log_info.total_tiles_per_path += num_tiles;
   dec->num_tiles = num_tiles;
+  if (opt->debug) { /* :938-941 */
+    LOGF(p, "name: %s\nnum tiles: %zu\n", record->id, num_tiles);
+  }
 
   /* the producer side (read_hashing.cpp:29-54): hashes of this read's tiles */
   orc_tile_hashes th;
@@ -1695,6 +1711,9 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
   const size_t num_assigned_tiles = orc_smooth_tiles(
     num_tiles, ids, bools, (const orc_id_count* const*)lists, list_n, opt->threshold, opt->debug ? p->log : NULL);
   const size_t num_unassigned_tiles = num_tiles - num_assigned_tiles;
+  if (opt->debug) { /* :957-964 */
+    LOGF(p, "num assigned tiles: %zu\nnum unassigned tiles: %zu\n", num_assigned_tiles, num_unassigned_tiles);
+  }
   dec->num_assigned = num_assigned_tiles;
   p->log_info.total_assigned_tiles_per_path += num_assigned_tiles;
   p->log_info.total_unassigned_tiles_per_path += num_unassigned_tiles;
@@ -1707,6 +1726,9 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
 
   if (!assigned) {
     /* :978-1011 */
+    if (opt->debug) {
+      LOGF(p, "unassigned\n");
+    }
     dec->decision = ORC_DEC_INSERT_WHOLE;
     ++p->ids_inserted;
     dec->first_id = p->ids_inserted;
@@ -1734,6 +1756,9 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
       dec->decision = ORC_DEC_ASSIGNED_ALL;
       ++p->id;
       ++p->log_info.valid_reads;
+      if (opt->debug) { /* :1016-1018 */
+        LOGF(p, "complete assignment\n");
+      }
       progress(p);
       goto cleanup;
     }
@@ -1744,6 +1769,9 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
     if (good_flank) {
       /* :1038-1080 */
       assigned = 0;
+      if (opt->debug) { /* :1037-1039 */
+        LOGF(p, "trimmed\n");
+      }
       dec->decision = ORC_DEC_INSERT_TRIMMED;
       dec->trim_start = trim_start_idx;
       dec->trim_end = trim_end_idx;
@@ -1781,6 +1809,9 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
     }
   }
   if (assigned) {
+    if (opt->debug) { /* :1084-1086 */
+      LOGF(p, "assigned\n");
+    }
     dec->decision = ORC_DEC_ASSIGNED;
   }
   if (p->finished) {

@@ -125,3 +125,31 @@ def test_a_garbage_line_ends_the_input_for_good_whatever_the_batching(oracle, na
         assert rp.returncode == 0, rp.stderr[-2000:]
         outs[name] = open(d / "out.fa", "rb").read()
     assert outs["cut"] and all(v == outs["cut"] for v in outs.values())
+
+
+@pytest.mark.parametrize("mode", ["silver", "golden"])
+def test_debug_output_matches_the_oracle(oracle, native, tmp_path, mode):
+    """--debug (goldrush_path.cpp:60-70, 109-124, 267-273, 907-1086): the Phred lines of the fill
+    pass, the median array, and per read the skipped records, name, tile count, the nine
+    tile-state dumps of the smoothing passes, the assigned / unassigned counts and the
+    decision — line by line equal to the oracle's."""
+    fq = os.path.join(GOLD, "tiny.fq")
+    common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-i", fq, "--debug"]
+    args = common + (["-P0", "-r0.9", "--silver_path", "-M3", "-m3000"] if mode == "silver" else ["-P12", "-m2500"])
+    d_o, d_p = tmp_path / "o", tmp_path / "p"
+    d_o.mkdir()
+    d_p.mkdir()
+    ro = oracle.run_cli(args + ["-p", str(d_o / "out")], timeout=600)
+    script = tmp_path / "runner.py"
+    script.write_text(RUNNER.format(root=ROOT))
+    rp = subprocess.run([sys.executable, str(script)] + args + ["-p", str(d_p / "out")], capture_output=True, text=True, timeout=900,
+                        env=dict(os.environ, GRP_HOST_INGEST="1", OMP_NUM_THREADS="2", GRP_BATCH_RECORDS="11"))
+    assert rp.returncode == ro.returncode, rp.stderr[-3000:]
+    for f in sorted(os.listdir(d_o)):
+        assert filecmp.cmp(d_o / f, d_p / f, shallow=False), f
+    keep = ("name:", "num tiles:", "num assigned tiles:", "num unassigned tiles:", "unassigned", "complete assignment", "trimmed", "assigned", "too short", "skipping:",
+            "hairpin or quality", "phred avg:", "phred delta:", "Number of reads used", "Median array:")
+    pick = lambda text: [l for l in text.splitlines() if l.startswith(keep) or (l[:1].isdigit() and "\t" in l)]  # noqa: E731
+    po, pp = pick(ro.stderr), pick(rp.stderr)
+    assert len(po) > 100 and any(l.startswith("too short") for l in po) and any("\t" in l for l in po)
+    assert pp == po

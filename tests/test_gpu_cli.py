@@ -253,3 +253,19 @@ def test_c4_geometry_on_a_subsample(oracle, host, tmp_path):
     assert files == ["out_%d.fq" % i for i in range(1, 6)] and all(os.path.getsize(d_p / f) > 0 for f in files)
     assert "WARNING: Expected" not in rp.stderr  # all five paths were generated
     assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+
+
+def test_debug_dumps_match_the_oracle(oracle, host, tmp_path):
+    """--debug through the HIP engine: the per-read lines and the nine tile-state dumps of the
+    smoothing passes (goldrush_path.cpp:109-124, 907-1086) equal the oracle's, line by line."""
+    fq = str(tmp_path / "reads.fq")
+    _mk_fastq(fq, 200_000, 300, 6000, 4000, seed=41, short=9)
+    args = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j4", "-d5", "-x10", "-s1011011110110111101101", "-g200000", "-b4", "-H3000000", "-P12", "-r0.9",
+            "--silver_path", "-M2", "-m3500", "-i", fq, "--debug"]
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "dbg")
+    keep = ("name:", "num tiles:", "num assigned tiles:", "num unassigned tiles:", "unassigned", "complete assignment", "trimmed", "assigned", "too short", "skipping:",
+            "hairpin or quality", "phred avg:", "phred delta:")
+    pick = lambda text: [l for l in text.splitlines() if l.startswith(keep) or (l[:1].isdigit() and "\t" in l)]  # noqa: E731
+    po, pp = pick(ro.stderr), pick(rp.stderr)
+    assert len(po) > 1000 and any(l.startswith("trimmed") for l in po)
+    assert pp == po

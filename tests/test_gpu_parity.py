@@ -474,3 +474,40 @@ def test_ntcard_tables_match_oracle(oracle, native):
     assert eng.finalize() == omf.finalize()
     assert np.array_equal(eng.export_bits(), omf.bits())
     eng.close()
+
+
+def test_bv_insert_is_reentrant(native):
+    """grp_bv_insert from eight host threads at once (the reference calls insertBV from an
+    `omp parallel` region, goldrush_path.cpp:257-305) sets the bits one thread sets."""
+    import threading
+
+    seeds = default_seeds(3)
+    m = 200_000_000
+    dr = native.synth_reads(4000, 5_000_000, mean_len=9000, min_len=7000)
+    a = native.Engine(K, 3, TILE, m, seeds)
+    ba = a.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+    a.bv_insert(ba)
+    a.sync()
+    ref = a.export_bits()
+    a.close()
+    b = native.Engine(K, 3, TILE, m, seeds)
+    bb = b.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+    errs = []
+
+    def work(t):
+        try:
+            for lo in range(t * 25, 4000, 8 * 25):
+                b.bv_insert(bb, lo, 25)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    b.sync()
+    assert np.array_equal(b.export_bits(), ref)
+    b.close()
+    dr.free()
