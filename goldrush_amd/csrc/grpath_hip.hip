@@ -452,7 +452,8 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     // one frame per lane and pass: fewer registers, more resident workgroups — measured
     // better than two for the persistent form (h = 3: +3 %, h = 5: +19 %)
     static const bool fr2 = getenv("GRP_STREAM_FR2") != nullptr; // developer hook
-    auto kern = fr2 ? k_query<HH, 2, 0, true> : k_query<HH, 1, 0, true>;
+    static const bool wt16 = getenv("GRP_STREAM_WT16") != nullptr; // developer hook: unrolled care loop
+    auto kern = fr2 ? k_query<HH, 2, 0, true> : (wt16 && c->uniform_weight == 16) ? k_query<HH, 1, 16, true> : k_query<HH, 1, 0, true>;
     int rc = ensure_lds(c, kern, g.lds);
     if (rc != GRP_OK) {
       return rc;
@@ -484,12 +485,10 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
       if (sv == "1,16" && c->uniform_weight == 16) return go(k_query<HH, 1, 16, false>);
     }
   }
-  if constexpr (HH == 3) {
-    // latency windows (a few reads on an otherwise idle device): a wave's time is the chain of
-    // its own instructions; the unrolled care loop shortens it
-    if (c->uniform_weight == 16 && n_launch <= SMALL_TILES) {
-      return go(k_query<HH, 2, 16, false>);
-    }
+  // latency windows (a few reads on an otherwise idle device): a wave's time is the chain of
+  // its own instructions; the unrolled care loop shortens it
+  if (c->uniform_weight == 16 && n_launch <= SMALL_TILES) {
+    return go(k_query<HH, 2, 16, false>);
   }
   return go(k_query<HH, 2, 0, false>);
 }

@@ -511,3 +511,40 @@ def test_bv_insert_is_reentrant(native):
     assert np.array_equal(b.export_bits(), ref)
     b.close()
     dr.free()
+
+
+def test_bit_vector_merge_primitives(native):
+    """grp_words_or_device / grp_bv_export_device / grp_bv_import_device (the pieces of the
+    multi-GPU fill merge, bench.py): two engines fill halves of the reads, the vectors are
+    OR-ed in caller memory and imported — the result is the vector of one engine filling all."""
+    seeds = default_seeds(3)
+    m = 150_000_000
+    dr = native.synth_reads(1500, 3_000_000, mean_len=9000, min_len=7000)
+    full = native.Engine(K, 3, TILE, m, seeds)
+    bf = full.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+    full.bv_insert(bf)
+    full.sync()
+    ref = full.export_bits()
+    full.close()
+    a = native.Engine(K, 3, TILE, m, seeds)
+    b = native.Engine(K, 3, TILE, m, seeds)
+    ba, bb = a.wrap_device(dr.d_ptr, dr.word_off, dr.lens), b.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+    a.bv_insert(ba, 0, 700)
+    b.bv_insert(bb, 700, 800)
+    a.sync()
+    b.sync()
+    n = a.bv_words()
+    pad = (n + 3) // 4 * 4
+    bufa = native.load().grp_synth_alloc(pad * 4)
+    bufb = native.load().grp_synth_alloc(pad * 4)
+    a.bv_export_device(bufa)
+    b.bv_export_device(bufb)
+    a.words_or_device(bufa, bufb, n)
+    b.bv_import_device(bufa)
+    assert np.array_equal(b.export_bits(), ref)
+    assert a.finalize() < b.finalize()  # a alone holds fewer bits than the merged vector
+    native.load().grp_synth_free(bufa)
+    native.load().grp_synth_free(bufb)
+    a.close()
+    b.close()
+    dr.free()
