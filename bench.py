@@ -481,6 +481,10 @@ def main():
 
     if rank == 0:
         kq = ks["query"]
+        kernel_name = "k_query, throughput forms (streaming windows k_query<h,1,0,true>, large windows k_query<h,2,0,false>); the latency windows of the insert-heavy head are in aux.query_latency"
+        if kq["units"] == 0:  # a run that never left the insert-heavy head: the latency form is all there is
+            kq = ks["query_latency"]
+            kernel_name = "k_query, latency form (k_query<h,2,16,false>: windows of a few reads; the run never left the insert-heavy head)"
         reads_done = st1["reads_committed"] - st0["reads_committed"]  # silver mode stops behind the last path
         avg_ms = kq["ms"] / max(kq["launches"], 1)
         probes_per_launch = kq["units"] / max(kq["launches"], 1)
@@ -539,7 +543,7 @@ def main():
                        "parallelism": ("one GPU, streaming windows" if world == 1 else "windows striped over %d GPUs, replicated miBF, 32-B decisions all-gathered per stripe group" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC pass of the same kernel, %s, scaled by probes)" % (os.path.basename(pmc_file) if pmc_file else "none"),
-                         "kernel": "k_query, throughput forms (streaming windows k_query<h,1,0,true>, large windows k_query<h,2,0,false>); the latency windows of the insert-heavy head are in aux.query_latency",
+                         "kernel": kernel_name,
                          "launches": kq["launches"], "avg_launch_ms": avg_ms,
                          "probes_per_launch": probes_per_launch, "bytes_per_probe": 128,
                          "note": "achieved/frac use the ALGORITHMIC 128 B per probe of SURVEY 8(d) (the reference's two-sector probe); this layout moves one 64-B bucket per probe, see moved_*; the kernel's real bound is the random-line rate, see line_rate_*",

@@ -187,7 +187,10 @@ Classifier::window_plan() const
     // streaming launch: no per-window round trip and a stale window is cut short by the
     // abort flag, so an insert costs one drain + relaunch (~120 us: resident workgroups
     // finish, insert kernels, ramp-up) whatever the window size
-    const double t_abort = 120e-6;
+    static const double t_abort = [] { // developer hook: what an insert costs a streaming launch (us)
+      const char* e = getenv("GRP_T_ABORT_US");
+      return (e ? atof(e) : 120.0) * 1e-6;
+    }();
     // the window size does not matter to an abort (only the resident workgroups are lost),
     // so the launches are as long as allowed.  Several ranks: every rank works on its own
     // stripe of the current group, an insert also discards about half a group; the
