@@ -189,7 +189,7 @@ Classifier::window_plan() const
     // finish, insert kernels, ramp-up) whatever the window size
     static const double t_abort = [] { // developer hook: what an insert costs a streaming launch (us)
       const char* e = getenv("GRP_T_ABORT_US");
-      return (e ? atof(e) : 120.0) * 1e-6;
+      return (e ? atof(e) : 400.0) * 1e-6; // 120 us on C1, ~300 us on C2 (tools/abort_matrix.sh)
     }();
     // the window size does not matter to an abort (only the resident workgroups are lost),
     // so the launches are as long as allowed.  Several ranks: every rank works on its own
