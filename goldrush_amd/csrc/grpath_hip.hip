@@ -95,6 +95,35 @@ struct QuerySlot
   uint64_t t0 = 0, nt = 0, probes = 0;
 };
 
+struct DevBatchView; // grp_kernels.inc
+
+// state of a batch of inserts applied ahead of their reads' queries (grp_batch_*, grp_batch.inc)
+struct BatchRun
+{
+  bool active = false;
+  uint32_t n_ins = 0, block_tiles = 0;
+  uint64_t n_units = 0, n_probes = 0;
+  uint32_t h_counters[4] = { 0, 0, 0, 0 }; // owner records, overflow touches, log entries, error
+  uint32_t* d_counters = nullptr;
+  uint32_t* d_ins = nullptr;      // [n_ins][6]: read, tile_start, tile_end, first_id, id_offset, first unit
+  uint64_t ins_cap = 0;
+  uint32_t* d_rec_slot = nullptr; // owner records
+  unsigned long long* d_rec_loc = nullptr;
+  uint64_t rec_cap = 0;
+  uint32_t* d_ovf_slot = nullptr; // touches of a rank that somebody else owns
+  uint32_t* d_ovf_jb = nullptr;
+  unsigned long long* d_log_keys = nullptr;
+  uint32_t* d_log_head = nullptr;
+  uint64_t log_tab_cap = 0;
+  uint32_t* d_log_old = nullptr;
+  uint32_t* d_log_writer = nullptr;
+  uint32_t* d_log_next = nullptr;
+  uint64_t log_cap = 0;
+  uint32_t* d_floor = nullptr;    // grp_batch_classify: per read of the window
+  uint64_t floor_cap = 0;
+  uint32_t first_read = 0;        // reads are numbered from here in the log
+};
+
 // buffers of the ordered commit loop (grp_commit_loop_*)
 struct LoopRun
 {
@@ -136,6 +165,7 @@ struct grp_ctx
   std::string arch;
   bool coherent_arch = false; // gfx942 / gfx950: agent-scope accesses are served by the memory side
   LoopRun loop;
+  BatchRun batch;
   hipStream_t stream = nullptr;
   // decision kernel + copy-back of a pipelined window run here, next to the following
   // window's query kernel on `stream`
@@ -168,6 +198,7 @@ struct grp_ctx
   // host commits the first (grp_classify_reads_begin / _end)
   QuerySlot slot[2];
   QuerySlot* q = &slot[0];
+  const DevBatchView* view = nullptr; // set while grp_batch_classify enqueues its window
   grp_tile_summary* h_tiles = nullptr; // pinned staging
   uint64_t h_tiles_cap = 0;
   grp_id_count* h_lists = nullptr; // pinned staging of the list prefix
@@ -444,9 +475,12 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     if (rc != GRP_OK) {
       return rc;
     }
-    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), d_tile_idx ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, stream_ctl ? *stream_ctl : DevStreamCtl{});
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), d_tile_idx ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, stream_ctl ? *stream_ctl : DevStreamCtl{}, c->view ? *c->view : DevBatchView{});
     return GRP_OK;
   };
+  if (c->view && !stream_ctl) { // grp_batch_classify: every read sees the state in front of its own insert
+    return go(k_query<HH, 2, 0, false, true>);
+  }
   if (stream_ctl) {
     // persistent workgroups: exactly what is resident at once
     // one frame per lane and pass: fewer registers, more resident workgroups — measured
@@ -741,6 +775,21 @@ grp_destroy(grp_ctx* c)
     (void)hipFree(lp.d_tile_trace);
     (void)hipFree(lp.d_unit_buf);
     (void)hipFree(lp.d_tile_parts);
+  }
+  {
+    BatchRun& b = c->batch;
+    (void)hipFree(b.d_counters);
+    (void)hipFree(b.d_ins);
+    (void)hipFree(b.d_rec_slot);
+    (void)hipFree(b.d_rec_loc);
+    (void)hipFree(b.d_ovf_slot);
+    (void)hipFree(b.d_ovf_jb);
+    (void)hipFree(b.d_log_keys);
+    (void)hipFree(b.d_log_head);
+    (void)hipFree(b.d_log_old);
+    (void)hipFree(b.d_log_writer);
+    (void)hipFree(b.d_log_next);
+    (void)hipFree(b.d_floor);
   }
   (void)hipFree(c->d_ntc);
   (void)hipFree(c->d_ntc_chunks);
@@ -2292,5 +2341,6 @@ grp_stream(grp_ctx* c)
 } // extern "C"
 
 #include "grp_loop_host.inc"
+#include "grp_batch.inc"
 #include "grp_ingest.inc"
 #include "grp_ntcard.inc"

@@ -71,6 +71,9 @@ Classifier::get_state(gr_classifier_state& s) const
   s.inserts = n_inserts_;
   s.seconds_windows = t_windows_;
   s.seconds_commit = t_commit_;
+  s.batches = n_batches_;
+  s.batches_undone = n_batch_undone_;
+  s.batch_reads = n_batch_reads_;
 }
 
 void
@@ -736,6 +739,216 @@ Classifier::want_loop() const
   return p_insert_mid_ >= (in_loop_ ? p_out : p_in);
 }
 
+// ---- windows committed as batches ------------------------------------------------------
+// Where many reads insert, a classic window ends at its first insert: one round trip (~80 us)
+// per inserting read.  Two reads of a window hardly ever influence each other (they would have
+// to overlap on the genome), so the whole window is decided against the state in front of it,
+// its inserts are applied at once, and a second query — every read against the state in front of
+// its own insert, through the engine's log — confirms the decisions or names the first read
+// where the serial loop would have gone another way (include/grpath.h, grp_batch_*).
+bool
+Classifier::can_batch() const
+{
+  const char* e = getenv("GRP_BATCH");
+  return vt_.batch_insert && vt_.batch_classify && vt_.batch_undo && vt_.batch_end && vt_.classify_reads && vt_.insert_read && !p_.debug && p_.max_window >= 2 &&
+         !(e && !strcmp(e, "off"));
+}
+
+bool
+Classifier::want_batch() const
+{
+  if (!can_batch() || batch_bypass_) {
+    return false;
+  }
+  const char* e = getenv("GRP_BATCH");
+  if (e && !strcmp(e, "force")) {
+    return true;
+  }
+  // a batch costs two queries per read whatever the insert rate; a classic round costs one
+  // query per read plus ~80 us per insert: the batch wins above ~5 % inserting reads
+  static const double p_in = [] {
+    const char* v = getenv("GRP_BATCH_ENTER");
+    return v ? atof(v) : 0.10;
+  }();
+  static const double p_out = [] {
+    const char* v = getenv("GRP_BATCH_LEAVE");
+    return v ? atof(v) : 0.05;
+  }();
+  return p_insert_ >= (in_batch_ ? p_out : p_in);
+}
+
+int
+Classifier::batch_round(uint32_t& pos)
+{
+  const uint32_t n = rg_.n;
+  const uint32_t tile = p_.tile_length, block = p_.block_size;
+  static const uint32_t max_batch = [] { // developer hook
+    const char* e = getenv("GRP_BATCH_MAX");
+    return e ? (uint32_t)std::max(2l, atol(e)) : 4096u;
+  }();
+  const uint32_t B = std::min<uint32_t>({ batch_reads_, n - pos, p_.max_window, max_batch });
+  const grp_decide_params dp{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
+  auto fail = [&](const char* what, int rc) {
+    err_ = std::string(what) + ": " + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+    return rc;
+  };
+  in_batch_ = true;
+  ++n_windows_;
+  bdec0_.resize(B);
+  int rc = vt_.classify_reads(ctx_, rg_.reads, base_ + pos, B, &dp, bdec0_.data());
+  if (rc != GRP_OK) {
+    return fail("classify_reads", rc);
+  }
+  n_queried_ += B;
+
+  // the inserts these decisions ask for, with the IDs commit() will allocate
+  bins_.clear();
+  bfloor_.assign(B, 0);
+  bfirst_.assign(B, 0);
+  uint32_t ids = ids_inserted_;
+  uint64_t bases = inserted_bases_;
+  uint32_t cnt = B, first_ins = UINT32_MAX;
+  for (uint32_t j = 0; j < B; ++j) {
+    const gr_read_decision& d = bdec0_[j];
+    const uint32_t len = rg_.lens[pos + j];
+    bfloor_[j] = ids + 1;
+    bool ins = false;
+    uint32_t ts = 0, te_excl = 0, off = 0, next_ids = ids;
+    if (d.kind == DEC_INSERT_WHOLE) {
+      ins = true;
+      te_excl = d.num_tiles;
+      next_ids = ids + 1 + (uint32_t)(len / ((size_t)tile * block));
+      bases += len;
+    } else if (d.kind == DEC_INSERT_TRIMMED) {
+      ins = true;
+      ts = d.trim_start;
+      te_excl = d.trim_end + 1;
+      off = 1;
+      next_ids = ids + 1 + (d.trim_end - d.trim_start) / block;
+      uint64_t n_out = len - (uint64_t)ts * tile;
+      if (d.trim_end != d.num_tiles - 1) {
+        n_out = std::min<uint64_t>(n_out, (uint64_t)(te_excl - ts) * tile);
+      }
+      bases += n_out;
+    } else if (d.kind != DEC_ASSIGNED_ALL && d.kind != DEC_ASSIGNED) {
+      cnt = j; // a read the engine hands back to the host's decision: the classic path takes it
+      break;
+    }
+    if (ins) {
+      if ((te_excl - ts + block - 1) / block > 256 || te_excl <= ts) {
+        cnt = j; // more ID blocks than a batch entry holds
+        break;
+      }
+      bins_.push_back(grp_batch_insert{ base_ + pos + j, ts, te_excl, ids + 1, off });
+      bfirst_[j] = ids + 1;
+      ids = next_ids;
+      if (first_ins == UINT32_MAX) {
+        first_ins = j;
+      }
+      if (p_.silver_path && p_.target_bases < bases) {
+        cnt = j + 1; // the silver path rolls over behind this read: the ID array is reset there
+        break;
+      }
+    }
+  }
+  if (cnt == 0) {
+    batch_bypass_ = true;
+    return GRP_OK;
+  }
+  // up to and including the first insert the decisions ARE the serial loop's
+  auto commit_classic = [&](uint32_t upto) {
+    uint32_t j = 0;
+    bool stale = false;
+    while (j < upto && !stale && !finished_ && rc == GRP_OK) {
+      stale = commit_one(pos + j, bdec0_[j], rc);
+      ++j;
+    }
+    pos += j;
+    return rc;
+  };
+  if (bins_.size() <= 1) {
+    return commit_classic(bins_.empty() ? cnt : first_ins + 1);
+  }
+  rc = vt_.batch_insert(ctx_, rg_.reads, bins_.data(), (uint32_t)bins_.size(), block, base_ + pos);
+  if (rc == GRP_ERR_NOMEM) {
+    // the window's reads share too many ranks (they overlap each other): a smaller batch next time
+    batch_reads_ = std::max<uint32_t>(2, cnt / 2);
+    rc = GRP_OK;
+    return commit_classic(first_ins + 1);
+  }
+  if (rc != GRP_OK) {
+    return fail("batch_insert", rc);
+  }
+  bdec1_.resize(cnt);
+  rc = vt_.batch_classify(ctx_, rg_.reads, base_ + pos, cnt, &dp, bfloor_.data(), bdec1_.data());
+  if (rc != GRP_OK) {
+    (void)vt_.batch_undo(ctx_, bfloor_[0]);
+    return fail("batch_classify", rc);
+  }
+  n_queried_ += cnt;
+  ++n_batches_;
+  uint32_t bad = cnt;
+  for (uint32_t j = 0; j < cnt; ++j) {
+    const gr_read_decision &a = bdec0_[j], &b = bdec1_[j];
+    if (a.kind != b.kind || a.num_tiles != b.num_tiles || (a.kind == DEC_INSERT_TRIMMED && (a.trim_start != b.trim_start || a.trim_end != b.trim_end))) {
+      bad = j;
+      break;
+    }
+  }
+  uint32_t confirmed = cnt;
+  if (bad == cnt) {
+    rc = vt_.batch_end(ctx_);
+    if (rc != GRP_OK) {
+      return fail("batch_end", rc);
+    }
+    batch_reads_ = std::min<uint32_t>(max_batch, batch_reads_ + batch_reads_ / 2 + 1);
+  } else {
+    // from read `bad` on the batch was not the serial loop: take it back and apply the
+    // confirmed inserts in front of `bad` again
+    ++n_batch_undone_;
+    batch_reads_ = std::max<uint32_t>(2, std::min(batch_reads_, cnt) / 2);
+    rc = vt_.batch_undo(ctx_, bfloor_[0]);
+    if (rc != GRP_OK) {
+      return fail("batch_undo", rc);
+    }
+    uint32_t n_pre = 0;
+    while (n_pre < bins_.size() && bins_[n_pre].read < base_ + pos + bad) {
+      ++n_pre;
+    }
+    confirmed = bad;
+    if (n_pre >= 2) {
+      rc = vt_.batch_insert(ctx_, rg_.reads, bins_.data(), n_pre, block, base_ + pos);
+      if (rc == GRP_OK) {
+        rc = vt_.batch_end(ctx_);
+      }
+      if (rc != GRP_OK) {
+        return fail("batch_insert (confirmed part)", rc);
+      }
+    } else if (n_pre == 1) {
+      const grp_batch_insert& e = bins_[0];
+      rc = vt_.insert_read(ctx_, rg_.reads, e.read, e.tile_start, e.tile_end, block, e.first_id, e.id_offset);
+      if (rc != GRP_OK) {
+        return fail("insert_read", rc);
+      }
+    }
+  }
+  // the second decisions are the records (hits / misses against the state in front of each read)
+  for (uint32_t j = 0; j < confirmed && rc == GRP_OK && !finished_; ++j) {
+    (void)commit_one(pos + j, bdec1_[j], rc, bfirst_[j] != 0, bfirst_[j]);
+  }
+  if (rc != GRP_OK) {
+    return rc;
+  }
+  n_batch_reads_ += confirmed;
+  pos += confirmed;
+  if (bad != cnt && !finished_) {
+    // `bad` itself: its second decision was taken against exactly the state it now sees
+    (void)commit_one(pos, bdec1_[bad], rc);
+    ++pos;
+  }
+  return rc;
+}
+
 // ---- commit loop on the device: the host only replays the records ---------------------
 int
 Classifier::loop_round(uint32_t& pos)
@@ -1036,6 +1249,14 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
       continue;
     }
     in_loop_ = false;
+    if (!next_.active && !snext_.active && want_batch()) {
+      const auto t0 = std::chrono::steady_clock::now();
+      rc = batch_round(pos);
+      t_windows_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      continue;
+    }
+    in_batch_ = false;
+    batch_bypass_ = false;
     if (!next_.active && (snext_.active || window_plan().streaming)) {
       const auto t0 = std::chrono::steady_clock::now();
       rc = stream_round(pos);

@@ -72,6 +72,9 @@ private:
   bool can_loop() const;
   bool want_loop() const; // the insert rate calls for the device-side commit loop
   int loop_round(uint32_t& pos);
+  bool can_batch() const;
+  bool want_batch() const; // the insert rate calls for windows committed as batches
+  int batch_round(uint32_t& pos);
   void drop_streams();
   int stream_decision(uint32_t j, gr_read_decision& d);
   int stream_round(uint32_t& pos);
@@ -107,6 +110,10 @@ private:
   bool in_loop_ = false;         // the last round ran as a commit loop (hysteresis of the choice)
   bool loop_disabled_ = false;   // a loop launch could not become resident (shared device): windows only
   uint64_t n_loops_ = 0, n_loop_reads_ = 0;
+  bool in_batch_ = false;        // the last round was a batch (hysteresis)
+  bool batch_bypass_ = false;    // the read in front cannot be part of a batch: one classic round
+  uint32_t batch_reads_ = 64;    // reads per batch: grows while batches are confirmed, halves when one is taken back
+  uint64_t n_batches_ = 0, n_batch_undone_ = 0, n_batch_reads_ = 0;
   double p_redo_ = 0.0;          // streaming records handed back to the synchronous path (EMA over ~64 reads)
   double avg_probes_per_read_ = 75000.0;
   uint64_t n_windows_ = 0, n_queried_ = 0, n_committed_ = 0, n_inserts_ = 0;
@@ -129,7 +136,9 @@ private:
   uint32_t base_ = 0;
   std::vector<grp_tile_summary> tiles_;
   std::vector<grp_id_count> lists_;
-  std::vector<gr_read_decision> dec_, dec_all_, stripe_send_, stripe_recv_;
+  std::vector<gr_read_decision> dec_, dec_all_, stripe_send_, stripe_recv_, bdec0_, bdec1_;
+  std::vector<grp_batch_insert> bins_;
+  std::vector<uint32_t> bfloor_, bfirst_;
   std::vector<TileWorkspace> ws_;
   std::string err_;
 };

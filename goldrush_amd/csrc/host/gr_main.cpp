@@ -40,6 +40,14 @@ hip_engine()
   vt.stream_abort = [](void* c, uint32_t slot) { return grp_classify_stream_abort(static_cast<grp_ctx*>(c), slot); };
   vt.stream_poll = [](void* c, uint32_t slot) { return grp_classify_stream_poll(static_cast<grp_ctx*>(c), slot); };
   vt.stream_end = [](void* c, uint32_t slot, uint32_t* n) { return grp_classify_stream_end(static_cast<grp_ctx*>(c), slot, n); };
+  vt.batch_insert = [](void* c, const void* r, const grp_batch_insert* ins, uint32_t n, uint32_t block, uint32_t first) {
+    return grp_batch_insert_reads(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), ins, n, block, first);
+  };
+  vt.batch_classify = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, const uint32_t* id_floor, grp_read_decision* out) {
+    return grp_batch_classify(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, id_floor, out);
+  };
+  vt.batch_undo = [](void* c, uint32_t id_floor) { return grp_batch_undo(static_cast<grp_ctx*>(c), id_floor); };
+  vt.batch_end = [](void* c) { return grp_batch_end(static_cast<grp_ctx*>(c)); };
   vt.ntcard_begin = [](void* c, uint32_t sbits) { return grp_ntcard_begin(static_cast<grp_ctx*>(c), sbits); };
   vt.ntcard_add = [](void* c, const void* r, uint32_t first, uint32_t count, const uint32_t* extra) {
     return grp_ntcard_add(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, extra);

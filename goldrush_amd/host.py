@@ -39,7 +39,8 @@ class gr_classifier_state(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("valid_reads", "total_tiles", "assigned_tiles", "unassigned_tiles", "queries", "hits", "misses", "num_reads_in_path")] + \
                [("phred_sum_in_path", C.c_double), ("inserted_bases", C.c_uint64), ("curr_path", C.c_uint64), ("id", C.c_uint32), ("ids_inserted", C.c_uint32)] + \
                [(n, C.c_uint64) for n in ("windows", "reads_queried", "reads_committed", "inserts")] + \
-               [("seconds_windows", C.c_double), ("seconds_commit", C.c_double)]
+               [("seconds_windows", C.c_double), ("seconds_commit", C.c_double)] + \
+               [(n, C.c_uint64) for n in ("batches", "batches_undone", "batch_reads")]
 
 
 # engine function table: members typed exactly like include/grpath.h
@@ -67,6 +68,10 @@ VT_TYPES = [
     ("loop_stop", C.CFUNCTYPE(C.c_int, _vp)),
     ("loop_poll", C.CFUNCTYPE(C.c_int, _vp)),
     ("loop_end", C.CFUNCTYPE(C.c_int, _vp, _vp)),
+    ("batch_insert", C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32)),
+    ("batch_classify", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp)),
+    ("batch_undo", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
+    ("batch_end", C.CFUNCTYPE(C.c_int, _vp)),
     ("ntcard_begin", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("ntcard_add", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp)),
     ("ntcard_finish", C.CFUNCTYPE(C.c_int, _vp, _vp)),
@@ -230,7 +235,8 @@ def hip_engine_vt() -> grp_engine_vt:
     vt = grp_engine_vt()
     alias = {"classify_begin": "classify_reads_begin", "classify_end": "classify_reads_end", "stream_begin": "classify_stream_begin_striped",
              "stream_abort": "classify_stream_abort", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end",
-             "loop_begin": "commit_loop_begin", "loop_stop": "commit_loop_stop", "loop_poll": "commit_loop_poll", "loop_end": "commit_loop_end"}
+             "loop_begin": "commit_loop_begin", "loop_stop": "commit_loop_stop", "loop_poll": "commit_loop_poll", "loop_end": "commit_loop_end",
+             "batch_insert": "batch_insert_reads"}
     for name, ftype in VT_TYPES:
         sym = getattr(lib, "grp_" + alias.get(name, name))
         setattr(vt, name, C.cast(sym, ftype))

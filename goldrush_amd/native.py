@@ -109,6 +109,10 @@ SIGNATURES = {
     "grp_commit_loop_stop": (C.c_int, [_vp]),
     "grp_commit_loop_poll": (C.c_int, [_vp]),
     "grp_commit_loop_end": (C.c_int, [_vp, C.POINTER(grp_loop_result)]),
+    "grp_batch_insert_reads": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "grp_batch_classify": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp, _vp]),
+    "grp_batch_undo": (C.c_int, [_vp, C.c_uint32]),
+    "grp_batch_end": (C.c_int, [_vp]),
     "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_insert_read": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_reset_ids": (C.c_int, [_vp]),
@@ -468,6 +472,24 @@ class Engine:
         buf = (C.c_uint8 * (max(n, 1) * decision_dtype.itemsize)).from_address(rec_p.value)
         rec = np.frombuffer(buf, dtype=decision_dtype)[:n].copy()
         return rec, {k: getattr(res, k) for k, _ in grp_loop_result._fields_}
+
+    def batch_insert_reads(self, batch: ReadBatch, inserts, block: int, first_read: int):
+        """inserts: list of (read, tile_start, tile_end, first_id, id_offset), ascending reads"""
+        arr = np.ascontiguousarray(np.array(inserts, dtype=np.uint32).reshape(-1, 5))
+        self._check(self.lib.grp_batch_insert_reads(self._h, batch._h, _ptr(arr), arr.shape[0], block, first_read))
+
+    def batch_classify(self, batch: ReadBatch, first: int, count: int, id_floor, threshold=10, unassigned_min=5, assigned_max=1):
+        out = np.zeros(count, dtype=decision_dtype)
+        fl = np.ascontiguousarray(id_floor, dtype=np.uint32)
+        dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
+        self._check(self.lib.grp_batch_classify(self._h, batch._h, first, count, C.byref(dp), _ptr(fl), _ptr(out)))
+        return out
+
+    def batch_undo(self, id_floor: int):
+        self._check(self.lib.grp_batch_undo(self._h, id_floor))
+
+    def batch_end(self):
+        self._check(self.lib.grp_batch_end(self._h))
 
     def tile_states(self, n_tiles: int):
         """(ids, assigned) per tile after the smoothing passes of the last classify_reads window."""

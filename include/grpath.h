@@ -437,6 +437,43 @@ int grp_insert_read(grp_ctx* ctx,
                     uint32_t first_id,
                     uint32_t id_offset);
 
+/* ---- phase 2: a batch of reads committed at once (exact speculation across inserts) -------- */
+/*
+ * Replaces the reference's serial loop (goldrush_path.cpp:1229-1256) for a window of consecutive
+ * reads where most reads insert: two reads share about one rank, so decisions taken for the whole
+ * window against ONE state almost always hold, and checking them costs a second query instead of a
+ * round trip per read.  The caller
+ *   1. decides the window against the state in front of it (grp_classify_reads);
+ *   2. grp_batch_insert_reads: applies the inserts those decisions ask for (one entry per inserting
+ *      read, ascending, with the block IDs the serial loop would allocate: exactly the sequence of
+ *      grp_insert_read calls) and keeps a log of what later reads of the window must not see;
+ *   3. grp_batch_classify: decides the window again, every read against the state in front of ITS
+ *      OWN insert — id_floor[j] = the first ID read j could allocate (IDs grow with the read order:
+ *      a probe returning an ID >= id_floor[j] was written by read j or a later one; the log holds the
+ *      value it replaced) — hits / misses included;
+ *   4. compares in order: while kind / trim range agree, the batch WAS the serial loop and the
+ *      second set of decisions are the records.  At the first read that differs: grp_batch_undo
+ *      (id_floor of the window's first read), insert the reads in front of it again, commit that
+ *      read through grp_insert_read, continue behind it;
+ *   5. grp_batch_end drops the log (no-op after grp_batch_undo).
+ * One batch at a time; nothing else may query or insert between _insert_reads and _end / _undo.
+ * GRP_ERR_NOMEM from _insert_reads: too many ranks are shared by several ID blocks of the batch —
+ * nothing was inserted, use a smaller window.
+ */
+typedef struct
+{
+  uint32_t read;       /* index in the batch of reads */
+  uint32_t tile_start; /* tiles [tile_start, tile_end) are inserted */
+  uint32_t tile_end;
+  uint32_t first_id;   /* as grp_insert_read */
+  uint32_t id_offset;  /* 0 whole read, 1 trimmed */
+} grp_batch_insert;
+
+int grp_batch_insert_reads(grp_ctx* ctx, const grp_reads* reads, const grp_batch_insert* inserts, uint32_t n_inserts, uint32_t block_tiles, uint32_t first_read);
+int grp_batch_classify(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, const uint32_t* id_floor, grp_read_decision* decisions_out);
+int grp_batch_undo(grp_ctx* ctx, uint32_t id_floor);
+int grp_batch_end(grp_ctx* ctx);
+
 /*
  * Replaces: miBFCS.reset_counts(); mibf->reset_ID_vector()
  * (goldrush_path.cpp:180-181 -> MIBFConstructSupport.hpp:183-186,

@@ -48,6 +48,11 @@ typedef struct
   int (*loop_stop)(void* ctx);
   int (*loop_poll)(void* ctx);
   int (*loop_end)(void* ctx, grp_loop_result* result);
+  /* optional (all four or none): a window of reads committed as one batch, grp_batch_* */
+  int (*batch_insert)(void* ctx, const void* reads, const grp_batch_insert* inserts, uint32_t n_inserts, uint32_t block_tiles, uint32_t first_read);
+  int (*batch_classify)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, const uint32_t* id_floor, grp_read_decision* out);
+  int (*batch_undo)(void* ctx, uint32_t id_floor);
+  int (*batch_end)(void* ctx);
   /* optional (all four or none): --ntcard on the device, grp_ntcard_* / grp_set_filter_size */
   int (*ntcard_begin)(void* ctx, uint32_t sbits);
   int (*ntcard_add)(void* ctx, const void* reads, uint32_t first, uint32_t count, const uint32_t* stale_extra);
@@ -185,6 +190,8 @@ typedef struct
   uint64_t windows, reads_queried, reads_committed, inserts;
   /* wall-clock split of gr_classifier_run: engine calls for the windows vs ordered commit */
   double seconds_windows, seconds_commit;
+  /* windows committed as batches (grp_batch_*): batches checked, batches taken back, reads committed through them */
+  uint64_t batches, batches_undone, batch_reads;
 } gr_classifier_state;
 void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
 

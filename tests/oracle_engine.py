@@ -9,9 +9,12 @@ from goldrush_amd import host, native
 
 
 class OracleEngine:
-    def __init__(self, orc, m, seeds, tile, k, reads, pipelined=False, streaming=False, redo_every=0):
+    def __init__(self, orc, m, seeds, tile, k, reads, pipelined=False, streaming=False, redo_every=0, batching=False, batch_crowded_above=0):
         self.pipelined = pipelined
         self.streaming = streaming
+        self.batching = batching      # classify_reads / insert_read / batch_* (windows committed as batches)
+        self.batch_crowded_above = batch_crowded_above  # batches of more inserts are refused (GRP_ERR_NOMEM)
+        self.n_batches = self.n_batch_undone = self.n_batch_refused = 0
         self.redo_every = redo_every  # every n-th streamed record asks for the synchronous path (kind 0)
         self.n_streams = 0
         self.n_stream_aborts = 0
@@ -146,6 +149,72 @@ class OracleEngine:
             self.mf.insert_read_tiles(self.reads[ri], ts, te, id_)
             return 0
 
+        # grp_insert_read: blocks of `block` tiles from tile_start, tile t gets first_id + (t - tile_start + id_offset) / block
+        def insert_read(ctx, reads, ri, ts, te, block, first_id, off):
+            bs = ts
+            while bs < te:
+                self.mf.insert_read_tiles(self.reads[ri], bs, min(bs + block, te), first_id + (bs - ts + off) // block)
+                bs += block
+            return 0
+
+        def classify_reads(ctx, reads, first, count, dp_p, out_p):
+            dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
+            arr = C.cast(out_p, C.POINTER(host.gr_read_decision))
+            self.n_queries += count
+            for j in range(count):
+                arr[j] = _decide(first + j, dp)
+            return 0
+
+        # windows committed as batches (include/grpath.h, grp_batch_*): the "state in front of
+        # read j's own insert" is produced literally — back to the state in front of the
+        # window, then read by read
+        bt = {}
+
+        def batch_insert(ctx, reads, ins_p, n_ins, block, first_read):
+            assert not bt, "one batch at a time"
+            if self.batch_crowded_above and n_ins > self.batch_crowded_above:
+                self.n_batch_refused += 1
+                return native.GRP_ERR_NOMEM
+            ins = np.ctypeslib.as_array(C.cast(ins_p, C.POINTER(C.c_uint32)), shape=(n_ins * 5,)).reshape(n_ins, 5).copy()
+            assert all(ins[i, 0] < ins[i + 1, 0] for i in range(n_ins - 1)) and ins[0, 0] >= first_read
+            bt.update(ins=ins, first=first_read, block=block, ids0=self.mf.ids().copy(), counts0=self.mf.counts().copy())
+            for e in ins:
+                insert_read(ctx, reads, int(e[0]), int(e[1]), int(e[2]), block, int(e[3]), int(e[4]))
+            self.n_batches += 1
+            return 0
+
+        def _batch_restore():
+            self.mf.ids()[:] = bt["ids0"]
+            self.mf.counts()[:] = bt["counts0"]
+
+        def batch_classify(ctx, reads, first, count, dp_p, floor_p, out_p):
+            assert bt and first == bt["first"]
+            dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
+            floors = np.ctypeslib.as_array(C.cast(floor_p, C.POINTER(C.c_uint32)), shape=(count,))
+            arr = C.cast(out_p, C.POINTER(host.gr_read_decision))
+            by_read = {int(e[0]): e for e in bt["ins"]}
+            assert all(first <= r < first + count for r in by_read)
+            _batch_restore()
+            self.n_queries += count
+            for j in range(count):
+                arr[j] = _decide(first + j, dp)
+                e = by_read.get(first + j)
+                if e is not None:
+                    assert int(e[3]) == int(floors[j])  # a read's first ID is the first one it could allocate
+                    insert_read(ctx, reads, int(e[0]), int(e[1]), int(e[2]), bt["block"], int(e[3]), int(e[4]))
+            return 0
+
+        def batch_undo(ctx, floor_id):
+            assert bt and floor_id == int(bt["ins"][0][3])
+            _batch_restore()
+            bt.clear()
+            self.n_batch_undone += 1
+            return 0
+
+        def batch_end(ctx):
+            bt.clear()
+            return 0
+
         def reset_ids(ctx):
             self.mf.reset_ids()
             return 0
@@ -161,6 +230,9 @@ class OracleEngine:
             impl.update({"classify_begin": classify_begin, "classify_end": classify_end})
         if self.streaming:
             impl.update({"stream_begin": stream_begin, "stream_abort": stream_abort, "stream_poll": stream_poll, "stream_end": stream_end})
+        if self.batching:
+            impl.update({"classify_reads": classify_reads, "insert_read": insert_read, "batch_insert": batch_insert, "batch_classify": batch_classify,
+                         "batch_undo": batch_undo, "batch_end": batch_end})
         impl.update({"query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync, "last_error": last_error})
         for name, ftype in host.VT_TYPES:
             if name in impl:

@@ -101,6 +101,52 @@ def test_streaming_windows_match_serial_loop(oracle, native, max_window, redo_ev
     assert cls.state()["reads_committed"] == len(exp)
 
 
+@pytest.mark.parametrize("max_window,crowded", [(2, 0), (5, 0), (64, 0), (4096, 0), (64, 3)])
+def test_batched_windows_match_serial_loop(oracle, native, max_window, crowded, monkeypatch):
+    """Windows committed as batches (batch_insert / _classify / _undo / _end): the window's
+    inserts are applied before its reads are decided a second time; a read that decides
+    differently behind an earlier read of its own window takes the batch back; a silver-path
+    rollover ends a batch; a refused batch (too crowded) falls back to the classic commit."""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine, serial_reference
+
+    monkeypatch.setenv("GRP_BATCH", "force")
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    reads = _workload()
+    m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=90_000, max_paths=2)
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads, batching=True, batch_crowded_above=crowded)
+    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, target_bases=90_000, max_paths=2, silver_path=True, max_window=max_window)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    skipped = np.zeros(len(reads), dtype=np.uint32)
+    skipped[4] = 3
+    finished = cls.run(None, lens, skipped_before=skipped)
+    assert _strip(cls.commits) == exp
+    assert [c[8:10] for c in cls.commits] == [c[8:10] for c in _hits_misses(oracle, m, seeds, tile, k, reads, block)]
+    assert cls.rollovers == [2] and finished
+    assert np.array_equal(eng.mf.ids(), mf_ref.ids()) and np.array_equal(eng.mf.counts(), mf_ref.counts())
+    st = cls.state()
+    assert st["reads_committed"] == len(exp)
+    assert eng.n_batches >= 2 and st["batches"] >= 1 and st["batch_reads"] > 0
+    if max_window >= 64 and not crowded:
+        assert eng.n_batch_undone >= 1 and st["batches_undone"] == eng.n_batch_undone
+    if crowded:
+        assert eng.n_batch_refused >= 1
+
+
+def _hits_misses(oracle, m, seeds, tile, k, reads, block):
+    """hits / misses per committed read as a window-of-one classifier reports them"""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine
+
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads)
+    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=3, target_bases=90_000, max_paths=2, silver_path=True, max_window=1)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    cls.run(None, lens, skipped_before=np.zeros(len(reads), dtype=np.uint32))
+    return cls.commits
+
+
 def test_skipped_reads_advance_counter(oracle, native):
     from goldrush_amd import host
     from oracle_engine import OracleEngine

@@ -1,0 +1,147 @@
+"""GPU: a window of reads committed as ONE batch (grp_batch_insert_reads / _classify / _undo /
+_end, include/grpath.h) against the oracle's serial process_read loop — records, ID
+allocation and the miBF end state (IDs and counts of every rank), at the engine level.
+The driver below is the protocol of the header comment: decide the window against the state
+in front of it, apply its inserts at once, decide again through the log, compare in order,
+take the batch back at the first read that differs."""
+import numpy as np
+import pytest
+
+from helpers import default_seeds
+
+from goldrush_amd import native as native_mod
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(d, reads, first, tile, block, ids_inserted):
+    """the inserts the decisions `d` ask for, with the IDs the serial loop would allocate"""
+    ins, floors, firsts = [], [], []
+    for j, r in enumerate(d):
+        floors.append(ids_inserted + 1)
+        kind = int(r["kind"])
+        if kind == 2:
+            ins.append((first + j, 0, int(r["num_tiles"]), ids_inserted + 1, 0))
+            firsts.append(ids_inserted + 1)
+            ids_inserted += 1 + len(reads[first + j]) // (tile * block)
+        elif kind == 4:
+            ts, te = int(r["trim_start"]), int(r["trim_end"])
+            ins.append((first + j, ts, te + 1, ids_inserted + 1, 1))
+            firsts.append(ids_inserted + 1)
+            ids_inserted += 1 + (te - ts) // block
+        else:
+            firsts.append(0)
+    return ins, floors, firsts, ids_inserted
+
+
+def _same(a, b):
+    return int(a["kind"]) == int(b["kind"]) and int(a["num_tiles"]) == int(b["num_tiles"]) and (
+        int(a["kind"]) != 4 or (int(a["trim_start"]), int(a["trim_end"])) == (int(b["trim_start"]), int(b["trim_end"])))
+
+
+def batch_commit(eng, b, reads, tile, block, window, stats):
+    """-> [(read, kind, num_tiles, num_assigned, trim_start, trim_end, first_id)]"""
+    out = []
+    pos, ids_inserted = 0, 0
+    n = len(reads)
+
+    def record(j, r, first_id):
+        k4 = int(r["kind"]) == 4
+        out.append((j, int(r["kind"]), int(r["num_tiles"]), int(r["num_assigned"]), int(r["trim_start"]) if k4 else 0, int(r["trim_end"]) if k4 else 0, first_id))
+
+    shrink = 0
+    while pos < n:
+        cnt = max(1, min(window >> shrink, n - pos))
+        shrink = 0
+        d0 = eng.classify_reads(b, pos, cnt)
+        ins, floors, firsts, ids_end = _plan(d0, reads, pos, tile, block, ids_inserted)
+        if not ins:
+            for j in range(cnt):
+                record(pos + j, d0[j], 0)
+            pos += cnt
+            continue
+        try:
+            eng.batch_insert_reads(b, ins, block, pos)
+        except native_mod.GrpError as e:
+            # reads of the window overlap each other: too many ranks shared inside the batch;
+            # nothing was inserted — a smaller window
+            assert e.code == native_mod.GRP_ERR_NOMEM and cnt > 1
+            stats["too_crowded"] = stats.get("too_crowded", 0) + 1
+            shrink = 1
+            while (window >> shrink) >= cnt:
+                shrink += 1
+            continue
+        d1 = eng.batch_classify(b, pos, cnt, floors)
+        bad = next((j for j in range(cnt) if not _same(d0[j], d1[j])), None)
+        stats["batches"] += 1
+        if bad is None:
+            eng.batch_end()
+            for j in range(cnt):
+                record(pos + j, d1[j], firsts[j])
+            ids_inserted = ids_end
+            pos += cnt
+            continue
+        # the batch was not the serial loop from read `bad` on: take it back, insert the
+        # reads in front of it again, commit `bad` by its second decision (taken against the
+        # state in front of its own insert, the reads in front of it being confirmed)
+        stats["undone"] += 1
+        eng.batch_undo(floors[0])
+        _, _, firsts1, _ = _plan(d1[: bad + 1], reads, pos, tile, block, ids_inserted)
+        ins1, _, _, ids_inserted = _plan(d1[: bad + 1], reads, pos, tile, block, ids_inserted)
+        for (ri, ts, te, fid, off) in ins1:
+            eng.insert_read(b, ri, ts, te, block, fid, off)
+        for j in range(bad + 1):
+            record(pos + j, d1[j], firsts1[j])
+        pos += bad + 1
+    return out
+
+
+def _run(oracle, native, reads, tile, k, h, m, block, window, key):
+    from oracle_engine import cached_serial_reference
+
+    seeds = default_seeds(h)
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    eng.finalize()
+    exp, ref_ids, ref_counts, _ = cached_serial_reference(key, oracle, m, seeds, tile, k, reads, block=block)
+    stats = {"batches": 0, "undone": 0}
+    got = batch_commit(eng, b, reads, tile, block, window, stats)
+    assert got == [e[:7] for e in exp]
+    ids, counts = eng.export_ids()
+    assert np.array_equal(counts, ref_counts)
+    assert np.array_equal(ids, ref_ids)
+    eng.close()
+    return stats, exp
+
+
+@pytest.mark.parametrize("window", [2, 7, 32, 200])
+def test_batches_equal_the_serial_loop(oracle, native, window):
+    """A genome covered ~5x: the first reads insert, later ones are assigned or trimmed, so
+    windows mix confirmed batches and batches taken back (a read that overlaps an earlier
+    read of its own window decides differently once that read is in the filter)."""
+    from goldrush_amd import synth
+
+    tile, k, h, block = 500, 22, 3, 4
+    g = synth.random_genome(150_000, 21)
+    reads = [r[1] for r in synth.make_reads(g, 140, mean_len=5000, min_len=3500, seed=22, max_len=9000)]
+    m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
+    stats, exp = _run(oracle, native, reads, tile, k, h, m, block, window, "loop_basic")
+    assert stats["batches"] > 0
+    if window >= 7:
+        assert stats["undone"] > 0  # the take-back path ran
+    assert {e[1] for e in exp} >= {2, 3, 5}
+
+
+def test_batches_on_a_small_crowded_filter(oracle, native):
+    """A filter far too small for its reads (occupancy ~0.5, most ranks shared by many tiles):
+    ranks written by several reads and blocks of one batch, overwrites of non-zero IDs, the
+    overflow table — the log has to restore all of it."""
+    from goldrush_amd import synth
+
+    tile, k, h, block = 250, 22, 3, 2
+    g = synth.random_genome(400_000, 5)
+    reads = [r[1] for r in synth.make_reads(g, 60, mean_len=4000, min_len=1500, seed=6, max_len=8000)]
+    m = 1 << 19
+    stats, exp = _run(oracle, native, reads, tile, k, h, m, block, 16, "batch_crowded")
+    assert stats["batches"] > 0

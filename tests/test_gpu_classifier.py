@@ -15,16 +15,17 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("max_window,mode", [(1, "auto"), (5, "auto"), (4096, "auto"), (4096, "loop"), (4096, "stream"), (48, "stream"), (4096, "pipeline"), (4096, "sync"),
-                                             (1, "windows"), (4096, "windows")])
+                                             (1, "windows"), (4096, "windows"), (4096, "batch"), (6, "batch")])
 def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, monkeypatch):
     from goldrush_amd import host, synth
     from oracle_engine import cached_serial_reference
 
     # auto: the product's own choice (device-side commit loop while inserts are frequent, windows after);
     # loop: commit loop only; the others: windows only, one form forced
-    env = {"auto": {}, "loop": {"GRP_LOOP": "force"}, "windows": {"GRP_LOOP": "off"}, "stream": {"GRP_LOOP": "off", "GRP_STREAM": "force"},
-           "pipeline": {"GRP_LOOP": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "force"},
-           "sync": {"GRP_LOOP": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "off"}}[mode]
+    env = {"auto": {}, "loop": {"GRP_LOOP": "force"}, "windows": {"GRP_LOOP": "off", "GRP_BATCH": "off"}, "stream": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "force"},
+           "pipeline": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "force"},
+           "sync": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "off"},
+           "batch": {"GRP_BATCH": "force"}}[mode]
     for key, val in env.items():
         monkeypatch.setenv(key, val)
     tile, k, h, block = 500, 22, 3, 4
@@ -47,6 +48,8 @@ def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, mo
     assert np.array_equal(ids, ref_ids) and np.array_equal(counts, ref_counts)
     st = cls.state()
     assert st["reads_committed"] == len(exp) and st["inserts"] == sum(1 for e in exp if e[1] in (2, 4))
+    if mode == "batch":
+        assert st["batches"] >= 2 and st["batch_reads"] > 0
 
 
 def test_golden_fixture_through_cli(native, tmp_path):
@@ -282,7 +285,7 @@ def test_long_reads_small_tiles_all_decision_paths(oracle, native, mode, monkeyp
     from goldrush_amd import host, synth
     from oracle_engine import serial_reference
 
-    for key, val in ({"GRP_STREAM": "force"} if mode == "stream" else {"GRP_STREAM": "off", "GRP_PIPELINE": "force"}).items():
+    for key, val in ({"GRP_BATCH": "off", "GRP_STREAM": "force"} if mode == "stream" else {"GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "force"}).items():
         monkeypatch.setenv(key, val)
     tile, k, h, block = 100, 22, 3, 10
     seeds = default_seeds(h)
@@ -323,8 +326,9 @@ def test_full_size_streaming_equals_synchronous_windows(native, monkeypatch, h, 
     dr = native.synth_reads(n, G)
     lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
     results = []
-    for mode in ({"GRP_STREAM": "force"}, {"GRP_STREAM": "off", "GRP_PIPELINE": "force"}, {"GRP_STREAM": "off", "GRP_PIPELINE": "off"}):
-        for key in ("GRP_STREAM", "GRP_PIPELINE"):
+    # the first run also commits its insert-heavy start as batches (the product's default), the others are classic windows only
+    for mode in ({"GRP_STREAM": "force"}, {"GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "force"}, {"GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "off"}):
+        for key in ("GRP_STREAM", "GRP_PIPELINE", "GRP_BATCH"):
             monkeypatch.delenv(key, raising=False)
         for key, val in mode.items():
             monkeypatch.setenv(key, val)
@@ -365,8 +369,9 @@ def test_c1_stream_streaming_equals_synchronous_windows(native, monkeypatch):
     dr = native.synth_reads(n, G)
     lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
     results = []
-    for mode in ({"GRP_STREAM": "force"}, {"GRP_STREAM": "off", "GRP_PIPELINE": "off"}):
-        for key in ("GRP_STREAM", "GRP_PIPELINE", "GRP_LOOP"):
+    # batches + streaming windows (the product's default) against classic synchronous windows
+    for mode in ({"GRP_STREAM": "force"}, {"GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "off"}):
+        for key in ("GRP_STREAM", "GRP_PIPELINE", "GRP_LOOP", "GRP_BATCH"):
             monkeypatch.delenv(key, raising=False)
         for key, val in mode.items():
             monkeypatch.setenv(key, val)
