@@ -443,8 +443,9 @@ def main():
             s1 = cls.state()
             slices.append((s1["reads_committed"] - s0["reads_committed"], te - ts, s1["inserts"] - s0["inserts"]))
             if a.trace and rank == 0:
-                sys.stderr.write("reads %d..%d: %.2f ms windows=%d queried=%d inserts=%d\n" % (
-                    first + done, first + done + n, (te - ts) * 1e3, s1["windows"] - s0["windows"], s1["reads_queried"] - s0["reads_queried"], s1["inserts"] - s0["inserts"]))
+                sys.stderr.write("reads %d..%d: %.2f ms windows=%d queried=%d inserts=%d batches=%d undone=%d batch_reads=%d\n" % (
+                    first + done, first + done + n, (te - ts) * 1e3, s1["windows"] - s0["windows"], s1["reads_queried"] - s0["reads_queried"], s1["inserts"] - s0["inserts"],
+                    s1["batches"] - s0["batches"], s1["batches_undone"] - s0["batches_undone"], s1["batch_reads"] - s0["batch_reads"]))
             done += n
 
     if a.no_kernel_timing:
@@ -561,7 +562,7 @@ def main():
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors OR-merged as reduce-scatter (all-to-all + OR) + all-gather" % world, "synth_s": t_synth,
                     "read_batches": rs.n_batches, "synth_in_timed_region_s": rs.synth_s - synth_before,
                     "warmup_s": t_warm, "warmup_mode": "%d steps of 512 reads on a throw-away engine (G=2e6)" % a.warmup,
-                    "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit")},
+                    "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit", "batches", "batches_undone", "batch_reads")},
                     "query_Gprobes_per_s": gprobes,
                     "query_kernel_s": kq_s, "decide_kernel_s": ks["decide"]["ms"] * 1e-3, "decide_launches": ks["decide"]["launches"],
                     "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],

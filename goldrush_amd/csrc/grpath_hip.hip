@@ -102,22 +102,30 @@ struct BatchRun
 {
   bool active = false;
   uint32_t n_ins = 0, block_tiles = 0;
-  uint64_t n_units = 0, n_probes = 0;
-  uint32_t h_counters[4] = { 0, 0, 0, 0 }; // owner records, overflow touches, log entries, error
+  uint64_t n_units = 0, n_rec = 0;
+  uint32_t h_counters[4] = { 0, 0, 0, 0 }; // -, chained touches, log entries, error
+  std::vector<uint32_t> h_ins;    // [n_ins][6]: read, tile_start, tile_end, first_id, id_offset, first unit
   uint32_t* d_counters = nullptr;
-  uint32_t* d_ins = nullptr;      // [n_ins][6]: read, tile_start, tile_end, first_id, id_offset, first unit
+  uint32_t* d_ins = nullptr;
   uint64_t ins_cap = 0;
-  uint32_t* d_rec_slot = nullptr; // owner records
+  unsigned long long* d_keys = nullptr; // collect: rank -> owner's record (zeroed behind every collect pass)
+  uint64_t tab_cap = 0, cur_cap = 0;    // allocated slots / slots the current batch uses (both tables)
+  unsigned long long* d_rec_key = nullptr; // records, one per (frame, seed) of the inserted tiles
   unsigned long long* d_rec_loc = nullptr;
+  unsigned long long* d_rec_old = nullptr;
+  uint32_t* d_rec_chain = nullptr;
   uint64_t rec_cap = 0;
-  uint32_t* d_ovf_slot = nullptr; // touches of a rank that somebody else owns
+  uint32_t* d_ovf_next = nullptr; // touches of a rank by other (read, block)s than its owner's, chained per record
   uint32_t* d_ovf_jb = nullptr;
+  uint64_t ovf_cap = 0;
   unsigned long long* d_log_keys = nullptr;
   uint32_t* d_log_head = nullptr;
+  uint32_t* d_log_bits = nullptr; // 1 bit per log table slot: something was logged with this home slot
   uint64_t log_tab_cap = 0;
   uint32_t* d_log_old = nullptr;
   uint32_t* d_log_writer = nullptr;
   uint32_t* d_log_next = nullptr;
+  uint32_t* d_log_slot = nullptr; // log entry -> its slot in the log table (to clean it)
   uint64_t log_cap = 0;
   uint32_t* d_floor = nullptr;    // grp_batch_classify: per read of the window
   uint64_t floor_cap = 0;
@@ -780,15 +788,20 @@ grp_destroy(grp_ctx* c)
     BatchRun& b = c->batch;
     (void)hipFree(b.d_counters);
     (void)hipFree(b.d_ins);
-    (void)hipFree(b.d_rec_slot);
+    (void)hipFree(b.d_keys);
+    (void)hipFree(b.d_rec_key);
     (void)hipFree(b.d_rec_loc);
-    (void)hipFree(b.d_ovf_slot);
+    (void)hipFree(b.d_rec_old);
+    (void)hipFree(b.d_rec_chain);
+    (void)hipFree(b.d_ovf_next);
     (void)hipFree(b.d_ovf_jb);
     (void)hipFree(b.d_log_keys);
     (void)hipFree(b.d_log_head);
+    (void)hipFree(b.d_log_bits);
     (void)hipFree(b.d_log_old);
     (void)hipFree(b.d_log_writer);
     (void)hipFree(b.d_log_next);
+    (void)hipFree(b.d_log_slot);
     (void)hipFree(b.d_floor);
   }
   (void)hipFree(c->d_ntc);

@@ -777,6 +777,49 @@ Classifier::want_batch() const
   return p_insert_ >= (in_batch_ ? p_out : p_in);
 }
 
+// The size of the next batch.  A read decides differently in a batch when it overlaps an
+// earlier read of the same batch: the chance that read x is the first one grows with x, hazard
+// c * x, so a batch of B reads is confirmed with probability exp(-c B^2 / 2).  c is estimated from
+// what the batches did (first differing reads over pairs of reads exposed, both decaying); B
+// maximises reads committed per unit of time, a batch costing a fixed part (launches, waits:
+// worth ~70 reads, measured) plus its reads, and a batch taken back its undo pass on top.
+void
+Classifier::batch_feedback(uint32_t reads, uint32_t bad)
+{
+  const bool failed = bad < reads;
+  const double x = failed ? bad + 1.0 : (double)reads;
+  bf_fail_ = 0.98 * bf_fail_ + (failed ? 1.0 : 0.0);
+  bf_expo_ = 0.98 * bf_expo_ + 0.5 * x * x;
+  static const uint32_t fixed = [] { // developer hook: a fixed batch size
+    const char* e = getenv("GRP_BATCH_READS");
+    return e ? (uint32_t)std::max(2l, atol(e)) : 0u;
+  }();
+  if (fixed) {
+    batch_reads_ = fixed;
+    return;
+  }
+  const double c = std::max(bf_fail_, 0.05) / bf_expo_;
+  const double fixed_cost = 70.0;
+  double best_rate = 0.0, area = 0.0, prev = 0.0;
+  uint32_t best = 8;
+  for (double b = 8.0; b <= 8192.0; b *= 1.125) {
+    // area = integral of the survival function up to b = expected reads confirmed
+    const int steps = 8;
+    for (int i = 0; i < steps; ++i) {
+      const double t = prev + (b - prev) * (i + 0.5) / steps;
+      area += std::exp(-0.5 * c * t * t) * (b - prev) / steps;
+    }
+    prev = b;
+    const double p_fail = 1.0 - std::exp(-0.5 * c * b * b);
+    const double rate = (area + p_fail) / (fixed_cost + b * (1.0 + 0.35 * p_fail));
+    if (rate > best_rate) {
+      best_rate = rate;
+      best = (uint32_t)b;
+    }
+  }
+  batch_reads_ = best;
+}
+
 int
 Classifier::batch_round(uint32_t& pos)
 {
@@ -871,8 +914,7 @@ Classifier::batch_round(uint32_t& pos)
   }
   rc = vt_.batch_insert(ctx_, rg_.reads, bins_.data(), (uint32_t)bins_.size(), block, base_ + pos);
   if (rc == GRP_ERR_NOMEM) {
-    // the window's reads share too many ranks (they overlap each other): a smaller batch next time
-    batch_reads_ = std::max<uint32_t>(2, cnt / 2);
+    batch_reads_ = std::max<uint32_t>(2, cnt / 2); // more records than a batch holds
     rc = GRP_OK;
     return commit_classic(first_ins + 1);
   }
@@ -881,8 +923,15 @@ Classifier::batch_round(uint32_t& pos)
   }
   bdec1_.resize(cnt);
   rc = vt_.batch_classify(ctx_, rg_.reads, base_ + pos, cnt, &dp, bfloor_.data(), bdec1_.data());
+  if (rc == GRP_ERR_NOMEM) {
+    // found on the device: the window's reads share too many ranks (they overlap each other);
+    // nothing was inserted, the batch is over — a smaller one next time
+    batch_reads_ = std::max<uint32_t>(2, cnt / 2);
+    rc = GRP_OK;
+    return commit_classic(first_ins + 1);
+  }
   if (rc != GRP_OK) {
-    (void)vt_.batch_undo(ctx_, bfloor_[0]);
+    (void)vt_.batch_undo(ctx_, base_ + pos, bfloor_[0]);
     return fail("batch_classify", rc);
   }
   n_queried_ += cnt;
@@ -895,43 +944,22 @@ Classifier::batch_round(uint32_t& pos)
       break;
     }
   }
-  uint32_t confirmed = cnt;
+  const uint32_t confirmed = bad;
   if (bad == cnt) {
     rc = vt_.batch_end(ctx_);
     if (rc != GRP_OK) {
       return fail("batch_end", rc);
     }
-    batch_reads_ = std::min<uint32_t>(max_batch, batch_reads_ + batch_reads_ / 2 + 1);
   } else {
-    // from read `bad` on the batch was not the serial loop: take it back and apply the
-    // confirmed inserts in front of `bad` again
+    // from read `bad` on the batch was not the serial loop: its insert and the ones behind it are
+    // taken back, the confirmed ones in front of it stay
     ++n_batch_undone_;
-    batch_reads_ = std::max<uint32_t>(2, std::min(batch_reads_, cnt) / 2);
-    rc = vt_.batch_undo(ctx_, bfloor_[0]);
+    rc = vt_.batch_undo(ctx_, base_ + pos + bad, bfloor_[bad]);
     if (rc != GRP_OK) {
       return fail("batch_undo", rc);
     }
-    uint32_t n_pre = 0;
-    while (n_pre < bins_.size() && bins_[n_pre].read < base_ + pos + bad) {
-      ++n_pre;
-    }
-    confirmed = bad;
-    if (n_pre >= 2) {
-      rc = vt_.batch_insert(ctx_, rg_.reads, bins_.data(), n_pre, block, base_ + pos);
-      if (rc == GRP_OK) {
-        rc = vt_.batch_end(ctx_);
-      }
-      if (rc != GRP_OK) {
-        return fail("batch_insert (confirmed part)", rc);
-      }
-    } else if (n_pre == 1) {
-      const grp_batch_insert& e = bins_[0];
-      rc = vt_.insert_read(ctx_, rg_.reads, e.read, e.tile_start, e.tile_end, block, e.first_id, e.id_offset);
-      if (rc != GRP_OK) {
-        return fail("insert_read", rc);
-      }
-    }
   }
+  batch_feedback(cnt, bad);
   // the second decisions are the records (hits / misses against the state in front of each read)
   for (uint32_t j = 0; j < confirmed && rc == GRP_OK && !finished_; ++j) {
     (void)commit_one(pos + j, bdec1_[j], rc, bfirst_[j] != 0, bfirst_[j]);

@@ -75,6 +75,7 @@ private:
   bool can_batch() const;
   bool want_batch() const; // the insert rate calls for windows committed as batches
   int batch_round(uint32_t& pos);
+  void batch_feedback(uint32_t reads, uint32_t bad);
   void drop_streams();
   int stream_decision(uint32_t j, gr_read_decision& d);
   int stream_round(uint32_t& pos);
@@ -112,7 +113,8 @@ private:
   uint64_t n_loops_ = 0, n_loop_reads_ = 0;
   bool in_batch_ = false;        // the last round was a batch (hysteresis)
   bool batch_bypass_ = false;    // the read in front cannot be part of a batch: one classic round
-  uint32_t batch_reads_ = 64;    // reads per batch: grows while batches are confirmed, halves when one is taken back
+  uint32_t batch_reads_ = 128;   // reads per batch, chosen by batch_feedback
+  double bf_fail_ = 1.0, bf_expo_ = 5e4; // first reads that decided differently / pairs of reads exposed (decaying sums)
   uint64_t n_batches_ = 0, n_batch_undone_ = 0, n_batch_reads_ = 0;
   double p_redo_ = 0.0;          // streaming records handed back to the synchronous path (EMA over ~64 reads)
   double avg_probes_per_read_ = 75000.0;

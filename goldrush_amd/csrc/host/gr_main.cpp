@@ -46,7 +46,7 @@ hip_engine()
   vt.batch_classify = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, const uint32_t* id_floor, grp_read_decision* out) {
     return grp_batch_classify(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, id_floor, out);
   };
-  vt.batch_undo = [](void* c, uint32_t id_floor) { return grp_batch_undo(static_cast<grp_ctx*>(c), id_floor); };
+  vt.batch_undo = [](void* c, uint32_t from_read, uint32_t id_floor) { return grp_batch_undo(static_cast<grp_ctx*>(c), from_read, id_floor); };
   vt.batch_end = [](void* c) { return grp_batch_end(static_cast<grp_ctx*>(c)); };
   vt.ntcard_begin = [](void* c, uint32_t sbits) { return grp_ntcard_begin(static_cast<grp_ctx*>(c), sbits); };
   vt.ntcard_add = [](void* c, const void* r, uint32_t first, uint32_t count, const uint32_t* extra) {

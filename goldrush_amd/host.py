@@ -70,7 +70,7 @@ VT_TYPES = [
     ("loop_end", C.CFUNCTYPE(C.c_int, _vp, _vp)),
     ("batch_insert", C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32)),
     ("batch_classify", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp)),
-    ("batch_undo", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
+    ("batch_undo", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, C.c_uint32)),
     ("batch_end", C.CFUNCTYPE(C.c_int, _vp)),
     ("ntcard_begin", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("ntcard_add", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp)),

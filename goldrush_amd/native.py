@@ -111,7 +111,7 @@ SIGNATURES = {
     "grp_commit_loop_end": (C.c_int, [_vp, C.POINTER(grp_loop_result)]),
     "grp_batch_insert_reads": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_batch_classify": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp, _vp]),
-    "grp_batch_undo": (C.c_int, [_vp, C.c_uint32]),
+    "grp_batch_undo": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "grp_batch_end": (C.c_int, [_vp]),
     "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_insert_read": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -485,8 +485,9 @@ class Engine:
         self._check(self.lib.grp_batch_classify(self._h, batch._h, first, count, C.byref(dp), _ptr(fl), _ptr(out)))
         return out
 
-    def batch_undo(self, id_floor: int):
-        self._check(self.lib.grp_batch_undo(self._h, id_floor))
+    def batch_undo(self, from_read: int, id_floor: int):
+        """takes back the inserts of reads >= from_read (batch index); id_floor = the first ID read from_read could allocate"""
+        self._check(self.lib.grp_batch_undo(self._h, from_read, id_floor))
 
     def batch_end(self):
         self._check(self.lib.grp_batch_end(self._h))

@@ -453,12 +453,15 @@ int grp_insert_read(grp_ctx* ctx,
  *      value it replaced) — hits / misses included;
  *   4. compares in order: while kind / trim range agree, the batch WAS the serial loop and the
  *      second set of decisions are the records.  At the first read that differs: grp_batch_undo
- *      (id_floor of the window's first read), insert the reads in front of it again, commit that
- *      read through grp_insert_read, continue behind it;
+ *      (that read's batch index and id_floor) takes back its insert and those of the reads behind
+ *      it and ends the batch — the filter is in the state in front of that read, whose second
+ *      decision was taken against exactly this state: commit it through grp_insert_read and
+ *      continue behind it;
  *   5. grp_batch_end drops the log (no-op after grp_batch_undo).
  * One batch at a time; nothing else may query or insert between _insert_reads and _end / _undo.
- * GRP_ERR_NOMEM from _insert_reads: too many ranks are shared by several ID blocks of the batch —
- * nothing was inserted, use a smaller window.
+ * GRP_ERR_NOMEM (from _insert_reads, or — found on the device — from _classify / _end): the batch
+ * is too large or too many ranks are shared by several ID blocks of it; nothing was inserted, the
+ * batch is over: use a smaller window.
  */
 typedef struct
 {
@@ -471,7 +474,7 @@ typedef struct
 
 int grp_batch_insert_reads(grp_ctx* ctx, const grp_reads* reads, const grp_batch_insert* inserts, uint32_t n_inserts, uint32_t block_tiles, uint32_t first_read);
 int grp_batch_classify(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, const uint32_t* id_floor, grp_read_decision* decisions_out);
-int grp_batch_undo(grp_ctx* ctx, uint32_t id_floor);
+int grp_batch_undo(grp_ctx* ctx, uint32_t from_read, uint32_t id_floor);
 int grp_batch_end(grp_ctx* ctx);
 
 /*

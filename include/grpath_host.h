@@ -51,7 +51,7 @@ typedef struct
   /* optional (all four or none): a window of reads committed as one batch, grp_batch_* */
   int (*batch_insert)(void* ctx, const void* reads, const grp_batch_insert* inserts, uint32_t n_inserts, uint32_t block_tiles, uint32_t first_read);
   int (*batch_classify)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, const uint32_t* id_floor, grp_read_decision* out);
-  int (*batch_undo)(void* ctx, uint32_t id_floor);
+  int (*batch_undo)(void* ctx, uint32_t from_read, uint32_t id_floor);
   int (*batch_end)(void* ctx);
   /* optional (all four or none): --ntcard on the device, grp_ntcard_* / grp_set_filter_size */
   int (*ntcard_begin)(void* ctx, uint32_t sbits);

@@ -204,9 +204,14 @@ class OracleEngine:
                     insert_read(ctx, reads, int(e[0]), int(e[1]), int(e[2]), bt["block"], int(e[3]), int(e[4]))
             return 0
 
-        def batch_undo(ctx, floor_id):
-            assert bt and floor_id == int(bt["ins"][0][3])
+        def batch_undo(ctx, from_read, floor_id):
+            assert bt and from_read >= bt["first"]
+            later = [e for e in bt["ins"] if int(e[0]) >= from_read]
+            assert not later or floor_id <= int(later[0][3])
             _batch_restore()
+            for e in bt["ins"]:  # the inserts in front of from_read stay
+                if int(e[0]) < from_read:
+                    insert_read(ctx, None, int(e[0]), int(e[1]), int(e[2]), bt["block"], int(e[3]), int(e[4]))
             bt.clear()
             self.n_batch_undone += 1
             return 0

@@ -3,7 +3,7 @@ _end, include/grpath.h) against the oracle's serial process_read loop — record
 allocation and the miBF end state (IDs and counts of every rank), at the engine level.
 The driver below is the protocol of the header comment: decide the window against the state
 in front of it, apply its inserts at once, decide again through the log, compare in order,
-take the batch back at the first read that differs."""
+take back the inserts from the first read that differs on."""
 import numpy as np
 import pytest
 
@@ -81,14 +81,14 @@ def batch_commit(eng, b, reads, tile, block, window, stats):
             ids_inserted = ids_end
             pos += cnt
             continue
-        # the batch was not the serial loop from read `bad` on: take it back, insert the
-        # reads in front of it again, commit `bad` by its second decision (taken against the
-        # state in front of its own insert, the reads in front of it being confirmed)
+        # the batch was not the serial loop from read `bad` on: its insert and the ones behind it
+        # are taken back; `bad` is committed by its second decision (taken against the state in
+        # front of its own insert, the reads in front of it being confirmed)
         stats["undone"] += 1
-        eng.batch_undo(floors[0])
-        _, _, firsts1, _ = _plan(d1[: bad + 1], reads, pos, tile, block, ids_inserted)
-        ins1, _, _, ids_inserted = _plan(d1[: bad + 1], reads, pos, tile, block, ids_inserted)
-        for (ri, ts, te, fid, off) in ins1:
+        eng.batch_undo(pos + bad, floors[bad])
+        ins1, _, firsts1, ids_inserted = _plan(d1[: bad + 1], reads, pos, tile, block, ids_inserted)
+        if ins1 and ins1[-1][0] == pos + bad:
+            ri, ts, te, fid, off = ins1[-1]
             eng.insert_read(b, ri, ts, te, block, fid, off)
         for j in range(bad + 1):
             record(pos + j, d1[j], firsts1[j])
