@@ -482,6 +482,7 @@ Classifier::silver_path_check(int& rc)
       rollover_cb_(user_, curr_path_);
     }
     ids_inserted_ = 0;
+    last_insert_shares_id_ = false;
   }
 }
 
@@ -554,6 +555,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
         }
       }
       ids_inserted_ = ids_inserted_ + (uint32_t)(len / ((size_t)tile * block));
+      last_insert_shares_id_ = false;
       const double ph = commit_cb_ ? commit_cb_(user_, &ev) : 0.0;
       inserted_bases_ += len;
       ++num_reads_in_path_;
@@ -587,6 +589,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
         }
       }
       ids_inserted_ = ids_inserted_ + (uint32_t)((te - ts) / block);
+      last_insert_shares_id_ = (te - ts + 1) % block == 0; // its last block holds ID ids_inserted_ + 1, the next insert's first
       // new_seq = seq.substr(ts*tile, te == nt-1 ? npos : (te-ts+1)*tile)
       const uint64_t off = (uint64_t)ts * tile;
       uint64_t n_out = len - off;
@@ -764,32 +767,33 @@ Classifier::want_batch() const
   if (e && !strcmp(e, "force")) {
     return true;
   }
-  // a batch costs two queries per read whatever the insert rate; a classic round costs one
-  // query per read plus ~80 us per insert: the batch wins above ~5 % inserting reads
+  // a batch costs two queries per read whatever the insert rate (~4.5 us on C2); the classic
+  // windows cost one query per read plus ~80-400 us per insert: measured on C2 (bench.py --trace)
+  // the batch wins down to ~1 % inserting reads
   static const double p_in = [] {
     const char* v = getenv("GRP_BATCH_ENTER");
-    return v ? atof(v) : 0.10;
+    return v ? atof(v) : 0.012;
   }();
   static const double p_out = [] {
     const char* v = getenv("GRP_BATCH_LEAVE");
-    return v ? atof(v) : 0.05;
+    return v ? atof(v) : 0.007;
   }();
-  return p_insert_ >= (in_batch_ ? p_out : p_in);
+  return p_insert_mid_ >= (in_batch_ ? p_out : p_in);
 }
 
-// The size of the next batch.  A read decides differently in a batch when it overlaps an
-// earlier read of the same batch: the chance that read x is the first one grows with x, hazard
-// c * x, so a batch of B reads is confirmed with probability exp(-c B^2 / 2).  c is estimated from
-// what the batches did (first differing reads over pairs of reads exposed, both decaying); B
-// maximises reads committed per unit of time, a batch costing a fixed part (launches, waits:
-// worth ~70 reads, measured) plus its reads, and a batch taken back its undo pass on top.
+// The size of the next batch.  A read decides differently in a batch when it overlaps a read
+// INSERTED in front of it in the same batch: with a fraction p of inserting reads the chance that
+// read x is the first one grows like c * p * x, so a batch of B reads is confirmed with
+// probability exp(-c p B^2 / 2).  c is estimated from what the batches did (first differing
+// reads over (inserted read, later read) pairs exposed, both decaying); B maximises reads
+// committed per unit of time, a batch costing a fixed part (launches, waits: worth ~70 reads,
+// measured) plus its reads, and a batch taken back its undo pass on top.
 void
-Classifier::batch_feedback(uint32_t reads, uint32_t bad)
+Classifier::batch_feedback(uint32_t reads, uint32_t bad, double exposure)
 {
   const bool failed = bad < reads;
-  const double x = failed ? bad + 1.0 : (double)reads;
   bf_fail_ = 0.98 * bf_fail_ + (failed ? 1.0 : 0.0);
-  bf_expo_ = 0.98 * bf_expo_ + 0.5 * x * x;
+  bf_expo_ = 0.98 * bf_expo_ + exposure;
   static const uint32_t fixed = [] { // developer hook: a fixed batch size
     const char* e = getenv("GRP_BATCH_READS");
     return e ? (uint32_t)std::max(2l, atol(e)) : 0u;
@@ -798,11 +802,12 @@ Classifier::batch_feedback(uint32_t reads, uint32_t bad)
     batch_reads_ = fixed;
     return;
   }
-  const double c = std::max(bf_fail_, 0.05) / bf_expo_;
+  const double p = std::min(1.0, std::max(p_insert_mid_, 1e-3));
+  const double c = std::max(bf_fail_, 0.05) / std::max(bf_expo_, 1.0) * p;
   const double fixed_cost = 70.0;
   double best_rate = 0.0, area = 0.0, prev = 0.0;
   uint32_t best = 8;
-  for (double b = 8.0; b <= 8192.0; b *= 1.125) {
+  for (double b = 8.0; b <= 16384.0; b *= 1.125) {
     // area = integral of the survival function up to b = expected reads confirmed
     const int steps = 8;
     for (int i = 0; i < steps; ++i) {
@@ -851,10 +856,12 @@ Classifier::batch_round(uint32_t& pos)
   uint32_t ids = ids_inserted_;
   uint64_t bases = inserted_bases_;
   uint32_t cnt = B, first_ins = UINT32_MAX;
+  // the last insert so far was a trimmed read whose last ID block carries the next first ID (:1048-1049, :1074)
+  bool shared_id = last_insert_shares_id_;
   for (uint32_t j = 0; j < B; ++j) {
     const gr_read_decision& d = bdec0_[j];
     const uint32_t len = rg_.lens[pos + j];
-    bfloor_[j] = ids + 1;
+    bfloor_[j] = (ids + 1) | (shared_id ? 0x80000000u : 0u);
     bool ins = false;
     uint32_t ts = 0, te_excl = 0, off = 0, next_ids = ids;
     if (d.kind == DEC_INSERT_WHOLE) {
@@ -885,6 +892,7 @@ Classifier::batch_round(uint32_t& pos)
       bins_.push_back(grp_batch_insert{ base_ + pos + j, ts, te_excl, ids + 1, off });
       bfirst_[j] = ids + 1;
       ids = next_ids;
+      shared_id = off == 1 && (te_excl - ts) % block == 0;
       if (first_ins == UINT32_MAX) {
         first_ins = j;
       }
@@ -931,7 +939,7 @@ Classifier::batch_round(uint32_t& pos)
     return commit_classic(first_ins + 1);
   }
   if (rc != GRP_OK) {
-    (void)vt_.batch_undo(ctx_, base_ + pos, bfloor_[0]);
+    (void)vt_.batch_undo(ctx_, base_ + pos, bfloor_[0] & 0x7FFFFFFFu);
     return fail("batch_classify", rc);
   }
   n_queried_ += cnt;
@@ -954,12 +962,25 @@ Classifier::batch_round(uint32_t& pos)
     // from read `bad` on the batch was not the serial loop: its insert and the ones behind it are
     // taken back, the confirmed ones in front of it stay
     ++n_batch_undone_;
-    rc = vt_.batch_undo(ctx_, base_ + pos + bad, bfloor_[bad]);
+    rc = vt_.batch_undo(ctx_, base_ + pos + bad, bfloor_[bad] & 0x7FFFFFFFu);
     if (rc != GRP_OK) {
       return fail("batch_undo", rc);
     }
   }
-  batch_feedback(cnt, bad);
+  {
+    // (inserted read, later read) pairs that had the chance to differ
+    double exposure = 0.0;
+    uint32_t seen = 0, k = 0;
+    const uint32_t upto = bad < cnt ? bad + 1 : cnt;
+    for (uint32_t j = 0; j < upto; ++j) {
+      exposure += seen;
+      if (k < bins_.size() && bins_[k].read == base_ + pos + j) {
+        ++seen;
+        ++k;
+      }
+    }
+    batch_feedback(cnt, bad, exposure);
+  }
   // the second decisions are the records (hits / misses against the state in front of each read)
   for (uint32_t j = 0; j < confirmed && rc == GRP_OK && !finished_; ++j) {
     (void)commit_one(pos + j, bdec1_[j], rc, bfirst_[j] != 0, bfirst_[j]);

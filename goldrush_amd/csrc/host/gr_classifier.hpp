@@ -75,7 +75,7 @@ private:
   bool can_batch() const;
   bool want_batch() const; // the insert rate calls for windows committed as batches
   int batch_round(uint32_t& pos);
-  void batch_feedback(uint32_t reads, uint32_t bad);
+  void batch_feedback(uint32_t reads, uint32_t bad, double exposure);
   void drop_streams();
   int stream_decision(uint32_t j, gr_read_decision& d);
   int stream_round(uint32_t& pos);
@@ -111,10 +111,11 @@ private:
   bool in_loop_ = false;         // the last round ran as a commit loop (hysteresis of the choice)
   bool loop_disabled_ = false;   // a loop launch could not become resident (shared device): windows only
   uint64_t n_loops_ = 0, n_loop_reads_ = 0;
+  bool last_insert_shares_id_ = false; // the last insert was a trimmed read whose last ID block carries the next insert's first ID
   bool in_batch_ = false;        // the last round was a batch (hysteresis)
   bool batch_bypass_ = false;    // the read in front cannot be part of a batch: one classic round
   uint32_t batch_reads_ = 128;   // reads per batch, chosen by batch_feedback
-  double bf_fail_ = 1.0, bf_expo_ = 5e4; // first reads that decided differently / pairs of reads exposed (decaying sums)
+  double bf_fail_ = 1.0, bf_expo_ = 5e4; // first reads that decided differently / (inserted read, later read) pairs exposed (decaying sums)
   uint64_t n_batches_ = 0, n_batch_undone_ = 0, n_batch_reads_ = 0;
   double p_redo_ = 0.0;          // streaming records handed back to the synchronous path (EMA over ~64 reads)
   double avg_probes_per_read_ = 75000.0;

@@ -448,9 +448,13 @@ int grp_insert_read(grp_ctx* ctx,
  *      read, ascending, with the block IDs the serial loop would allocate: exactly the sequence of
  *      grp_insert_read calls) and keeps a log of what later reads of the window must not see;
  *   3. grp_batch_classify: decides the window again, every read against the state in front of ITS
- *      OWN insert — id_floor[j] = the first ID read j could allocate (IDs grow with the read order:
- *      a probe returning an ID >= id_floor[j] was written by read j or a later one; the log holds the
- *      value it replaced) — hits / misses included;
+ *      OWN insert — id_floor[j] = the first ID read j could allocate.  IDs grow with the read
+ *      order: a probe returning an ID > id_floor[j] was written by read j or a later one, an ID
+ *      equal to it by one of those or by the last ID block of the trimmed read in front
+ *      (goldrush_path.cpp:1048-1049 / :1074: when (trim_end - trim_start + 1) is a multiple of
+ *      block_tiles that block carries the next read's first ID): the caller sets bit 31 of
+ *      id_floor[j] where the last insert in front of read j — inside the batch or before it — was
+ *      such a read, and the engine then looks up who wrote the rank — hits / misses included;
  *   4. compares in order: while kind / trim range agree, the batch WAS the serial loop and the
  *      second set of decisions are the records.  At the first read that differs: grp_batch_undo
  *      (that read's batch index and id_floor) takes back its insert and those of the reads behind

@@ -200,7 +200,7 @@ class OracleEngine:
                 arr[j] = _decide(first + j, dp)
                 e = by_read.get(first + j)
                 if e is not None:
-                    assert int(e[3]) == int(floors[j])  # a read's first ID is the first one it could allocate
+                    assert int(e[3]) == int(floors[j]) & 0x7FFFFFFF  # a read's first ID is the first one it could allocate (bit 31: see grpath.h)
                     insert_read(ctx, reads, int(e[0]), int(e[1]), int(e[2]), bt["block"], int(e[3]), int(e[4]))
             return 0
 

@@ -14,24 +14,28 @@ from goldrush_amd import native as native_mod
 pytestmark = pytest.mark.gpu
 
 
-def _plan(d, reads, first, tile, block, ids_inserted):
-    """the inserts the decisions `d` ask for, with the IDs the serial loop would allocate"""
+def _plan(d, reads, first, tile, block, ids_inserted, shared=False):
+    """the inserts the decisions `d` ask for, with the IDs the serial loop would allocate;
+    shared: the last insert in front was a trimmed read whose last ID block carries the next
+    insert's first ID (bit 31 of the floors, include/grpath.h)"""
     ins, floors, firsts = [], [], []
     for j, r in enumerate(d):
-        floors.append(ids_inserted + 1)
+        floors.append((ids_inserted + 1) | (0x80000000 if shared else 0))
         kind = int(r["kind"])
         if kind == 2:
             ins.append((first + j, 0, int(r["num_tiles"]), ids_inserted + 1, 0))
             firsts.append(ids_inserted + 1)
             ids_inserted += 1 + len(reads[first + j]) // (tile * block)
+            shared = False
         elif kind == 4:
             ts, te = int(r["trim_start"]), int(r["trim_end"])
             ins.append((first + j, ts, te + 1, ids_inserted + 1, 1))
             firsts.append(ids_inserted + 1)
             ids_inserted += 1 + (te - ts) // block
+            shared = (te - ts + 1) % block == 0
         else:
             firsts.append(0)
-    return ins, floors, firsts, ids_inserted
+    return ins, floors, firsts, ids_inserted, shared
 
 
 def _same(a, b):
@@ -42,7 +46,7 @@ def _same(a, b):
 def batch_commit(eng, b, reads, tile, block, window, stats):
     """-> [(read, kind, num_tiles, num_assigned, trim_start, trim_end, first_id)]"""
     out = []
-    pos, ids_inserted = 0, 0
+    pos, ids_inserted, shared = 0, 0, False
     n = len(reads)
 
     def record(j, r, first_id):
@@ -54,7 +58,7 @@ def batch_commit(eng, b, reads, tile, block, window, stats):
         cnt = max(1, min(window >> shrink, n - pos))
         shrink = 0
         d0 = eng.classify_reads(b, pos, cnt)
-        ins, floors, firsts, ids_end = _plan(d0, reads, pos, tile, block, ids_inserted)
+        ins, floors, firsts, ids_end, shared_end = _plan(d0, reads, pos, tile, block, ids_inserted, shared)
         if not ins:
             for j in range(cnt):
                 record(pos + j, d0[j], 0)
@@ -78,15 +82,15 @@ def batch_commit(eng, b, reads, tile, block, window, stats):
             eng.batch_end()
             for j in range(cnt):
                 record(pos + j, d1[j], firsts[j])
-            ids_inserted = ids_end
+            ids_inserted, shared = ids_end, shared_end
             pos += cnt
             continue
         # the batch was not the serial loop from read `bad` on: its insert and the ones behind it
         # are taken back; `bad` is committed by its second decision (taken against the state in
         # front of its own insert, the reads in front of it being confirmed)
         stats["undone"] += 1
-        eng.batch_undo(pos + bad, floors[bad])
-        ins1, _, firsts1, ids_inserted = _plan(d1[: bad + 1], reads, pos, tile, block, ids_inserted)
+        eng.batch_undo(pos + bad, floors[bad] & 0x7FFFFFFF)
+        ins1, _, firsts1, ids_inserted, shared = _plan(d1[: bad + 1], reads, pos, tile, block, ids_inserted, shared)
         if ins1 and ins1[-1][0] == pos + bad:
             ri, ts, te, fid, off = ins1[-1]
             eng.insert_read(b, ri, ts, te, block, fid, off)
@@ -145,3 +149,63 @@ def test_batches_on_a_small_crowded_filter(oracle, native):
     m = 1 << 19
     stats, exp = _run(oracle, native, reads, tile, k, h, m, block, 16, "batch_crowded")
     assert stats["batches"] > 0
+
+
+def test_batch_of_long_reads_equals_inserts_one_by_one(native):
+    """BASELINE geometry (25 kb reads, tile 1000, block 10, a small genome so that the reads of a
+    batch share many ranks): 16 whole-read inserts as ONE batch — several hundred workgroups,
+    more than one per compute unit — leave the IDs and counts of every rank exactly as the
+    same inserts one by one (grp_insert_read, itself pinned to the oracle in test_gpu_parity);
+    the second decisions equal decisions taken between the serial inserts; taking back the
+    second half equals inserting only the first half."""
+    from goldrush_amd import host
+
+    h, n, nb = 3, 64, 16
+    k, tile, block, G = 22, 1000, 10, 8_000_000
+    seeds = default_seeds(h)
+    hl = host.load()
+    m = hl.gr_calc_optimal_size(hl.gr_hash_universe(16, G, h), 1, 0.1)
+    dr = native.synth_reads(n, G)
+    lens = np.ascontiguousarray(dr.lens, dtype=np.uint32)
+
+    def engine():
+        eng = native.Engine(k, h, tile, m, seeds)
+        rb = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+        eng.bv_insert(rb)
+        eng.finalize()
+        return eng, rb
+
+    ins, floors, ids = [], [], 0
+    for j in range(nb):
+        floors.append(ids + 1)
+        ins.append((j, 0, int(lens[j]) // tile, ids + 1, 0))
+        ids += 1 + int(lens[j]) // (tile * block)
+
+    a, ra = engine()
+    serial_dec, half_state = [], None
+    for j, (ri, ts, te, fid, off) in enumerate(ins):
+        if j == nb // 2:
+            half_state = a.export_ids()
+        serial_dec.append(a.classify_reads(ra, j, 1)[0])
+        a.insert_read(ra, ri, ts, te, block, fid, off)
+    ids_a, counts_a = a.export_ids()
+    a.close()
+
+    b, rb_ = engine()
+    b.batch_insert_reads(rb_, ins, block, 0)
+    d1 = b.batch_classify(rb_, 0, nb, floors)
+    b.batch_end()
+    ids_b, counts_b = b.export_ids()
+    b.close()
+    assert np.array_equal(ids_a, ids_b) and np.array_equal(counts_a, counts_b)
+    fields = ("kind", "num_tiles", "num_assigned", "trim_start", "trim_end", "hits", "misses")
+    assert [[int(x[f]) for f in fields] for x in serial_dec] == [[int(x[f]) for f in fields] for x in d1]
+
+    c, rc_ = engine()
+    c.batch_insert_reads(rc_, ins, block, 0)
+    c.batch_classify(rc_, 0, nb, floors)
+    c.batch_undo(nb // 2, floors[nb // 2])
+    ids_c, counts_c = c.export_ids()
+    c.close()
+    assert np.array_equal(ids_c, half_state[0]) and np.array_equal(counts_c, half_state[1])
+    dr.free()
