@@ -209,3 +209,40 @@ def test_batch_of_long_reads_equals_inserts_one_by_one(native):
     c.close()
     assert np.array_equal(ids_c, half_state[0]) and np.array_equal(counts_c, half_state[1])
     dr.free()
+
+
+@pytest.mark.parametrize("h", [3, 5])
+def test_very_long_read_inserted_whole(oracle, native, h):
+    """A 130 kb read (130 tiles of 1000: more than 256 workgroups of the collect kernels are in
+    flight at once) inserted whole by grp_insert_read and as a batch of one: IDs / counts of every
+    rank against the oracle's block-by-block inserts."""
+    from goldrush_amd import synth
+
+    tile, k, block = 1000, 22, 10
+    seeds = default_seeds(h)
+    g = synth.random_genome(400_000, 77)
+    reads = [g[1000:1000 + 130_500].tobytes(), g[200_000:200_000 + 30_000].tobytes()]
+    orc = oracle
+    m = orc.load().orc_calc_optimal_size(4_000_000, 1, 0.1)
+    mf = orc.MiBF(m, orc.Seeds(seeds), tile, k)
+    for s in reads:
+        mf.bv_insert_read(s)
+    mf.finalize()
+    nt = len(reads[0]) // tile
+    for bs in range(0, nt, block):
+        mf.insert_read_tiles(reads[0], bs, min(bs + block, nt), 1 + bs // block)
+    for variant in ("insert_read", "batch"):
+        eng = native.Engine(k, h, tile, m, seeds)
+        b = eng.upload(reads)
+        eng.bv_insert(b)
+        eng.finalize()
+        if variant == "insert_read":
+            eng.insert_read(b, 0, 0, nt, block, 1, 0)
+        else:
+            eng.batch_insert_reads(b, [(0, 0, nt, 1, 0)], block, 0)
+            eng.batch_end()
+        ids, counts = eng.export_ids()
+        assert np.array_equal(counts, mf.counts()), variant
+        assert np.array_equal(ids, mf.ids()), variant
+        eng.close()
+    mf.close()
