@@ -541,7 +541,7 @@ def main():
                            cfg["name"], " [C3: stream shared by %d GPUs]" % world if (world > 1 and a.config == "C2") else "", h,
                            "silver-path mode, %d paths (the run ends behind the last path: reads_timed = reads consumed)" % max_paths if silver else "golden-path mode"),
                        "reads": n_reads, "reads_timed": reads_done, "reads_per_step": per_step, "genome": G, "filter_bits": m, "pop": pop,
-                       "parallelism": ("one GPU, streaming windows" if world == 1 else "windows striped over %d GPUs, replicated miBF, 32-B decisions all-gathered per stripe group" % world)},
+                       "parallelism": ("one GPU: windows committed as batches where >= ~1 % of the reads insert, streaming windows elsewhere" if world == 1 else "replicated miBF on %d GPUs: batches on every rank where >= ~1 %% of the reads insert, streaming windows striped over the ranks elsewhere (32-B decisions all-gathered per stripe group)" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC pass of the same kernel, %s, scaled by probes)" % (os.path.basename(pmc_file) if pmc_file else "none"),
                          "kernel": kernel_name,

@@ -858,6 +858,10 @@ Classifier::batch_round(uint32_t& pos)
   uint32_t cnt = B, first_ins = UINT32_MAX;
   // the last insert so far was a trimmed read whose last ID block carries the next first ID (:1048-1049, :1074)
   bool shared_id = last_insert_shares_id_;
+  // a batch holds 2^26 (frame, seed) records (frames in units of 256 per tile): the window ends
+  // in front of the insert that would not fit (the engine refuses larger batches, GRP_ERR_NOMEM)
+  const uint64_t rec_per_tile = (uint64_t)((tile + 255u) / 256u) * 256u * p_.hash_num;
+  uint64_t rec = 0;
   for (uint32_t j = 0; j < B; ++j) {
     const gr_read_decision& d = bdec0_[j];
     const uint32_t len = rg_.lens[pos + j];
@@ -887,6 +891,11 @@ Classifier::batch_round(uint32_t& pos)
     if (ins) {
       if ((te_excl - ts + block - 1) / block > 256 || te_excl <= ts) {
         cnt = j; // more ID blocks than a batch entry holds
+        break;
+      }
+      rec += (uint64_t)(te_excl - ts) * rec_per_tile;
+      if (rec > (60ull << 20) && !bins_.empty()) {
+        cnt = j;
         break;
       }
       bins_.push_back(grp_batch_insert{ base_ + pos + j, ts, te_excl, ids + 1, off });

@@ -73,44 +73,6 @@ for (ri, ts, te, fid, off) in ins:
         bs += block
 ids_o, counts_o = mf.ids().copy(), mf.counts().copy()
 print("oracle vs serial: ids differ", int((ids_o != ids_a).sum()), "counts differ", int((counts_o != counts_a).sum()))
-if os.environ.get("GRP_BATCH_DUMP"):
-    raw = np.fromfile(os.environ["GRP_BATCH_DUMP"], dtype=np.uint64)
-    nrec = raw.size // 2
-    key, old = raw[:nrec], raw[nrec:]
-    rank = (key >> np.uint64(26)).astype(np.int64) - 1
-    has = (key >> np.uint64(26)) != 0
-    print("non-record codes:", dict(zip(*[x.tolist() for x in np.unique(key[~has], return_counts=True)])))
-    un = np.arange(nrec) // 768
-    if os.environ.get("GRP_BATCH_DEBUG") == "5":
-        mk = old
-        zk = key == 0
-        print("marker present overall:", int(((mk >> np.uint64(56)) == 0xAB).sum()), "of", nrec, "; on claimed:", int(((mk >> np.uint64(56)) == 0xAB)[~zk].sum()), "sample raw zero-key markers", [hex(int(x)) for x in mk[zk][:4]])
-        print("marker present on zero-key records:", int(((mk >> np.uint64(56)) == 0xAB)[zk].sum()), "of", int(zk.sum()))
-        zs2 = zk & ((np.arange(nrec) // 256) % 3 == 2) & (un >= 256)
-        m2 = mk[zs2]
-        print("seed-2 units>=256 zero-key: marker present", int(((m2 >> np.uint64(56)) == 0xAB).sum()), "valid", int(((m2 >> np.uint64(40)) & np.uint64(1)).sum()), "live", int(((m2 >> np.uint64(41)) & np.uint64(1)).sum()), "claimed", int(((m2 >> np.uint64(42)) & np.uint64(1)).sum()))
-    z = np.nonzero(key == 0)[0]
-    print("zero records per unit 250..290:", [int((un[z] == u).sum()) for u in range(250, 290)])
-    zz = z[un[z] >= 256]
-    print("zero records (units >= 256) by seed:", np.bincount((zz % 768) // 256, minlength=3), "by wave:", np.bincount((zz % 256) // 64, minlength=4), "by lane%64 head:", np.bincount(zz % 64, minlength=64)[:16])
-    print("zero records with tid >= 232 in last part / total:", int((((z % 256) >= 232) & ((un[z] % 4) == 3)).sum()), z.size)
-    print("code 1 (no set bit) per unit, units 250..275:", [int(((key == 1) & (un == u)).sum()) for u in range(250, 276)])
-    print("code 2 per unit 250..275:", [int(((key == 2) & (un == u)).sum()) for u in range(250, 276)])
-    print("code 3 per unit 250..275:", [int(((key == 3) & (un == u)).sum()) for u in range(250, 276)])
-    lost = np.nonzero((counts_o != counts_b))[0]
-    rec_of = {}
-    idxs = np.nonzero(has)[0]
-    order = np.argsort(rank[idxs])
-    sr = rank[idxs][order]
-    pos = np.searchsorted(sr, lost)
-    found = (pos < sr.size) & (sr[np.minimum(pos, sr.size - 1)] == lost)
-    print("records", nrec, "claimed", int(has.sum()), "lost ranks", lost.size, "of which have a record:", int(found.sum()))
-    fi = idxs[order][pos[found]]
-    print("  their record index // 768 (unit) histogram head:", np.unique(fi // 768, return_counts=True)[0][:20], "lane%256 sample", (fi % 256)[:20], "seed", ((fi // 256) % 3)[:20])
-    print("  rec_old of found: wrote", int((old[fi] >> np.uint64(63)).sum()), "count0 nonzero", int((((old[fi] >> np.uint64(32)) & np.uint64(0x7FFFFFFF)) != 0).sum()))
-    # duplicates: the same rank claimed twice
-    u, cnt = np.unique(rank[idxs], return_counts=True)
-    print("  ranks with more than one record:", int((cnt > 1).sum()))
 print("oracle vs batch : ids differ", int((ids_o != ids_b).sum()), "counts differ", int((counts_o != counts_b).sum()))
 
 # per tile of every inserted read: the count of the tile's top ID in both end states

@@ -1,15 +1,13 @@
 #!/bin/bash
 # Run on the GPU box (gpurun): PMC passes of the bench command, one counter group per run
 # (never combined with sys/hip/hsa tracing).   tools/pmc_round.sh <tag>
-# C2 geometry (G = 3e9: 65 GB of buckets, W = 60), 2 M reads; the insert-heavy head goes
-# through the commit loop down to an insert rate of 1 % (GRP_LOOP=on with low thresholds: a
-# handful of launches instead of ~500 k latency windows, which a counter pass would
-# serialise), so the query counters are those of the streaming windows of the steady state.
+# C2 geometry (G = 3e9: 65 GB of buckets, W = 60), 2 M reads: the insert-heavy head runs as
+# batches (a few thousand launches), the rest as streaming windows; the summary keeps the
+# k_query dispatches.
 tag=${1:-rXX}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-export GRP_LOOP=on GRP_LOOP_ENTER=0.02 GRP_LOOP_LEAVE=0.01
 args="--no-cpu-baseline --steps 4 --warmup 0 --reads 2000000"
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $out/${tag}_pmcA -o a -- python3 bench.py $args > $out/${tag}_pmcA_bench.json 2> $out/${tag}_pmcA.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmcB -o b -- python3 bench.py $args > $out/${tag}_pmcB_bench.json 2> $out/${tag}_pmcB.err

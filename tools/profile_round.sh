@@ -33,6 +33,10 @@ json.dump({"note": "rocprofv3 --kernel-trace of `python3 bench.py --no-cpu-basel
 print(open(sys.argv[3]).read())
 PY
 rm -rf $out/${tag}_prof
+# the insert-heavy head alone (first 300 k reads of C2: batches): slice trace + per-kernel stats
+tools/head_profile.sh ${tag} 300000 > $out/${tag}_head_trace.txt 2>&1
+# C4 geometry (h = 5, silver mode, 5 paths): the stream is head after head
+python3 bench.py --config C4 --reads 4000000 --no-cpu-baseline > $out/${tag}_bench_c4_4M.json 2> /dev/null
 # two ranks on the one GPU (gloo): plumbing of the N > 1 path (fill merge, striped windows, shm exchange)
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --config C1 --steps 6 --no-cpu-baseline --backend gloo --share-gpu --reads 300000 --verify-ranks > $out/${tag}_bench_2ranks_one_gpu_gloo_plumbing.json 2> $out/${tag}_2ranks.err
 grep verify-ranks $out/${tag}_2ranks.err | head -1
