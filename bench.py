@@ -482,7 +482,7 @@ def main():
 
     if rank == 0:
         kq = ks["query"]
-        kernel_name = "k_query, throughput forms (streaming windows k_query<h,1,0,true>, large windows k_query<h,2,0,false>); the latency windows of the insert-heavy head are in aux.query_latency"
+        kernel_name = "k_query, throughput forms (streaming windows k_query<h,1,0,true,false>; large windows and the first query of a batch k_query<h,2,0,false,false>; the second query of a batch, through the batch's records, k_query<h,2,0,false,true>); the few latency windows are in aux.query_latency"
         if kq["units"] == 0:  # a run that never left the insert-heavy head: the latency form is all there is
             kq = ks["query_latency"]
             kernel_name = "k_query, latency form (k_query<h,2,16,false>: windows of a few reads; the run never left the insert-heavy head)"
