@@ -141,7 +141,13 @@ Classifier::window_plan() const
   const bool force_pipeline = pipe_env && !strcmp(pipe_env, "force");
   const char* stream_env = getenv("GRP_STREAM");
   const bool force_stream = stream_env && !strcmp(stream_env, "force");
-  const double p = std::min(1.0, std::max(std::max(p_insert_, p_insert_slow_), 1e-7));
+  // With the batches of batch_round taking every stretch where more than ~1 % of the reads insert,
+  // the windows only see isolated inserts: the 32-read average (one insert = 3 %) would answer
+  // each of them with a handful of small synchronous windows (~0.8 ms per insert, measured on
+  // C2); the 256-read average follows a real change of regime within a few inserts.
+  static const bool fast_p = getenv("GRP_PLAN_FAST_P") != nullptr; // developer hook: the 32-read average as before
+  const double p_recent = (can_batch() && !fast_p) ? p_insert_mid_ : p_insert_;
+  const double p = std::min(1.0, std::max(std::max(p_recent, p_insert_slow_), 1e-7));
   const double world = (double)p_.world;
   // measured on MI355X (bench.py --trace): a synchronous round costs ~70 us when it
   // takes the latency path (host decision, < 16 reads), ~170 us with the decision
@@ -1143,6 +1149,7 @@ Classifier::stream_round(uint32_t& pos)
 {
   const uint32_t n = rg_.n;
   int rc = GRP_OK;
+  const auto tr_enter = std::chrono::steady_clock::now();
   if (snext_.active) {
     scur_ = snext_; // starts at pos: an insert would have aborted it
     snext_.active = false;
@@ -1157,6 +1164,17 @@ Classifier::stream_round(uint32_t& pos)
   group_base_ = UINT32_MAX;
   uint32_t j = 0;
   bool stale = false, redo = false;
+  // developer hook: where the time of an insert goes (launch call, first record, drain + insert)
+  static const bool trace_abort = getenv("GRP_TRACE_ABORT") != nullptr;
+  static double t_launch = 0, t_first = 0, t_commit_ins = 0, t_drop = 0;
+  static uint64_t n_rounds = 0, n_stale = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const auto tr_after_launch = now();
+  if (trace_abort) {
+    t_launch += secs(tr_enter, tr_after_launch);
+    ++n_rounds;
+  }
   while (j < S) {
     // the next window goes in shortly before this launch runs out of work: early
     // enough to start back to back (the GPU is at most ~100 reads ahead of the host),
@@ -1175,6 +1193,9 @@ Classifier::stream_round(uint32_t& pos)
     if (rc != GRP_OK) {
       break;
     }
+    if (trace_abort && j == 0) {
+      t_first += secs(tr_after_launch, now());
+    }
     d.pad = 0;
     p_redo_ += (1.0 / 64.0) * ((d.kind == 0 ? 1.0 : 0.0) - p_redo_);
     if (d.kind == 0) {
@@ -1189,7 +1210,11 @@ Classifier::stream_round(uint32_t& pos)
       }
       stale = true;
     }
+    const auto tr_c0 = now();
     commit_one(pos + j, d, rc);
+    if (trace_abort && stale) {
+      t_commit_ins += secs(tr_c0, now());
+    }
     if (rc != GRP_OK) {
       break;
     }
@@ -1200,7 +1225,16 @@ Classifier::stream_round(uint32_t& pos)
   }
   pos += j;
   if (rc != GRP_OK || stale || finished_ || redo) {
+    const auto tr_d0 = now();
     drop_streams();
+    if (trace_abort) {
+      t_drop += secs(tr_d0, now());
+      ++n_stale;
+      if ((n_stale & 1023u) == 0) {
+        fprintf(stderr, "stream rounds %llu, ended by an insert %llu: per round launch call %.1f us, first record %.1f us; per insert commit+insert call %.1f us, drop (drain + insert kernels) %.1f us\n",
+                (unsigned long long)n_rounds, (unsigned long long)n_stale, 1e6 * t_launch / n_rounds, 1e6 * t_first / n_rounds, 1e6 * t_commit_ins / n_stale, 1e6 * t_drop / n_stale);
+      }
+    }
   } else {
     rc = end_stream(scur_); // completed: returns at once
     if (rc != GRP_OK) {
