@@ -342,7 +342,8 @@ def test_full_size_streaming_equals_synchronous_windows(native, monkeypatch, h, 
         eng.sync()
         st = cls.state()
         ids, counts = eng.export_ids()
-        results.append(([c[:8] for c in cls.commits], ids.copy(), counts.copy(), st["inserts"], st["windows"]))
+        # the whole commit record: decision, first ID, path AND the hits / misses of the read's query
+        results.append(([c[:10] for c in cls.commits], ids.copy(), counts.copy(), st["inserts"], st["windows"]))
         cls.close()
         eng.close()
     a = results[0]
