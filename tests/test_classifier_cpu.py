@@ -184,7 +184,8 @@ reads = _workload()
 m = orc.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
 PIPE = os.environ.get("GRP_PIPELINE") == "force"
 STREAM = os.environ.get("GRP_STREAM") == "force"
-eng = OracleEngine(orc, m, seeds, tile, k, reads, pipelined=PIPE, streaming=STREAM, redo_every=11 if STREAM else 0)   # every rank holds a full replica
+BATCH = os.environ.get("GRP_BATCH") == "force"   # windows committed as batches: every rank applies and checks the whole batch on its replica
+eng = OracleEngine(orc, m, seeds, tile, k, reads, pipelined=PIPE, streaming=STREAM, redo_every=11 if STREAM else 0, batching=BATCH)   # every rank holds a full replica
 
 
 def allgather(user, send, nbytes, recv):
@@ -211,13 +212,14 @@ dist.all_reduce(tot)
 assert mine < int(tot.item())
 assert not PIPE or (eng.n_begun >= 2 and eng.n_abandoned >= 1)
 assert not STREAM or (eng.n_streams >= 3 and eng.n_stream_aborts >= 2 and eng.n_redo >= 1)
+assert not BATCH or (eng.n_batches >= 2 and cls.state()["batch_reads"] > 0)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok", mine, int(tot.item()), eng.n_begun, eng.n_abandoned)
 """
 
 
-@pytest.mark.parametrize("pipeline", ["off", "force", "stream"])
+@pytest.mark.parametrize("pipeline", ["off", "force", "stream", "batch"])
 def test_two_ranks_gloo(oracle, native, tmp_path, pipeline):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
@@ -228,7 +230,8 @@ def test_two_ranks_gloo(oracle, native, tmp_path, pipeline):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
-                   **({"GRP_STREAM": "force", "GRP_STRIPE": "3"} if pipeline == "stream" else {"GRP_PIPELINE": pipeline, "GRP_STREAM": "off"}))
+                   **({"GRP_STREAM": "force", "GRP_STRIPE": "3"} if pipeline == "stream" else {"GRP_BATCH": "force", "GRP_STREAM": "off"} if pipeline == "batch"
+                      else {"GRP_PIPELINE": pipeline, "GRP_STREAM": "off"}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
