@@ -343,6 +343,9 @@ def main():
         n_words = eng.bv_words()
         slice_words = ((n_words + world - 1) // world + 3) // 4 * 4
         mine = torch.zeros(slice_words * world * 4, dtype=torch.uint8, device="cuda")
+        # torch fills the buffer on ITS stream, the engine copies into it on its own (non-blocking)
+        # stream: without this wait the zero fill can land behind the export and wipe bits
+        torch.cuda.synchronize()
         eng.bv_export_device(mine.data_ptr())
         got = torch.empty_like(mine)  # slice `rank` of every rank's vector
         if coll_dev == "cuda":
@@ -470,6 +473,12 @@ def main():
         dt = float(tt.item())
     ks = eng.kernel_stats()
     st1 = cls.state()
+    # Every read of the stream went into the bit vector, so every probe of every frame meets a set
+    # bit and is counted as a hit or a miss (goldrush_path.cpp:567-594): anything else means the
+    # filter lost bits on the way (a sharded fill merged wrongly, a fill that did not cover the reads).
+    if st1["hits"] + st1["misses"] != h * st1["queries"]:
+        raise SystemExit("bench: hits + misses = %d, expected h x queries = %d: the filter does not hold every read of the stream"
+                         % (st1["hits"] + st1["misses"], h * st1["queries"]))
     if world > 1 and a.verify_ranks:
         keys = ("valid_reads", "total_tiles", "assigned_tiles", "unassigned_tiles", "queries", "hits", "misses", "inserted_bases", "id", "ids_inserted",
                 "reads_committed", "inserts")

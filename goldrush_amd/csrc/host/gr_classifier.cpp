@@ -848,12 +848,47 @@ Classifier::batch_round(uint32_t& pos)
   };
   in_batch_ = true;
   ++n_windows_;
+  // Several ranks (every one holds a replica and applies the whole batch to it): the two queries
+  // of a batch are striped over the ranks like any other window, the 32-byte decisions
+  // all-gathered; small batches are not worth the two exchanges.
+  static const uint32_t stripe_min = [] { // developer hook / tests: reads per rank from which a batch's queries are striped
+    const char* e = getenv("GRP_BATCH_STRIPE_MIN");
+    return e ? (uint32_t)std::max(1l, atol(e)) : 32u;
+  }();
+  const uint32_t world = p_.world;
+  // reads [lo, lo + my) of a window of `count` reads are this rank's; q = reads per rank
+  auto my_stripe = [&](uint32_t count, uint32_t& q, uint32_t& lo, uint32_t& my) {
+    q = (count + world - 1) / world;
+    lo = std::min<uint64_t>((uint64_t)p_.rank * q, count);
+    my = std::min<uint32_t>(q, count - lo);
+  };
   bdec0_.resize(B);
-  int rc = vt_.classify_reads(ctx_, rg_.reads, base_ + pos, B, &dp, bdec0_.data());
-  if (rc != GRP_OK) {
-    return fail("classify_reads", rc);
+  int rc = GRP_OK;
+  const bool striped = world > 1 && allgather_cb_ && B >= stripe_min * world;
+  if (striped) {
+    uint32_t q, lo, my;
+    my_stripe(B, q, lo, my);
+    dec_.assign(q, gr_read_decision{});
+    if (my) {
+      rc = vt_.classify_reads(ctx_, rg_.reads, base_ + pos + lo, my, &dp, dec_.data());
+    }
+    if (rc != GRP_OK) {
+      return fail("classify_reads", rc);
+    }
+    n_queried_ += my;
+    rc = gather_decisions(q);
+    if (rc != GRP_OK) {
+      return rc;
+    }
+    --n_windows_; // counted above
+    std::copy(dec_all_.begin(), dec_all_.begin() + B, bdec0_.begin()); // rank r's block starts at read r * q
+  } else {
+    rc = vt_.classify_reads(ctx_, rg_.reads, base_ + pos, B, &dp, bdec0_.data());
+    if (rc != GRP_OK) {
+      return fail("classify_reads", rc);
+    }
+    n_queried_ += B;
   }
-  n_queried_ += B;
 
   // the inserts these decisions ask for, with the IDs commit() will allocate
   bins_.clear();
@@ -945,7 +980,26 @@ Classifier::batch_round(uint32_t& pos)
     return fail("batch_insert", rc);
   }
   bdec1_.resize(cnt);
-  rc = vt_.batch_classify(ctx_, rg_.reads, base_ + pos, cnt, &dp, bfloor_.data(), bdec1_.data());
+  uint32_t queried = cnt;
+  if (striped) {
+    uint32_t q, lo, my;
+    my_stripe(cnt, q, lo, my);
+    dec_.assign(q, gr_read_decision{});
+    // (also with an empty stripe: the call tells every rank alike whether the batch was refused)
+    rc = vt_.batch_classify(ctx_, rg_.reads, base_ + pos + lo, my, &dp, bfloor_.data() + lo, dec_.data());
+    queried = my;
+    if (rc == GRP_OK) {
+      const int grc = gather_decisions(q);
+      --n_windows_;
+      if (grc != GRP_OK) {
+        (void)vt_.batch_undo(ctx_, base_ + pos, bfloor_[0] & 0x7FFFFFFFu);
+        return grc;
+      }
+      std::copy(dec_all_.begin(), dec_all_.begin() + cnt, bdec1_.begin());
+    }
+  } else {
+    rc = vt_.batch_classify(ctx_, rg_.reads, base_ + pos, cnt, &dp, bfloor_.data(), bdec1_.data());
+  }
   if (rc == GRP_ERR_NOMEM) {
     // found on the device: the window's reads share too many ranks (they overlap each other);
     // nothing was inserted, the batch is over — a smaller one next time
@@ -957,7 +1011,7 @@ Classifier::batch_round(uint32_t& pos)
     (void)vt_.batch_undo(ctx_, base_ + pos, bfloor_[0] & 0x7FFFFFFFu);
     return fail("batch_classify", rc);
   }
-  n_queried_ += cnt;
+  n_queried_ += queried;
   ++n_batches_;
   uint32_t bad = cnt;
   for (uint32_t j = 0; j < cnt; ++j) {

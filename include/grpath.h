@@ -455,6 +455,9 @@ int grp_insert_read(grp_ctx* ctx,
  *      block_tiles that block carries the next read's first ID): the caller sets bit 31 of
  *      id_floor[j] where the last insert in front of read j — inside the batch or before it — was
  *      such a read, and the engine then looks up who wrote the rank — hits / misses included;
+ *      Any range of the window's reads may be asked for ([first, first + count) with first >= the
+ *      window's first read, id_floor[0] belonging to read `first`): the ranks of a multi-GPU run,
+ *      each holding a replica with the same batch applied, take one stripe each;
  *   4. compares in order: while kind / trim range agree, the batch WAS the serial loop and the
  *      second set of decisions are the records.  At the first read that differs: grp_batch_undo
  *      (that read's batch index and id_floor) takes back its insert and those of the reads behind

@@ -188,19 +188,22 @@ class OracleEngine:
             self.mf.counts()[:] = bt["counts0"]
 
         def batch_classify(ctx, reads, first, count, dp_p, floor_p, out_p):
-            assert bt and first == bt["first"]
+            # any range of the window's reads (a rank's stripe): read by read from the window's first
+            assert bt and first >= bt["first"]
             dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
-            floors = np.ctypeslib.as_array(C.cast(floor_p, C.POINTER(C.c_uint32)), shape=(count,))
+            floors = np.ctypeslib.as_array(C.cast(floor_p, C.POINTER(C.c_uint32)), shape=(max(count, 1),))
             arr = C.cast(out_p, C.POINTER(host.gr_read_decision))
             by_read = {int(e[0]): e for e in bt["ins"]}
-            assert all(first <= r < first + count for r in by_read)
             _batch_restore()
             self.n_queries += count
-            for j in range(count):
-                arr[j] = _decide(first + j, dp)
-                e = by_read.get(first + j)
+            last = max([first + count - 1] + list(by_read))
+            for r in range(bt["first"], last + 1):
+                if first <= r < first + count:
+                    arr[r - first] = _decide(r, dp)
+                e = by_read.get(r)
                 if e is not None:
-                    assert int(e[3]) == int(floors[j]) & 0x7FFFFFFF  # a read's first ID is the first one it could allocate (bit 31: see grpath.h)
+                    if first <= r < first + count:
+                        assert int(e[3]) == int(floors[r - first]) & 0x7FFFFFFF  # a read's first ID is the first one it could allocate (bit 31: see grpath.h)
                     insert_read(ctx, reads, int(e[0]), int(e[1]), int(e[2]), bt["block"], int(e[3]), int(e[4]))
             return 0
 

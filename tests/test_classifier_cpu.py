@@ -212,7 +212,7 @@ dist.all_reduce(tot)
 assert mine < int(tot.item())
 assert not PIPE or (eng.n_begun >= 2 and eng.n_abandoned >= 1)
 assert not STREAM or (eng.n_streams >= 3 and eng.n_stream_aborts >= 2 and eng.n_redo >= 1)
-assert not BATCH or (eng.n_batches >= 2 and cls.state()["batch_reads"] > 0)
+assert not BATCH or (eng.n_batches >= 2 and cls.state()["batch_reads"] > 0)  # both queries of a batch are striped over the ranks (GRP_BATCH_STRIPE_MIN=2)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok", mine, int(tot.item()), eng.n_begun, eng.n_abandoned)
@@ -230,7 +230,7 @@ def test_two_ranks_gloo(oracle, native, tmp_path, pipeline):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
-                   **({"GRP_STREAM": "force", "GRP_STRIPE": "3"} if pipeline == "stream" else {"GRP_BATCH": "force", "GRP_STREAM": "off"} if pipeline == "batch"
+                   **({"GRP_STREAM": "force", "GRP_STRIPE": "3"} if pipeline == "stream" else {"GRP_BATCH": "force", "GRP_STREAM": "off", "GRP_BATCH_STRIPE_MIN": "2"} if pipeline == "batch"
                       else {"GRP_PIPELINE": pipeline, "GRP_STREAM": "off"}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
