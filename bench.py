@@ -567,7 +567,10 @@ def main():
                        "head": {"reads": head_reads, "seconds": head_s, "reads_per_s": head_reads / head_s if head_s > 0 else None, "inserts": head_ins,
                                 "definition": "slices before the first %d-read slice with an insert rate < 1 %%" % PHASE_SLICE},
                        "steady": {"reads": tail_reads, "seconds": tail_s, "reads_per_s": tail_reads / tail_s if tail_s > 0 else None, "inserts": tail_ins}},
-            "aux": {"fill_reads_per_s": n_reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill, "finalize_s": t_finalize,
+            "aux": {"counters": {k_: int(st1[k_]) for k_ in ("valid_reads", "total_tiles", "assigned_tiles", "unassigned_tiles", "queries", "hits", "misses", "inserted_bases",
+                                                             "ids_inserted", "reads_committed", "inserts")},  # the run's result: the same for every N, mode and switch
+                    "pop": int(pop),
+                    "fill_reads_per_s": n_reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill, "finalize_s": t_finalize,
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors OR-merged as reduce-scatter (all-to-all + OR) + all-gather" % world, "synth_s": t_synth,
                     "read_batches": rs.n_batches, "synth_in_timed_region_s": rs.synth_s - synth_before,
                     "warmup_s": t_warm, "warmup_mode": "%d steps of 512 reads on a throw-away engine (G=2e6)" % a.warmup,

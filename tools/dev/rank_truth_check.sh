@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU box: the counters of a 1-rank run against those of a 2-rank run (two ranks on the one GPU)
+# of the same stream: aux.counters and pop must be identical.   tools/dev/rank_truth_check.sh [config] [reads]
+cfg=${1:-C1}
+reads=${2:-300000}
+python3 bench.py --config $cfg --reads $reads --steps 6 --no-cpu-baseline 2>/dev/null > /tmp/one.json
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --config $cfg --steps 6 --no-cpu-baseline --backend gloo --share-gpu --reads $reads --verify-ranks 2>/dev/null > /tmp/two.json
+python3 - <<'PY'
+import json
+a = json.loads([l for l in open("/tmp/one.json") if l.startswith("{")][-1])
+b = json.loads([l for l in open("/tmp/two.json") if l.startswith("{")][-1])
+print("1 rank :", a["aux"]["pop"], a["aux"]["counters"])
+print("2 ranks:", b["aux"]["pop"], b["aux"]["counters"])
+print("IDENTICAL" if (a["aux"]["pop"], a["aux"]["counters"]) == (b["aux"]["pop"], b["aux"]["counters"]) else "DIFFERENT")
+PY
