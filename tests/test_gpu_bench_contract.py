@@ -33,3 +33,29 @@ def test_bench_line_has_the_contract_fields():
     assert ph["head"]["reads"] + ph["steady"]["reads"] == 3 * 4096 and d["config"]["reads_timed"] == 3 * 4096
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "reads/s" and cb["sample"]
+
+
+def test_two_ranks_on_the_one_gpu_end_where_one_rank_ends():
+    """The N > 1 path end to end on the one available GPU (two processes share it): sharded fill
+    merged by reduce-scatter + all-gather, batches with striped queries, striped streaming
+    windows, the shared-memory exchange.  The run's counters (tiles, hits, misses, inserted
+    bases, IDs, inserts) and the filter's population must equal the single-rank run's — not
+    just agree between the ranks."""
+    import socket
+
+    common = ["--config", "C1", "--steps", "4", "--reads", "120000", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--verify-ranks"] + common,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert two.returncode == 0, two.stderr[-3000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and a["n_gpus"] == 1
+    assert a["aux"]["pop"] == b["aux"]["pop"]
+    assert a["aux"]["counters"] == b["aux"]["counters"]
+    assert a["aux"]["counters"]["inserts"] > 1000 and b["aux"]["timed"]["batches"] > 10
