@@ -194,6 +194,10 @@ def test_batch_of_long_reads_equals_inserts_one_by_one(native):
     b, rb_ = engine()
     b.batch_insert_reads(rb_, ins, block, 0)
     d1 = b.batch_classify(rb_, 0, nb, floors)
+    # a stripe of the window (what one rank of a multi-GPU run asks for), and an empty one
+    stripe = b.batch_classify(rb_, 5, 6, floors[5:11])
+    assert stripe.tobytes() == d1[5:11].tobytes()
+    assert len(b.batch_classify(rb_, nb, 0, [0])) == 0
     b.batch_end()
     ids_b, counts_b = b.export_ids()
     b.close()
