@@ -18,6 +18,10 @@ tools/rocprof_round.sh ${tag}
 tools/head_profile.sh ${tag} 300000 > $out/${tag}_head_trace.txt 2>&1
 # C4 geometry (h = 5, silver mode, 5 paths): the stream is head after head
 python3 bench.py --config C4 --reads 4000000 --no-cpu-baseline > $out/${tag}_bench_c4_4M.json 2> /dev/null
+# exactness at full size: C2's head (61 Gbit filter, 700 k reads) through the default path twice and
+# through the classic windows only; one rank against two ranks (C1 and C2): the run's counters
+tools/dev/mode_truth_check.sh C2 700000 > $out/${tag}_truth_modes_c2.txt 2>&1
+(tools/dev/rank_truth_check.sh C1 300000; tools/dev/rank_truth_check.sh C2 600000) > $out/${tag}_truth_ranks.txt 2>&1
 # two ranks on the one GPU (gloo): plumbing of the N > 1 path (fill merge, striped windows, shm exchange)
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --config C1 --steps 6 --no-cpu-baseline --backend gloo --share-gpu --reads 300000 --verify-ranks > $out/${tag}_bench_2ranks_one_gpu_gloo_plumbing.json 2> $out/${tag}_2ranks.err
 grep verify-ranks $out/${tag}_2ranks.err | head -1
