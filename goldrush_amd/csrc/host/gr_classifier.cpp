@@ -74,6 +74,7 @@ Classifier::get_state(gr_classifier_state& s) const
   s.batches = n_batches_;
   s.batches_undone = n_batch_undone_;
   s.batch_reads = n_batch_reads_;
+  s.batches_refused = n_batch_refused_;
 }
 
 void
@@ -973,6 +974,7 @@ Classifier::batch_round(uint32_t& pos)
   rc = vt_.batch_insert(ctx_, rg_.reads, bins_.data(), (uint32_t)bins_.size(), block, base_ + pos);
   if (rc == GRP_ERR_NOMEM) {
     batch_reads_ = std::max<uint32_t>(2, cnt / 2); // more records than a batch holds
+    ++n_batch_refused_;
     rc = GRP_OK;
     return commit_classic(first_ins + 1);
   }
@@ -1004,6 +1006,7 @@ Classifier::batch_round(uint32_t& pos)
     // found on the device: the window's reads share too many ranks (they overlap each other);
     // nothing was inserted, the batch is over — a smaller one next time
     batch_reads_ = std::max<uint32_t>(2, cnt / 2);
+    ++n_batch_refused_;
     rc = GRP_OK;
     return commit_classic(first_ins + 1);
   }

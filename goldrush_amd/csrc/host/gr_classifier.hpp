@@ -116,7 +116,7 @@ private:
   bool batch_bypass_ = false;    // the read in front cannot be part of a batch: one classic round
   uint32_t batch_reads_ = 128;   // reads per batch, chosen by batch_feedback
   double bf_fail_ = 1.0, bf_expo_ = 5e4; // first reads that decided differently / (inserted read, later read) pairs exposed (decaying sums)
-  uint64_t n_batches_ = 0, n_batch_undone_ = 0, n_batch_reads_ = 0;
+  uint64_t n_batches_ = 0, n_batch_undone_ = 0, n_batch_reads_ = 0, n_batch_refused_ = 0;
   double p_redo_ = 0.0;          // streaming records handed back to the synchronous path (EMA over ~64 reads)
   double avg_probes_per_read_ = 75000.0;
   uint64_t n_windows_ = 0, n_queried_ = 0, n_committed_ = 0, n_inserts_ = 0;

@@ -190,8 +190,9 @@ typedef struct
   uint64_t windows, reads_queried, reads_committed, inserts;
   /* wall-clock split of gr_classifier_run: engine calls for the windows vs ordered commit */
   double seconds_windows, seconds_commit;
-  /* windows committed as batches (grp_batch_*): batches checked, batches taken back, reads committed through them */
+  /* windows committed as batches (grp_batch_*): batches checked, batches ended early, reads committed through them */
   uint64_t batches, batches_undone, batch_reads;
+  uint64_t batches_refused; /* batches the engine refused (GRP_ERR_NOMEM): committed the classic way */
 } gr_classifier_state;
 void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
 

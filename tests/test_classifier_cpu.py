@@ -132,7 +132,7 @@ def test_batched_windows_match_serial_loop(oracle, native, max_window, crowded, 
     if max_window >= 64 and not crowded:
         assert eng.n_batch_undone >= 1 and st["batches_undone"] == eng.n_batch_undone
     if crowded:
-        assert eng.n_batch_refused >= 1
+        assert eng.n_batch_refused >= 1 and st["batches_refused"] == eng.n_batch_refused
 
 
 def _hits_misses(oracle, m, seeds, tile, k, reads, block):

@@ -15,7 +15,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("max_window,mode", [(1, "auto"), (5, "auto"), (4096, "auto"), (4096, "loop"), (4096, "stream"), (48, "stream"), (4096, "pipeline"), (4096, "sync"),
-                                             (1, "windows"), (4096, "windows"), (4096, "batch"), (6, "batch")])
+                                             (1, "windows"), (4096, "windows"), (4096, "batch"), (6, "batch"), (4096, "batch_refused")])
 def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, monkeypatch):
     from goldrush_amd import host, synth
     from oracle_engine import cached_serial_reference
@@ -25,7 +25,10 @@ def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, mo
     env = {"auto": {}, "loop": {"GRP_LOOP": "force"}, "windows": {"GRP_LOOP": "off", "GRP_BATCH": "off"}, "stream": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "force"},
            "pipeline": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "force"},
            "sync": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "off"},
-           "batch": {"GRP_BATCH": "force"}}[mode]
+           "batch": {"GRP_BATCH": "force"},
+           # a chain store of 8 entries: every batch whose reads share more than 8 ranks is refused ON THE DEVICE (the owners'
+           # touches are taken back from the records), the classifier falls back to the classic commit and halves the batch
+           "batch_refused": {"GRP_BATCH": "force", "GRP_BATCH_OVF_CAP": "8"}}[mode]
     for key, val in env.items():
         monkeypatch.setenv(key, val)
     tile, k, h, block = 500, 22, 3, 4
@@ -50,6 +53,8 @@ def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, mo
     assert st["reads_committed"] == len(exp) and st["inserts"] == sum(1 for e in exp if e[1] in (2, 4))
     if mode == "batch":
         assert st["batches"] >= 2 and st["batch_reads"] > 0
+    if mode == "batch_refused":
+        assert st["batches_refused"] >= 2 and st["batches"] >= 1
 
 
 def test_golden_fixture_through_cli(native, tmp_path):
