@@ -1017,10 +1017,12 @@ Classifier::batch_round(uint32_t& pos)
   n_queried_ += queried;
   ++n_batches_;
   uint32_t bad = cnt;
+  bool bad_undecided = false; // the engine handed the read back in its second decision: the classic path takes it
   for (uint32_t j = 0; j < cnt; ++j) {
     const gr_read_decision &a = bdec0_[j], &b = bdec1_[j];
     if (a.kind != b.kind || a.num_tiles != b.num_tiles || (a.kind == DEC_INSERT_TRIMMED && (a.trim_start != b.trim_start || a.trim_end != b.trim_end))) {
       bad = j;
+      bad_undecided = b.kind != DEC_INSERT_WHOLE && b.kind != DEC_INSERT_TRIMMED && b.kind != DEC_ASSIGNED_ALL && b.kind != DEC_ASSIGNED;
       break;
     }
   }
@@ -1063,9 +1065,13 @@ Classifier::batch_round(uint32_t& pos)
   n_batch_reads_ += confirmed;
   pos += confirmed;
   if (bad != cnt && !finished_) {
-    // `bad` itself: its second decision was taken against exactly the state it now sees
-    (void)commit_one(pos, bdec1_[bad], rc);
-    ++pos;
+    if (bad_undecided) {
+      batch_bypass_ = true;
+    } else {
+      // `bad` itself: its second decision was taken against exactly the state it now sees
+      (void)commit_one(pos, bdec1_[bad], rc);
+      ++pos;
+    }
   }
   return rc;
 }
