@@ -250,3 +250,43 @@ def test_very_long_read_inserted_whole(oracle, native, h):
         assert np.array_equal(ids, mf.ids()), variant
         eng.close()
     mf.close()
+
+
+def test_batch_api_refuses_misuse(native):
+    """Error behaviour of the grp_batch_* entry points (include/grpath.h): arguments are checked
+    before anything is touched, one batch at a time, calls without a batch say so."""
+    from goldrush_amd import synth
+
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    g = synth.random_genome(60_000, 3)
+    reads = [r[1] for r in synth.make_reads(g, 6, mean_len=4000, min_len=3000, seed=4, max_len=6000)]
+    eng = native.Engine(k, h, tile, 1 << 22, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    nt = [len(r) // tile for r in reads]
+
+    def code(fn, *a):
+        with pytest.raises(native_mod.GrpError) as e:
+            fn(*a)
+        return e.value.code
+
+    assert code(eng.batch_insert_reads, b, [(0, 0, nt[0], 1, 0)], block, 0) == native_mod.GRP_ERR_STATE  # before grp_finalize
+    eng.finalize()
+    ids0, counts0 = eng.export_ids()
+    assert code(eng.batch_classify, b, 0, 2, [1, 1]) == native_mod.GRP_ERR_STATE        # no batch
+    assert code(eng.batch_undo, 0, 1) == native_mod.GRP_ERR_STATE                        # no batch
+    eng.batch_end()                                                                      # nothing to end: fine
+    assert code(eng.batch_insert_reads, b, [(1, 0, nt[1], 1, 0), (0, 0, nt[0], 9, 0)], block, 0) == native_mod.GRP_ERR_INVALID  # not ascending
+    assert code(eng.batch_insert_reads, b, [(0, 0, nt[0] + 1, 1, 0)], block, 0) == native_mod.GRP_ERR_INVALID                   # tiles outside the read
+    assert code(eng.batch_insert_reads, b, [(0, 0, nt[0], 1, 0)], block, 1) == native_mod.GRP_ERR_INVALID                       # a read in front of the window
+    assert code(eng.batch_insert_reads, b, [(0, 2, 2, 1, 0)], block, 0) == native_mod.GRP_ERR_INVALID                           # empty range
+    assert code(eng.batch_insert_reads, b, [(0, 0, nt[0], 1, 2)], block, 0) == native_mod.GRP_ERR_INVALID                       # id_offset is 0 or 1
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, ids0) and np.array_equal(counts, counts0)                 # nothing was touched
+    eng.batch_insert_reads(b, [(0, 0, nt[0], 1, 0), (2, 0, nt[2], 9, 0)], block, 0)
+    assert code(eng.batch_insert_reads, b, [(3, 0, nt[3], 20, 0)], block, 3) == native_mod.GRP_ERR_STATE  # one batch at a time
+    eng.batch_undo(0, 1)                                                                  # everything taken back
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, ids0) and np.array_equal(counts, counts0)
+    eng.close()
