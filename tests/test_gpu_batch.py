@@ -151,7 +151,8 @@ def test_batches_on_a_small_crowded_filter(oracle, native):
     assert stats["batches"] > 0
 
 
-def test_batch_of_long_reads_equals_inserts_one_by_one(native):
+@pytest.mark.parametrize("h", [3, 5])
+def test_batch_of_long_reads_equals_inserts_one_by_one(native, h):
     """BASELINE geometry (25 kb reads, tile 1000, block 10, a small genome so that the reads of a
     batch share many ranks): 16 whole-read inserts as ONE batch — several hundred workgroups,
     more than one per compute unit — leave the IDs and counts of every rank exactly as the
@@ -160,7 +161,7 @@ def test_batch_of_long_reads_equals_inserts_one_by_one(native):
     second half equals inserting only the first half."""
     from goldrush_amd import host
 
-    h, n, nb = 3, 64, 16
+    n, nb = 64, 16
     k, tile, block, G = 22, 1000, 10, 8_000_000
     seeds = default_seeds(h)
     hl = host.load()
