@@ -387,8 +387,17 @@ def main():
             # libgrpath_host's node-local exchange (C++: no Python between the classifier and the other ranks)
             key = "bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run"))
             shm = hl.gr_shm_allgather_open(world, rank, key.encode(), 120.0)
-            if not shm and rank == 0:
-                sys.stderr.write("bench: no /dev/shm exchange, using a gloo group\n")
+        # the choice is collective: one rank without the exchange (a timeout, no /dev/shm in its
+        # container) and EVERY rank takes the gloo path — otherwise some ranks would enter
+        # dist.new_group while the others skip it, and the stripe widths would differ per rank
+        flag = torch.tensor([1 if shm else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if shm:
+                hl.gr_shm_allgather_close(shm)
+            shm = None
+            if rank == 0:
+                sys.stderr.write("bench: no /dev/shm exchange on every rank, using a gloo group\n")
         if shm:
             # the exchange costs tens of microseconds here, not hundreds: shorter stripes
             # (less speculative work lost per insert) still hide it behind the launches

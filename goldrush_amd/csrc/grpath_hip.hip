@@ -84,6 +84,15 @@ struct QuerySlot
   unsigned long long* d_executed = nullptr;
   unsigned long long* h_executed = nullptr; // pinned
   bool streaming = false;
+  // a streaming window that applies inserts itself (grp_classify_stream_insert)
+  uint32_t* d_sctl = nullptr;   // SCT_* control block
+  uint32_t* h_cmd = nullptr;    // mapped, coherent: [0] sequence number, [1..10] the command
+  uint32_t* dmap_cmd = nullptr;
+  uint32_t* h_ack = nullptr;    // mapped, coherent: [0] inserts applied by the launch, [1] failure code
+  uint32_t* dmap_ack = nullptr;
+  bool resumable = false;       // the window in flight takes grp_classify_stream_insert
+  uint32_t gen = 1;             // generation of the records the host is waiting for
+  uint32_t cmd_seq = 0;         // commands posted to the window in flight
   uint32_t* h_stripe_tiles = nullptr; // pinned: this rank's tiles of a striped window
   uint32_t* d_stripe_tiles = nullptr;
   uint64_t stripe_tiles_cap = 0;
@@ -493,9 +502,7 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     // persistent workgroups: exactly what is resident at once
     // one frame per lane and pass: fewer registers, more resident workgroups — measured
     // better than two for the persistent form (h = 3: +3 %, h = 5: +19 %)
-    static const bool fr2 = getenv("GRP_STREAM_FR2") != nullptr; // developer hook
-    static const bool wt16 = getenv("GRP_STREAM_WT16") != nullptr; // developer hook: unrolled care loop
-    auto kern = fr2 ? k_query<HH, 2, 0, true> : (wt16 && c->uniform_weight == 16) ? k_query<HH, 1, 16, true> : k_query<HH, 1, 0, true>;
+    auto kern = k_query<HH, 1, 0, true>;
     int rc = ensure_lds(c, kern, g.lds);
     if (rc != GRP_OK) {
       return rc;
@@ -515,22 +522,14 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     n_launch = std::min<uint64_t>(n_launch, resident);
     return go(kern);
   }
-  // 2 frames per lane and pass: 2*H*4 quad reads in flight per lane (measured best on MI355X)
-  if constexpr (HH == 3) {
-    // tuning hook (developer only): GRP_QUERY_VARIANT = "<frames per lane>,<unrolled weight>"
-    static const char* v = getenv("GRP_QUERY_VARIANT");
-    if (v) {
-      const std::string sv(v);
-      if (sv == "1,0") return go(k_query<HH, 1, 0, false>);
-      if (sv == "4,0") return go(k_query<HH, 4, 0, false>);
-      if (sv == "2,16" && c->uniform_weight == 16) return go(k_query<HH, 2, 16, false>);
-      if (sv == "1,16" && c->uniform_weight == 16) return go(k_query<HH, 1, 16, false>);
-    }
-  }
+  // 2 frames per lane and pass: 2*H*4 quad reads in flight per lane (measured best on MI355X).
   // latency windows (a few reads on an otherwise idle device): a wave's time is the chain of
-  // its own instructions; the unrolled care loop shortens it
-  if (c->uniform_weight == 16 && n_launch <= SMALL_TILES) {
-    return go(k_query<HH, 2, 16, false>);
+  // its own instructions; the unrolled care loop shortens it — up to h = 3, beyond that the
+  // unrolled form runs out of registers (h = 5: 512 VGPRs + 110 spilled to scratch, round 2)
+  if constexpr (HH <= 3) {
+    if (c->uniform_weight == 16 && n_launch <= SMALL_TILES) {
+      return go(k_query<HH, 2, 16, false>);
+    }
   }
   return go(k_query<HH, 2, 0, false>);
 }
@@ -686,6 +685,13 @@ grp_create(const grp_params* p, grp_ctx** out)
     CREATE_TRY(hipHostMalloc(&sl.h_abort, 64, hipHostMallocMapped | hipHostMallocCoherent));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_abort), sl.h_abort, 0));
     *sl.h_abort = 0;
+    CREATE_TRY(hipMalloc(&sl.d_sctl, SCT_WORDS * sizeof(uint32_t)));
+    CREATE_TRY(hipHostMalloc(&sl.h_cmd, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_cmd), sl.h_cmd, 0));
+    CREATE_TRY(hipHostMalloc(&sl.h_ack, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_ack), sl.h_ack, 0));
+    memset(sl.h_cmd, 0, 64);
+    memset(sl.h_ack, 0, 64);
     CREATE_TRY(hipMalloc(&sl.d_executed, sizeof(unsigned long long)));
     CREATE_TRY(hipHostMalloc(&sl.h_executed, sizeof(unsigned long long), hipHostMallocDefault));
   }
@@ -758,6 +764,13 @@ grp_destroy(grp_ctx* c)
     }
     (void)hipFree(sl.d_tiles_done);
     (void)hipFree(sl.d_executed);
+    (void)hipFree(sl.d_sctl);
+    if (sl.h_cmd) {
+      (void)hipHostFree(sl.h_cmd);
+    }
+    if (sl.h_ack) {
+      (void)hipHostFree(sl.h_ack);
+    }
   }
   {
     LoopRun& lp = c->loop;
@@ -1741,14 +1754,61 @@ grp_classify_reads(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t coun
 
 // ---- streaming window --------------------------------------------------------------
 
+// the scratch table of a whole-read insert (k_insert_collect / k_insert_apply and the in-launch
+// insert of a streaming window): room for `max_ranks` distinct ranks at load <= 1/2.  Growing it
+// waits for the stream (never while a window that holds its address is in flight: see the caller).
+static int
+ensure_insert_table(grp_ctx* c, uint64_t max_ranks)
+{
+  const uint64_t want = next_pow2_64(max_ranks * 2);
+  if (want <= c->ir_cap) {
+    return GRP_OK;
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(c->d_ir_keys);
+  (void)hipFree(c->d_ir_masks);
+  (void)hipFree(c->d_ir_locs);
+  (void)hipFree(c->d_ir_slots);
+  c->d_ir_keys = c->d_ir_masks = c->d_ir_locs = nullptr;
+  c->d_ir_slots = nullptr;
+  c->ir_cap = 0;
+  HIP_TRY(c, hipMalloc(&c->d_ir_keys, want * 8));
+  HIP_TRY(c, hipMalloc(&c->d_ir_masks, want * 8));
+  HIP_TRY(c, hipMalloc(&c->d_ir_locs, want * 8));
+  HIP_TRY(c, hipMalloc(&c->d_ir_slots, want * 4));
+  HIP_TRY(c, hipMemsetAsync(c->d_ir_keys, 0, want * 8, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_ir_masks, 0, want * 8, c->stream));
+  if (!c->d_ir_counter) {
+    HIP_TRY(c, hipMalloc(&c->d_ir_counter, 2 * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->d_ir_counter, 0, 2 * sizeof(uint32_t), c->stream));
+  }
+  c->ir_cap = want;
+  return GRP_OK;
+}
+
+static int
+stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions, bool want_resumable);
+
 int
 grp_classify_stream_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, const grp_read_decision** decisions)
 {
-  return grp_classify_stream_begin_striped(c, r, first, count, dp, slot, 0, 1, 0, decisions);
+  return stream_begin_impl(c, r, first, count, dp, slot, 0, 1, 0, decisions, false);
 }
 
 int
 grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions)
+{
+  return stream_begin_impl(c, r, first, count, dp, slot, stripe_reads, n_owners, owner, decisions, false);
+}
+
+int
+grp_classify_stream_begin_resumable(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, const grp_read_decision** decisions)
+{
+  return stream_begin_impl(c, r, first, count, dp, slot, 0, 1, 0, decisions, true);
+}
+
+static int
+stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions, bool want_resumable)
 {
   if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads || !dp || slot > 1 || !decisions || n_owners == 0 || owner >= n_owners ||
       (n_owners > 1 && stripe_reads == 0)) {
@@ -1772,6 +1832,19 @@ grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first
   if (nt > (1u << 30)) {
     return set_err(c, GRP_ERR_INVALID, "grp_classify_stream_begin: %llu tiles in one call (limit 2^30)", (unsigned long long)nt);
   }
+  {
+    // Growing a buffer frees the old one, and hipFree / hipHostFree wait for the device.  A
+    // resumable window in the other slot may be parked, waiting for THIS thread's answer — the
+    // wait would never end (found on C2: a window with a record number of tiles, begun while
+    // the current one still had an insert to take; the launch gave up after its idle limit).
+    // Not now, then: the caller begins this window once the other one has ended.
+    const QuerySlot& other = c->slot[slot ^ 1u];
+    const bool grows = count > sl.sdec_cap || std::max<uint64_t>(count, 1) > sl.tiles_done_cap || nt + 1 > sl.d_dec_cap || std::max<uint64_t>(nt, 1) > sl.d_tiles_cap ||
+                       std::max<uint64_t>(sl.d_lists_cap, 4 * nt + 4096) > sl.d_lists_cap || std::max<uint64_t>(nt, 1) > sl.d_flag_cap;
+    if (grows && other.busy && other.streaming && other.resumable) {
+      return set_err(c, GRP_ERR_BUSY, "grp_classify_stream_begin: the slot's buffers must grow while a resumable window is in flight in the other slot: begin this window when that one has ended");
+    }
+  }
   c->q = &sl;
   if (count > sl.sdec_cap) {
     if (sl.h_sdec) {
@@ -1779,7 +1852,7 @@ grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first
       sl.h_sdec = nullptr;
     }
     sl.sdec_cap = 0;
-    const uint64_t cap = std::max<uint64_t>((uint64_t)count + count / 4, 1024);
+    const uint64_t cap = std::max<uint64_t>((uint64_t)count + count / 2, 1024);
     HIP_TRY(c, hipHostMalloc(&sl.h_sdec, cap * sizeof(grp_read_decision), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_sdec), sl.h_sdec, 0));
     sl.sdec_cap = cap;
@@ -1848,14 +1921,40 @@ grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first
   }
   // reads without a single tile are never completed by a workgroup: decided here
   memset(sl.h_sdec, 0, (size_t)count * sizeof(grp_read_decision));
+  uint32_t n_decidable = 0;
+  uint64_t max_tiles_read = 0;
   for (uint32_t j = 0; j < count; ++j) {
-    if (r->tile0[first + j + 1] == r->tile0[first + j]) {
+    const uint64_t ntj = r->tile0[first + j + 1] - r->tile0[first + j];
+    max_tiles_read = std::max(max_tiles_read, ntj);
+    if (ntj == 0) {
       grp_read_decision d{};
       gr::core::decide(dp->threshold, dp->unassigned_min, dp->assigned_max, 0, nullptr, nullptr, nullptr, nullptr, nullptr, d);
       d.pad = 1;
       sl.h_sdec[j] = d;
+    } else {
+      ++n_decidable;
     }
   }
+  // A resumable window (grp_classify_stream_begin_resumable) does not end where it parks: it
+  // waits for the host's word — _abort, or _insert: the insert the host has committed, applied
+  // inside the launch.  Not when the scratch table would have to grow while the other slot's
+  // window holds its address (the window is then an ordinary one; _insert says so).
+  const char* resume_env = getenv("GRP_STREAM_RESUME"); // developer switch / tests: "off" = every window ends where it parks
+  const bool resume_off = resume_env && !strcmp(resume_env, "off");
+  sl.resumable = false;
+  if (want_resumable && !striped && !resume_off && n_mine != 0) {
+    const uint64_t need_ranks = max_tiles_read * c->params.tile * c->params.h;
+    const bool other_streaming = c->slot[slot ^ 1u].busy && c->slot[slot ^ 1u].streaming;
+    if (next_pow2_64(need_ranks * 2) <= c->ir_cap || !other_streaming) {
+      rc = ensure_insert_table(c, need_ranks);
+      if (rc != GRP_OK) {
+        return rc;
+      }
+      sl.resumable = true;
+    }
+  }
+  sl.gen = 1;
+  sl.cmd_seq = 0;
   __atomic_store_n(sl.h_abort, 0u, __ATOMIC_RELEASE);
   sl.reads = r;
   sl.first = first;
@@ -1878,6 +1977,13 @@ grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first
     HIP_TRY(c, hipMemsetAsync(sl.d_abort + 48, 0xFF, sizeof(uint32_t), c->stream)); // park: nothing stale yet
     HIP_TRY(c, hipMemsetAsync(sl.d_tiles_done, 0, (size_t)count * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipMemsetAsync(sl.d_executed, 0, sizeof(unsigned long long), c->stream));
+    if (sl.resumable) {
+      HIP_TRY(c, hipMemsetAsync(sl.d_sctl, 0, SCT_WORDS * sizeof(uint32_t), c->stream));
+      HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sl.d_sctl + SCT_GEN), 1, 1, c->stream));
+      __atomic_store_n(&sl.h_cmd[0], 0u, __ATOMIC_RELEASE);
+      sl.h_ack[0] = 0;
+      sl.h_ack[1] = 0;
+    }
     DevStreamCtl sc;
     sc.first = first;
     sc.tiles_done = sl.d_tiles_done;
@@ -1893,6 +1999,19 @@ grp_classify_stream_begin_striped(grp_ctx* c, const grp_reads* r, uint32_t first
     sc.g_ids = sl.d_dec_ids;
     sc.g_asg = sl.d_dec_asg;
     sc.g_scratch = sl.d_dec_scratch;
+    sc.n_reads = count;
+    sc.n_decidable = n_decidable;
+    if (sl.resumable) {
+      sc.ctl = sl.d_sctl;
+      sc.cmd_host = sl.dmap_cmd;
+      sc.ack_host = sl.dmap_ack;
+      sc.tb = InsertTable{ c->d_ir_keys, c->d_ir_masks, c->d_ir_locs, c->d_ir_slots, c->d_ir_counter, c->ir_cap - 1 };
+      static const double wait_s = [] { // developer hook: time limit of a grid-wide wait (seconds)
+        const char* e = getenv("GRP_STREAM_WAIT_S");
+        return e ? atof(e) : 2.0;
+      }();
+      sc.timeout_ticks = (unsigned long long)(wait_s * 1e8); // wall_clock64 counts at 100 MHz
+    }
     const QueryGeom g = query_geom(c, false);
     {
       Timer t(c, GRP_K_QUERY, 0); // the probes actually executed are added at _end
@@ -1962,6 +2081,104 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
   if (c->pending.size() > 64) {
     drain_events(c);
   }
+  if (sl.resumable) {
+    sl.resumable = false;
+    const uint32_t code = __atomic_load_n(&sl.h_ack[1], __ATOMIC_ACQUIRE);
+    const uint32_t applied = __atomic_load_n(&sl.h_ack[0], __ATOMIC_ACQUIRE);
+    if (code == 2) {
+      return set_err(c, GRP_ERR_STATE, "grp_classify_stream_end: a grid-wide wait timed out in the middle of an insert (the ID array may be inconsistent)");
+    }
+    if (code == 3) {
+      uint32_t first_open = sl.count;
+      for (uint32_t j = 0; j < sl.count; ++j) {
+        if (sl.h_sdec[j].pad != sl.gen) {
+          first_open = j;
+          break;
+        }
+      }
+      return set_err(c, GRP_ERR_STATE,
+                     "grp_classify_stream_end: the parked window was never told how to go on (idle time limit); launch: park %u decided %u / %u next tile %u / %llu event %u command seen %u "
+                     "generation %u; host: %u reads, generation %u, commands posted %u applied %u, first record of another generation %u (pad %u kind %u)",
+                     sl.h_ack[8], sl.h_ack[9], 0u, sl.h_ack[10], (unsigned long long)sl.nt, sl.h_ack[11], sl.h_ack[12], sl.h_ack[13], sl.count, sl.gen, sl.cmd_seq, applied, first_open,
+                     first_open < sl.count ? sl.h_sdec[first_open].pad : 0u, first_open < sl.count ? sl.h_sdec[first_open].kind : 0u);
+    }
+    if (applied != sl.cmd_seq) {
+      // The launch ended without the insert posted last (an abort overtook it, or the first
+      // grid-wide wait timed out: the device is shared).  Only the scratch table may have been
+      // touched; the caller applies the insert with grp_insert_read.
+      HIP_TRY(c, hipMemsetAsync(c->d_ir_keys, 0, c->ir_cap * 8, c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_ir_masks, 0, c->ir_cap * 8, c->stream));
+      return 1;
+    }
+  }
+  return GRP_OK;
+}
+
+int
+grp_classify_stream_insert(grp_ctx* c, uint32_t slot, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset, uint32_t* generation)
+{
+  if (!c || slot > 1 || !c->slot[slot].busy || !c->slot[slot].streaming || block_tiles == 0 || id_offset > 1 || !generation) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_stream_insert: no streaming window in this slot / bad argument");
+  }
+  QuerySlot& sl = c->slot[slot];
+  const grp_reads* r = sl.reads;
+  if (!sl.resumable) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_stream_insert: this window ends where it parks (not begun with grp_classify_stream_begin_resumable, or GRP_STREAM_RESUME=off)");
+  }
+  if (read_idx < sl.first || read_idx >= sl.first + sl.count) {
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_stream_insert: read %u is not in the window", read_idx);
+  }
+  const uint64_t ntile = r->tile0[read_idx + 1] - r->tile0[read_idx];
+  if (tile_start >= tile_end || tile_end > ntile) {
+    return set_err(c, GRP_ERR_INVALID, "grp_classify_stream_insert: tiles [%u,%u) outside the read's %llu tiles", tile_start, tile_end, (unsigned long long)ntile);
+  }
+  if ((tile_end - tile_start + block_tiles - 1) / block_tiles > 64) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_stream_insert: more than 64 ID blocks (the caller ends the window and uses grp_insert_read)");
+  }
+  if (sl.cmd_seq != 0 && getenv("GRP_TRACE_ABORT")) { // developer trace: phase times of the previous in-launch insert (100 MHz ticks)
+    static double t_ph[4] = { 0, 0, 0, 0 };
+    static uint64_t n_tr = 0;
+    for (int i = 0; i < 4; ++i) {
+      t_ph[i] += sl.h_ack[4 + i] * 1e-2;
+    }
+    if ((++n_tr & 511u) == 0) {
+      fprintf(stderr, "in-launch inserts %llu: workgroup 0 spent %.1f us collecting, %.1f us in the first wait, %.1f us applying, %.1f us in the second wait\n", (unsigned long long)n_tr, t_ph[0] / n_tr,
+              t_ph[1] / n_tr, t_ph[2] / n_tr, t_ph[3] / n_tr);
+    }
+  }
+  // (records of the new generation can overtake the launch's acknowledgement of the insert in front of them by a moment)
+  for (uint32_t spins = 0; __atomic_load_n(&sl.h_ack[0], __ATOMIC_ACQUIRE) != sl.cmd_seq; ++spins) {
+    if (spins > (1u << 26) || __atomic_load_n(&sl.h_ack[1], __ATOMIC_ACQUIRE) != 0) {
+      return set_err(c, GRP_ERR_STATE, "grp_classify_stream_insert: the previous insert of this window has not been applied");
+    }
+    __builtin_ia32_pause();
+  }
+  const uint32_t x = read_idx - sl.first;
+  uint32_t decided_base = 0;
+  for (uint32_t j = 0; j <= x; ++j) {
+    decided_base += r->tile0[sl.first + j + 1] != r->tile0[sl.first + j];
+  }
+  const uint32_t gen = ++sl.gen;
+  for (uint32_t j = x + 1; j < sl.count; ++j) { // the host's own records (reads without tiles) move to the new generation
+    if (r->tile0[sl.first + j + 1] == r->tile0[sl.first + j]) {
+      __atomic_store_n(&sl.h_sdec[j].pad, gen, __ATOMIC_RELEASE);
+    }
+  }
+  uint32_t* w = sl.h_cmd + 1;
+  w[0] = read_idx;
+  w[1] = tile_start;
+  w[2] = tile_end;
+  w[3] = block_tiles;
+  w[4] = first_id;
+  w[5] = id_offset;
+  w[6] = x + 1;
+  w[7] = (uint32_t)(r->tile0[read_idx + 1] - sl.t0);
+  w[8] = decided_base;
+  w[9] = gen;
+  __atomic_store_n(&sl.h_cmd[0], ++sl.cmd_seq, __ATOMIC_RELEASE);
+  c->kstat[GRP_K_INSERT].launches += 1;
+  c->kstat[GRP_K_INSERT].units += (uint64_t)(tile_end - tile_start) * c->params.tile * c->params.h;
+  *generation = gen;
   return GRP_OK;
 }
 
@@ -2042,27 +2259,11 @@ grp_insert_read(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t tile
   }
   HIP_TRY(c, hipSetDevice(c->device));
   const uint64_t max_ranks = (uint64_t)nt * c->params.tile * c->params.h;
-  const uint64_t want = next_pow2_64(max_ranks * 2);
-  if (want > c->ir_cap) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(c->d_ir_keys);
-    (void)hipFree(c->d_ir_masks);
-    (void)hipFree(c->d_ir_locs);
-    (void)hipFree(c->d_ir_slots);
-    c->d_ir_keys = c->d_ir_masks = c->d_ir_locs = nullptr;
-    c->d_ir_slots = nullptr;
-    c->ir_cap = 0;
-    HIP_TRY(c, hipMalloc(&c->d_ir_keys, want * 8));
-    HIP_TRY(c, hipMalloc(&c->d_ir_masks, want * 8));
-    HIP_TRY(c, hipMalloc(&c->d_ir_locs, want * 8));
-    HIP_TRY(c, hipMalloc(&c->d_ir_slots, want * 4));
-    HIP_TRY(c, hipMemsetAsync(c->d_ir_keys, 0, want * 8, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_ir_masks, 0, want * 8, c->stream));
-    if (!c->d_ir_counter) {
-      HIP_TRY(c, hipMalloc(&c->d_ir_counter, 2 * sizeof(uint32_t)));
-      HIP_TRY(c, hipMemsetAsync(c->d_ir_counter, 0, 2 * sizeof(uint32_t), c->stream));
+  {
+    const int trc = ensure_insert_table(c, max_ranks);
+    if (trc != GRP_OK) {
+      return trc;
     }
-    c->ir_cap = want;
   }
   InsertTable tb{ c->d_ir_keys, c->d_ir_masks, c->d_ir_locs, c->d_ir_slots, c->d_ir_counter, c->ir_cap - 1 };
   const uint32_t parity = c->ir_parity;
@@ -2305,6 +2506,73 @@ grp_debug_tile_states(grp_ctx* c, uint64_t n_tiles, uint32_t* ids, uint8_t* assi
 }
 
 // ---- measurement ---------------------------------------------------------------
+
+// k_decide on caller-provided tile summaries (inspection: the decision kernel against the
+// reference's own smoothing / stretch / flank vectors, tests/golden/reference_funcs.json)
+int
+grp_debug_decide(grp_ctx* c, uint32_t n_reads, const uint64_t* tile0, const grp_tile_summary* tiles, const grp_id_count* lists, uint64_t n_lists, const grp_decide_params* dp, grp_read_decision* out, uint32_t* ids_out, uint8_t* asg_out)
+{
+  if (!c || !tile0 || !dp || !out || n_reads == 0) {
+    return set_err(c, GRP_ERR_INVALID, "grp_debug_decide: bad argument");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t nt = tile0[n_reads];
+  uint64_t* d_tile0 = nullptr;
+  grp_tile_summary* d_tiles = nullptr;
+  grp_id_count* d_lists = nullptr;
+  uint32_t* d_ids = nullptr;
+  uint8_t* d_asg = nullptr;
+  uint64_t* d_scr = nullptr;
+  grp_read_decision* d_out = nullptr;
+  auto cleanup = [&] {
+    (void)hipFree(d_tile0);
+    (void)hipFree(d_tiles);
+    (void)hipFree(d_lists);
+    (void)hipFree(d_ids);
+    (void)hipFree(d_asg);
+    (void)hipFree(d_scr);
+    (void)hipFree(d_out);
+  };
+#define DBG_TRY(expr)                                                                                                  \
+  do {                                                                                                                 \
+    hipError_t e_ = (expr);                                                                                            \
+    if (e_ != hipSuccess) {                                                                                            \
+      cleanup();                                                                                                       \
+      return set_err(c, GRP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                                   \
+    }                                                                                                                  \
+  } while (0)
+  DBG_TRY(hipMalloc(&d_tile0, (n_reads + 1) * sizeof(uint64_t)));
+  DBG_TRY(hipMalloc(&d_tiles, std::max<uint64_t>(nt, 1) * sizeof(grp_tile_summary)));
+  DBG_TRY(hipMalloc(&d_lists, std::max<uint64_t>(n_lists, 1) * sizeof(grp_id_count)));
+  DBG_TRY(hipMalloc(&d_ids, std::max<uint64_t>(nt, 1) * 4));
+  DBG_TRY(hipMalloc(&d_asg, std::max<uint64_t>(nt, 1)));
+  DBG_TRY(hipMalloc(&d_scr, std::max<uint64_t>(nt, 1) * 8));
+  DBG_TRY(hipMalloc(&d_out, n_reads * sizeof(grp_read_decision)));
+  DBG_TRY(hipMemcpy(d_tile0, tile0, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (nt) {
+    DBG_TRY(hipMemcpy(d_tiles, tiles, nt * sizeof(grp_tile_summary), hipMemcpyHostToDevice));
+  }
+  if (n_lists) {
+    DBG_TRY(hipMemcpy(d_lists, lists, n_lists * sizeof(grp_id_count), hipMemcpyHostToDevice));
+  }
+  DBG_TRY(hipMemset(d_ids, 0, std::max<uint64_t>(nt, 1) * 4));
+  DBG_TRY(hipMemset(d_asg, 0, std::max<uint64_t>(nt, 1)));
+  DevReads rd{};
+  rd.tile0 = d_tile0;
+  k_decide<<<dim3(n_reads), dim3(DECIDE_THREADS), 0, c->stream>>>(rd, 0, n_reads, *dp, d_tiles, d_lists, std::max<uint64_t>(n_lists, 1), d_ids, d_asg, d_scr, d_out);
+  DBG_TRY(hipGetLastError());
+  DBG_TRY(hipStreamSynchronize(c->stream));
+  DBG_TRY(hipMemcpy(out, d_out, n_reads * sizeof(grp_read_decision), hipMemcpyDeviceToHost));
+  if (ids_out && nt) {
+    DBG_TRY(hipMemcpy(ids_out, d_ids, nt * 4, hipMemcpyDeviceToHost));
+  }
+  if (asg_out && nt) {
+    DBG_TRY(hipMemcpy(asg_out, d_asg, nt, hipMemcpyDeviceToHost));
+  }
+#undef DBG_TRY
+  cleanup();
+  return GRP_OK;
+}
 
 int
 grp_set_timing(grp_ctx* c, int enabled)

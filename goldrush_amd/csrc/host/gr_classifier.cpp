@@ -250,12 +250,34 @@ Classifier::stripe_reads() const
   return stripe;
 }
 
+// The engine takes at most 2^22 tiles per synchronous / pipelined window or batch (a HIP grid holds
+// fewer than 2^32 work-items) and 2^30 per streaming window: windows are capped in reads by the
+// plan, this caps them in tiles (small -t, very long reads).  At least one read.
+uint32_t
+Classifier::clamp_tiles(uint32_t pos, uint32_t S, uint64_t max_tiles) const
+{
+  if (const char* e = getenv("GRP_MAX_WINDOW_TILES")) { // tests: a tiny cap
+    max_tiles = std::min<uint64_t>(max_tiles, std::max(1l, atol(e)));
+  }
+  if (S <= 1 || tile0_[(size_t)pos + S] - tile0_[pos] <= max_tiles) {
+    return S;
+  }
+  const auto first = tile0_.begin() + pos;
+  const auto it = std::upper_bound(first, first + S + 1, tile0_[pos] + max_tiles); // first prefix value beyond the cap
+  return (uint32_t)std::max<ptrdiff_t>(1, (it - first) - 1);
+}
+
 int
 Classifier::launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, StreamFlight& f)
 {
+  S = clamp_tiles(pos, S, 1ull << 30);
   const grp_decide_params dp{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
   const gr_read_decision* dec = nullptr;
-  int rc = vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, stripe_reads(), p_.world, p_.rank, &dec);
+  // One rank, golden-path mode: a window that waits where it parks and applies the insert the
+  // host commits inside its own launch (stream_round); a silver-path run resets the ID array
+  // at a rollover, several ranks share a window in stripes: those windows end where they park.
+  const bool resumable = vt_.stream_begin_resumable && vt_.stream_insert && vt_.insert_read && p_.world == 1 && !p_.silver_path && !resume_disabled_;
+  int rc = resumable ? vt_.stream_begin_resumable(ctx_, reads, base_ + pos, S, &dp, slot, &dec) : vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, stripe_reads(), p_.world, p_.rank, &dec);
   if (rc != GRP_OK) {
     err_ = std::string("stream_begin: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
     return rc;
@@ -265,6 +287,9 @@ Classifier::launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, 
   f.S = S;
   f.slot = slot;
   f.dec = dec;
+  f.resumable = resumable;
+  f.gen = 1;
+  f.ins_posted = false;
   ++n_windows_;
   return GRP_OK;
 }
@@ -278,25 +303,45 @@ Classifier::end_stream(StreamFlight& f)
   f.active = false;
   uint32_t decided = 0;
   int rc = vt_.stream_end(ctx_, f.slot, &decided);
-  if (rc != GRP_OK) {
+  if (rc == 1) {
+    // the launch ended without the insert it had been handed (its workgroups were not all
+    // resident — a shared device — or an abort overtook it): nothing was inserted; the classic
+    // call applies it, stream-ordered behind whatever is queued, and windows end at inserts again
+    resume_disabled_ = true;
+    rc = GRP_OK;
+    if (f.ins_posted) {
+      rc = vt_.insert_read(ctx_, rg_.reads, f.ins_read, f.ins_ts, f.ins_te, p_.block_size, f.ins_first_id, f.ins_off);
+      if (rc != GRP_OK) {
+        err_ = std::string("insert_read: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+      }
+    }
+  } else if (rc != GRP_OK) {
     err_ = std::string("stream_end: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
     return rc;
   }
+  f.ins_posted = false;
   n_queried_ += decided;
-  return GRP_OK;
+  return rc;
 }
 
+static constexpr uint64_t kMaxWindowTiles = 1ull << 22; // grp_classify_reads / grp_query_tiles / grp_batch_* take no more per call
+
 // spin until record j of the window is complete
+static constexpr int STREAM_LOST = 100;
+
 int
 Classifier::wait_record(const StreamFlight& f, uint32_t j)
 {
   const uint32_t* flag = &f.dec[j].pad;
   uint32_t spins = 0;
   bool finished_seen = false;
-  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == 0) {
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != f.gen) { // (an older generation: decided before an insert in front of the read, stale)
     __builtin_ia32_pause();
     if ((++spins & 0x3FFFu) == 0) {
       if (finished_seen) {
+        if (f.ins_posted) {
+          return STREAM_LOST; // the launch gave up on the insert it was handed: end_stream applies it
+        }
         err_ = "streaming window finished without deciding one of its reads";
         return GRP_ERR_STATE;
       }
@@ -539,6 +584,29 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       }
       return;
     }
+    if (stream_ins_) {
+      // the record comes out of a streaming window that is parked at it: the launch applies the
+      // insert itself and carries on behind the read (no launch boundary)
+      StreamFlight& f = *stream_ins_;
+      uint32_t gen = 0;
+      if (vt_.stream_insert(ctx_, f.slot, base_ + r, ts, te_excl, block, ids_inserted_, id_offset, &gen) == GRP_OK) {
+        f.gen = gen;
+        f.ins_posted = true;
+        f.ins_read = base_ + r;
+        f.ins_ts = ts;
+        f.ins_te = te_excl;
+        f.ins_first_id = ids_inserted_;
+        f.ins_off = id_offset;
+        stream_ins_ok_ = true;
+        ++n_stream_inserts_;
+        return;
+      }
+      // this window cannot: end the launches, then the insert behind them as before
+      (void)vt_.stream_abort(ctx_, scur_.slot);
+      if (snext_.active) {
+        (void)vt_.stream_abort(ctx_, snext_.slot);
+      }
+    }
     int e = vt_.insert_read(ctx_, reads, base_ + r, ts, te_excl, block, ids_inserted_, id_offset);
     if (e != GRP_OK) {
       rc = e;
@@ -596,7 +664,12 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
         }
       }
       ids_inserted_ = ids_inserted_ + (uint32_t)((te - ts) / block);
-      last_insert_shares_id_ = (te - ts + 1) % block == 0; // its last block holds ID ids_inserted_ + 1, the next insert's first
+      // The blocks of a trimmed read are numbered from (0 + 1) / block (:1048-1049) while the counter
+      // advances by (te - ts) / block (:1074): with block == 1 the LAST block holds ID ids_inserted_ + 1,
+      // the next insert's first; with block > 1 block j holds first + j and the counter ends on the
+      // last of them, nothing is shared (the rule used to be (te - ts + 1) % block == 0,
+      // exact but needlessly wide — every probe with ID == floor then took the slow look-up)
+      last_insert_shares_id_ = block == 1;
       // new_seq = seq.substr(ts*tile, te == nt-1 ? npos : (te-ts+1)*tile)
       const uint64_t off = (uint64_t)ts * tile;
       uint64_t n_out = len - off;
@@ -662,15 +735,24 @@ Classifier::commit_one(uint32_t r, const gr_read_decision& d, int& rc, bool engi
   return ins;
 }
 
-void
+int
 Classifier::drop_streams()
 {
-  for (StreamFlight* f : { &scur_, &snext_ }) {
+  int rc = GRP_OK;
+  for (StreamFlight* f : { &scur_, &snext_ }) { // both flags first: the window queued behind must not start on a state an insert is still missing from
     if (f->active) {
       (void)vt_.stream_abort(ctx_, f->slot);
-      (void)end_stream(*f);
     }
   }
+  for (StreamFlight* f : { &scur_, &snext_ }) {
+    if (f->active) {
+      const int e = end_stream(*f);
+      if (rc == GRP_OK) {
+        rc = e;
+      }
+    }
+  }
+  return rc;
 }
 
 // Decision of read j of the streaming window scur_.  One rank reads its own record as
@@ -719,7 +801,8 @@ Classifier::can_loop() const
   // opt-in (GRP_LOOP=on / force): over a whole C2 stream the loop did not beat the host-driven
   // windows (head 27.2 s against 25.0 s, profiles/README.md), see want_loop
   const char* e = getenv("GRP_LOOP");
-  return vt_.loop_begin && vt_.loop_stop && vt_.loop_poll && vt_.loop_end && !loop_disabled_ && e && (!strcmp(e, "on") || !strcmp(e, "force"));
+  const bool built = p_.hash_num == 1 || p_.hash_num == 3 || p_.hash_num == 5; // the frozen path is compiled for these seed counts (round 3)
+  return vt_.loop_begin && vt_.loop_stop && vt_.loop_poll && vt_.loop_end && !loop_disabled_ && built && e && (!strcmp(e, "on") || !strcmp(e, "force"));
 }
 
 // Measured on MI355X (tools/loop_matrix.sh, profiles/r02_loop_matrix.txt): the device-side
@@ -841,7 +924,7 @@ Classifier::batch_round(uint32_t& pos)
     const char* e = getenv("GRP_BATCH_MAX");
     return e ? (uint32_t)std::max(2l, atol(e)) : 4096u;
   }();
-  const uint32_t B = std::min<uint32_t>({ batch_reads_, n - pos, p_.max_window, max_batch });
+  const uint32_t B = clamp_tiles(pos, std::min<uint32_t>({ batch_reads_, n - pos, p_.max_window, max_batch }), kMaxWindowTiles);
   const grp_decide_params dp{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
   auto fail = [&](const char* what, int rc) {
     err_ = std::string(what) + ": " + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
@@ -898,7 +981,7 @@ Classifier::batch_round(uint32_t& pos)
   uint32_t ids = ids_inserted_;
   uint64_t bases = inserted_bases_;
   uint32_t cnt = B, first_ins = UINT32_MAX;
-  // the last insert so far was a trimmed read whose last ID block carries the next first ID (:1048-1049, :1074)
+  // the last insert so far was a trimmed read whose last ID block carries the next first ID (:1048-1049, :1074; block == 1 only)
   bool shared_id = last_insert_shares_id_;
   // a batch holds 2^26 (frame, seed) records (frames in units of 256 per tile): the window ends
   // in front of the insert that would not fit (the engine refuses larger batches, GRP_ERR_NOMEM)
@@ -943,7 +1026,7 @@ Classifier::batch_round(uint32_t& pos)
       bins_.push_back(grp_batch_insert{ base_ + pos + j, ts, te_excl, ids + 1, off });
       bfirst_[j] = ids + 1;
       ids = next_ids;
-      shared_id = off == 1 && (te_excl - ts) % block == 0;
+      shared_id = off == 1 && block == 1; // see commit(): only ID blocks of one tile share the next insert's first ID
       if (first_ins == UINT32_MAX) {
         first_ins = j;
       }
@@ -1226,11 +1309,13 @@ Classifier::stream_round(uint32_t& pos)
   const uint32_t S = scur_.S;
   group_base_ = UINT32_MAX;
   uint32_t j = 0;
-  bool stale = false, redo = false;
+  bool stale = false, redo = false, lost = false, next_refused = false;
   // developer hook: where the time of an insert goes (launch call, first record, drain + insert)
   static const bool trace_abort = getenv("GRP_TRACE_ABORT") != nullptr;
-  static double t_launch = 0, t_first = 0, t_commit_ins = 0, t_drop = 0;
-  static uint64_t n_rounds = 0, n_stale = 0;
+  static double t_launch = 0, t_first = 0, t_commit_ins = 0, t_drop = 0, t_resume = 0;
+  static uint64_t n_rounds = 0, n_stale = 0, n_resumed = 0;
+  std::chrono::steady_clock::time_point tr_resume0{};
+  bool tr_resume_pending = false;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
   const auto tr_after_launch = now();
@@ -1242,10 +1327,16 @@ Classifier::stream_round(uint32_t& pos)
     // the next window goes in shortly before this launch runs out of work: early
     // enough to start back to back (the GPU is at most ~100 reads ahead of the host),
     // late enough that an insert rarely has to abort it
-    if (!snext_.active && j + 256 * p_.world >= S && pos + S < n) {
+    if (!snext_.active && !next_refused && j + 256 * p_.world >= S && pos + S < n) {
       const Plan plan = window_plan();
       if (plan.streaming) { // queued right behind the current launch
         rc = launch_stream(rg_.reads, pos + S, std::min<uint32_t>(plan.S, n - pos - S), scur_.slot ^ 1u, snext_);
+        if (rc == GRP_ERR_BUSY) {
+          // the engine would have to wait for the device (buffers to grow) while the current window
+          // may be waiting for this thread: the next window is begun when this one has ended
+          rc = GRP_OK;
+          next_refused = true;
+        }
         if (rc != GRP_OK) {
           break;
         }
@@ -1253,11 +1344,23 @@ Classifier::stream_round(uint32_t& pos)
     }
     gr_read_decision d;
     rc = stream_decision(j, d);
+    if (rc == STREAM_LOST) {
+      rc = GRP_OK;
+      lost = true;
+      break;
+    }
     if (rc != GRP_OK) {
       break;
     }
     if (trace_abort && j == 0) {
       t_first += secs(tr_after_launch, now());
+    }
+    if (trace_abort && tr_resume_pending) { // the first record behind an insert the launch applied itself
+      tr_resume_pending = false;
+      t_resume += secs(tr_resume0, now());
+      if ((++n_resumed & 511u) == 0) {
+        fprintf(stderr, "in-launch inserts %llu: %.1f us from the insert record to the first record behind it\n", (unsigned long long)n_resumed, 1e6 * t_resume / n_resumed);
+      }
     }
     d.pad = 0;
     p_redo_ += (1.0 / 64.0) * ((d.kind == 0 ? 1.0 : 0.0) - p_redo_);
@@ -1265,16 +1368,33 @@ Classifier::stream_round(uint32_t& pos)
       redo = true; // needs the worst-case table / a larger arena: synchronous path below
       break;
     }
+    bool resume = false;
     if (d.kind == DEC_INSERT_WHOLE || d.kind == DEC_INSERT_TRIMMED) {
-      // everything behind this read is stale: stop the launches before the insert is queued
-      (void)vt_.stream_abort(ctx_, scur_.slot);
-      if (snext_.active) {
-        (void)vt_.stream_abort(ctx_, snext_.slot);
+      // One rank, golden-path mode: the parked launch applies the insert itself and carries on
+      // behind the read (commit() hands it over).  Otherwise everything behind this read is
+      // stale: stop the launches before the insert is queued.
+      resume = scur_.resumable;
+      if (resume) {
+        stream_ins_ = &scur_;
+        stream_ins_ok_ = false;
+      } else {
+        (void)vt_.stream_abort(ctx_, scur_.slot);
+        if (snext_.active) {
+          (void)vt_.stream_abort(ctx_, snext_.slot);
+        }
+        stale = true;
       }
-      stale = true;
     }
     const auto tr_c0 = now();
     commit_one(pos + j, d, rc);
+    if (resume) {
+      stream_ins_ = nullptr;
+      stale = !stream_ins_ok_; // the engine refused (the launches were aborted, the insert queued behind them)
+      if (trace_abort && !stale) {
+        tr_resume0 = now();
+        tr_resume_pending = true;
+      }
+    }
     if (trace_abort && stale) {
       t_commit_ins += secs(tr_c0, now());
     }
@@ -1287,9 +1407,12 @@ Classifier::stream_round(uint32_t& pos)
     }
   }
   pos += j;
-  if (rc != GRP_OK || stale || finished_ || redo) {
+  if (rc != GRP_OK || stale || finished_ || redo || lost) {
     const auto tr_d0 = now();
-    drop_streams();
+    const int drc = drop_streams();
+    if (rc == GRP_OK) {
+      rc = drc;
+    }
     if (trace_abort) {
       t_drop += secs(tr_d0, now());
       ++n_stale;
@@ -1330,7 +1453,7 @@ Classifier::window_round(uint32_t& pos)
     S = cur.S;
   } else {
     const Plan plan = window_plan();
-    S = std::min<uint32_t>(plan.S, n - pos);
+    S = clamp_tiles(pos, std::min<uint32_t>(plan.S, n - pos), kMaxWindowTiles);
     debug_window_pos_ = pos;
     rc = plan.pipelined ? launch_window(rg_.reads, pos, S, 0, cur) : query_window(rg_.reads, rg_.lens, pos, S);
     if (rc != GRP_OK) {
@@ -1340,7 +1463,7 @@ Classifier::window_round(uint32_t& pos)
   if (cur.active) {
     if (pos + S < n) {
       const Plan plan = window_plan();
-      const uint32_t S2 = std::min<uint32_t>(plan.S, n - pos - S);
+      const uint32_t S2 = clamp_tiles(pos + S, std::min<uint32_t>(plan.S, n - pos - S), kMaxWindowTiles);
       if (plan.pipelined && (S2 >= 16 * p_.world || S2 == plan.S)) {
         rc = launch_window(rg_.reads, pos + S, S2, cur.slot ^ 1u, next_);
       }
@@ -1421,7 +1544,12 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
     }
   }
   abandon_window(next_);
-  drop_streams();
+  {
+    const int drc = drop_streams();
+    if (rc == GRP_OK) {
+      rc = drc;
+    }
+  }
   if (rc != GRP_OK) {
     return rc;
   }

@@ -63,7 +63,12 @@ private:
     bool active = false;
     uint32_t pos = 0, S = 0, slot = 0;
     const gr_read_decision* dec = nullptr;
+    bool resumable = false;   // begun with stream_begin_resumable: it waits where it parks, for stream_abort or stream_insert
+    uint32_t gen = 1;         // generation (.pad) of the records that count: +1 per insert the window applied itself
+    bool ins_posted = false;  // an insert was handed to the launch (stream_insert); its arguments, should the launch end without it:
+    uint32_t ins_read = 0, ins_ts = 0, ins_te = 0, ins_first_id = 0, ins_off = 0;
   };
+  uint32_t clamp_tiles(uint32_t pos, uint32_t S, uint64_t max_tiles) const;
   int launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, StreamFlight& f);
   int end_stream(StreamFlight& f);
   int wait_record(const StreamFlight& f, uint32_t j);
@@ -76,7 +81,7 @@ private:
   bool want_batch() const; // the insert rate calls for windows committed as batches
   int batch_round(uint32_t& pos);
   void batch_feedback(uint32_t reads, uint32_t bad, double exposure);
-  void drop_streams();
+  int drop_streams();
   int stream_decision(uint32_t j, gr_read_decision& d);
   int stream_round(uint32_t& pos);
   int window_round(uint32_t& pos);
@@ -132,6 +137,10 @@ private:
   } rg_;
   Flight next_;              // pipelined: the window after the current one
   StreamFlight scur_, snext_; // streaming: the current window and the one queued behind it
+  StreamFlight* stream_ins_ = nullptr; // set while stream_round commits an insert record: commit() hands the insert to this window's launch
+  bool stream_ins_ok_ = false;         // ... and the engine took it
+  bool resume_disabled_ = false;       // a launch could not apply an insert itself (shared device): windows end at inserts again
+  uint64_t n_stream_inserts_ = 0;
   uint32_t group_base_ = UINT32_MAX; // first read of the stripe group held in stripe_recv_
 
   // scratch

@@ -62,6 +62,12 @@ hip_engine()
     return grp_fastq_pack(static_cast<grp_ctx*>(c), static_cast<grp_fastq*>(fq), sel, n, reinterpret_cast<grp_reads**>(out));
   };
   vt.fastq_free = [](void* fq) { grp_fastq_free(static_cast<grp_fastq*>(fq)); };
+  vt.stream_begin_resumable = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, const grp_read_decision** dec) {
+    return grp_classify_stream_begin_resumable(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, slot, dec);
+  };
+  vt.stream_insert = [](void* c, uint32_t slot, uint32_t read, uint32_t ts, uint32_t te, uint32_t block, uint32_t first_id, uint32_t off, uint32_t* gen) {
+    return grp_classify_stream_insert(static_cast<grp_ctx*>(c), slot, read, ts, te, block, first_id, off, gen);
+  };
   return vt;
 }
 

@@ -5,7 +5,8 @@
 // and two PCIe copies per call (RCCL is used where bulk data moves: the bit vectors).
 // Every rank writes its block into the round's buffer, then publishes the round number in
 // its own cache line; readers spin on the round numbers.  Two buffers alternate, so a rank
-// one round ahead never overwrites what a slower rank still reads.
+// one round ahead never overwrites what a slower rank still reads.  A waiting rank notices a
+// peer that has detached (its close()) or stopped answering (GRP_SHM_TIMEOUT_S, default 120 s).
 #include "../../../include/grpath_host.h"
 
 #include <atomic>
@@ -13,7 +14,10 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <thread>
 
@@ -25,13 +29,14 @@
 namespace {
 
 constexpr uint64_t kSlot = 1u << 20;     // bytes per rank and buffer
-constexpr uint64_t kHeader = 64 * 1024;  // one 64-byte line per rank: [0] round, [1] attached, [2] detached
-constexpr uint64_t kMagic = 0x47525053484d3031ull; // "GRPSHM01"
+constexpr uint64_t kHeader = 64 * 1024;  // one 64-byte line per rank: [0] round, [1] token of the attached rank, [2] detached, [3] rank 0's echo of the token
+constexpr uint64_t kMagic = 0x47525053484d3032ull; // "GRPSHM02"
 
 struct Shm
 {
   uint32_t world = 0, rank = 0;
   uint64_t round = 0;
+  double timeout_s = 120.0; // what a rank waits for a peer inside gr_shm_allgather
   std::string path;
   uint8_t* base = nullptr;
   size_t size = 0;
@@ -40,10 +45,27 @@ struct Shm
   uint8_t* data(uint32_t buf, uint32_t r) const { return base + kHeader + ((size_t)buf * world + r) * kSlot; }
 };
 
+// a value no earlier run has used: what a rank proves its presence with (a file left behind by a
+// crashed run holds the tokens and echoes of THAT run — they never match)
+uint64_t
+fresh_token()
+{
+  uint64_t t = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+  t ^= (uint64_t)getpid() << 32;
+  timespec ts{};
+  clock_gettime(CLOCK_REALTIME, &ts);
+  t ^= (uint64_t)ts.tv_nsec * 0x9E3779B97F4A7C15ull + (uint64_t)ts.tv_sec;
+  return t | 1ull; // never 0
+}
+
 } // namespace
 
 extern "C" {
 
+// Rank 0 builds the file under a private name and renames it into place (an atomic replacement of
+// whatever a crashed run left under the key); every other rank opens the path, announces itself
+// with a fresh token and waits for rank 0's echo of it — a stale file never echoes, and a rank
+// that mapped one notices that the path has changed hands and opens it again.
 void*
 gr_shm_allgather_open(uint32_t world, uint32_t rank, const char* key, double timeout_s)
 {
@@ -55,63 +77,108 @@ gr_shm_allgather_open(uint32_t world, uint32_t rank, const char* key, double tim
   s->rank = rank;
   s->path = std::string("/dev/shm/grp_") + key;
   s->size = kHeader + 2 * (size_t)world * kSlot;
+  if (const char* e = getenv("GRP_SHM_TIMEOUT_S")) {
+    s->timeout_s = std::max(0.05, atof(e));
+  }
   const auto t0 = std::chrono::steady_clock::now();
   auto expired = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s; };
-  int fd = -1;
-  if (rank == 0) {
-    (void)unlink(s->path.c_str()); // a stale file of a crashed run
-    fd = open(s->path.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
-    if (fd < 0 || ftruncate(fd, (off_t)s->size) != 0) {
-      if (fd >= 0) {
-        close(fd);
-      }
-      delete s;
-      return nullptr;
+  auto fail = [&]() -> void* {
+    if (s->base) {
+      munmap(s->base, s->size);
     }
-  } else {
-    for (;;) { // rank 0 creates and sizes the file
-      fd = open(s->path.c_str(), O_RDWR);
-      struct stat st;
-      if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size == s->size) {
-        break;
-      }
-      if (fd >= 0) {
-        close(fd);
-        fd = -1;
-      }
-      if (expired()) {
-        delete s;
-        return nullptr;
-      }
-      std::this_thread::sleep_for(std::chrono::milliseconds(1));
-    }
-  }
-  void* p = mmap(nullptr, s->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (p == MAP_FAILED) {
     delete s;
     return nullptr;
-  }
-  s->base = static_cast<uint8_t*>(p);
+  };
   if (rank == 0) {
+    const std::string tmp = s->path + ".new." + std::to_string((long)getpid());
+    (void)unlink(tmp.c_str());
+    int fd = open(tmp.c_str(), O_RDWR | O_CREAT | O_EXCL, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)s->size) != 0) { // a new file: all zeros
+      if (fd >= 0) {
+        close(fd);
+        (void)unlink(tmp.c_str());
+      }
+      return fail();
+    }
+    void* p = mmap(nullptr, s->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+      (void)unlink(tmp.c_str());
+      return fail();
+    }
+    s->base = static_cast<uint8_t*>(p);
     s->magic()->store(kMagic, std::memory_order_release);
-  } else {
-    while (s->magic()->load(std::memory_order_acquire) != kMagic) { // not a stale file: rank 0 of THIS run has set it up
-      if (expired()) {
-        munmap(s->base, s->size);
-        delete s;
-        return nullptr;
+    if (rename(tmp.c_str(), s->path.c_str()) != 0) {
+      (void)unlink(tmp.c_str());
+      return fail();
+    }
+    // everybody is attached before the first round: echo every token
+    s->word(0, 1)->store(fresh_token(), std::memory_order_release);
+    for (uint32_t r = 1; r < world; ++r) {
+      uint64_t tok;
+      while ((tok = s->word(r, 1)->load(std::memory_order_acquire)) == 0) {
+        if (expired()) {
+          (void)unlink(s->path.c_str());
+          return fail();
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+      s->word(r, 3)->store(tok, std::memory_order_release);
+    }
+    return s;
+  }
+  const uint64_t token = fresh_token();
+  for (;;) {
+    if (expired()) {
+      return fail();
+    }
+    int fd = open(s->path.c_str(), O_RDWR);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size != s->size) { // rank 0 has not put the file there yet
+      if (fd >= 0) {
+        close(fd);
       }
       std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      continue;
     }
+    void* p = mmap(nullptr, s->size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+      return fail();
+    }
+    s->base = static_cast<uint8_t*>(p);
+    bool ours = false, retry = false;
+    if (s->magic()->load(std::memory_order_acquire) == kMagic) {
+      s->word(rank, 1)->store(token, std::memory_order_release);
+      while (!expired()) {
+        if (s->word(rank, 3)->load(std::memory_order_acquire) == token) {
+          ours = true; // rank 0 of THIS run has seen this process
+          break;
+        }
+        struct stat now;
+        if (stat(s->path.c_str(), &now) != 0 || now.st_ino != st.st_ino || now.st_dev != st.st_dev) {
+          retry = true; // the file mapped here was a crashed run's: rank 0 has replaced it meanwhile
+          break;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+    } else {
+      retry = true;
+    }
+    if (ours) {
+      break;
+    }
+    munmap(s->base, s->size);
+    s->base = nullptr;
+    if (!retry) {
+      return fail();
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
   }
-  s->word(rank, 1)->store(1, std::memory_order_release);
-  for (uint32_t r = 0; r < world; ++r) { // everybody is attached before the first round
-    while (s->word(r, 1)->load(std::memory_order_acquire) != 1) {
+  for (uint32_t r = 1; r < world; ++r) { // every rank has been echoed before the first round
+    while (s->word(r, 3)->load(std::memory_order_acquire) == 0) {
       if (expired()) {
-        munmap(s->base, s->size);
-        delete s;
-        return nullptr;
+        return fail();
       }
       std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
@@ -131,13 +198,21 @@ gr_shm_allgather(void* handle, const void* send, uint64_t bytes, void* recv)
   const uint32_t b = (uint32_t)(s->round & 1);
   memcpy(s->data(b, s->rank), send, bytes);
   s->word(s->rank, 0)->store(s->round, std::memory_order_release);
+  const auto t0 = std::chrono::steady_clock::now();
   for (uint32_t r = 0; r < s->world; ++r) {
     uint64_t spins = 0;
     while (s->word(r, 0)->load(std::memory_order_acquire) < s->round) {
       if (++spins > 200000) {
         std::this_thread::yield(); // a rank that is far behind: do not burn its core
-        if (spins > 2000000000ull) {
-          return -2;
+        if ((spins & 0x3FFu) == 0) {
+          // a peer that has left (an error on its side: its close marks it detached) or that has
+          // not answered for timeout_s: report it instead of spinning for hours
+          if (s->word(r, 2)->load(std::memory_order_acquire) != 0) {
+            return -3;
+          }
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > s->timeout_s) {
+            return -2;
+          }
         }
       } else {
 #if defined(__x86_64__)

@@ -80,6 +80,8 @@ VT_TYPES = [
     ("fastq_records", C.CFUNCTYPE(C.c_int, _vp, _vp)),
     ("fastq_pack", C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_uint32, C.POINTER(_vp))),
     ("fastq_free", C.CFUNCTYPE(None, _vp)),
+    ("stream_begin_resumable", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp)),
+    ("stream_insert", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32))),
 ]
 
 
@@ -234,7 +236,7 @@ def hip_engine_vt() -> grp_engine_vt:
     lib = native.load()
     vt = grp_engine_vt()
     alias = {"classify_begin": "classify_reads_begin", "classify_end": "classify_reads_end", "stream_begin": "classify_stream_begin_striped",
-             "stream_abort": "classify_stream_abort", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end",
+             "stream_abort": "classify_stream_abort", "stream_insert": "classify_stream_insert", "stream_begin_resumable": "classify_stream_begin_resumable", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end",
              "loop_begin": "commit_loop_begin", "loop_stop": "commit_loop_stop", "loop_poll": "commit_loop_poll", "loop_end": "commit_loop_end",
              "batch_insert": "batch_insert_reads"}
     for name, ftype in VT_TYPES:

@@ -20,7 +20,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(LIB_DIR, "libgrpath_hip.so")
 
 GRP_OK = 0
-GRP_ERR_INVALID, GRP_ERR_NO_DEVICE, GRP_ERR_HIP, GRP_ERR_STATE, GRP_ERR_NOMEM = -1, -2, -3, -4, -5
+GRP_ERR_INVALID, GRP_ERR_NO_DEVICE, GRP_ERR_HIP, GRP_ERR_STATE, GRP_ERR_NOMEM, GRP_ERR_BUSY = -1, -2, -3, -4, -5, -6
 GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_LOOP, GRP_K_QUERY_LAT, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
 KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard", "loop", "query_latency")
 GRP_LOOP_RUNNING, GRP_LOOP_DONE, GRP_LOOP_ROLLOVER, GRP_LOOP_HANDBACK, GRP_LOOP_STOPPED, GRP_LOOP_TIMEOUT = 0, 1, 2, 3, 4, 5
@@ -105,6 +105,9 @@ SIGNATURES = {
     "grp_classify_stream_abort": (C.c_int, [_vp, C.c_uint32]),
     "grp_classify_stream_poll": (C.c_int, [_vp, C.c_uint32]),
     "grp_classify_stream_end": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "grp_debug_decide": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint64, C.POINTER(grp_decide_params), _vp, _vp, _vp]),
+    "grp_classify_stream_begin_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "grp_classify_stream_insert": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "grp_commit_loop_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_loop_params), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "grp_commit_loop_stop": (C.c_int, [_vp]),
     "grp_commit_loop_poll": (C.c_int, [_vp]),
@@ -409,6 +412,20 @@ class Engine:
         self._check(self.lib.grp_classify_reads(self._h, batch._h, first, count, C.byref(dp), _ptr(out)))
         return out
 
+    def debug_decide(self, tile0, tiles, lists, threshold=10, unassigned_min=5, assigned_max=1):
+        """k_decide on given tile summaries (grp_debug_decide): -> (decisions, per-tile ids, per-tile assigned flags)."""
+        tile0 = np.ascontiguousarray(tile0, dtype=np.uint64)
+        n = tile0.size - 1
+        tiles = np.ascontiguousarray(tiles, dtype=tile_summary_dtype)
+        lists = np.ascontiguousarray(lists, dtype=id_count_dtype)
+        nt = int(tile0[-1])
+        out = np.zeros(n, dtype=decision_dtype)
+        ids = np.zeros(max(nt, 1), dtype=np.uint32)
+        asg = np.zeros(max(nt, 1), dtype=np.uint8)
+        dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
+        self._check(self.lib.grp_debug_decide(self._h, n, _ptr(tile0), _ptr(tiles), _ptr(lists), lists.size, C.byref(dp), _ptr(out), _ptr(ids), _ptr(asg)))
+        return out, ids[:nt], asg[:nt]
+
     def classify_begin(self, batch: ReadBatch, first: int, count: int, slot: int, threshold=10, unassigned_min=5, assigned_max=1):
         """Enqueue query + decision of a window in slot 0 / 1 (asynchronous)."""
         if first < 0 or count < 0 or first + count > batch.n_reads:
@@ -429,13 +446,16 @@ class Engine:
         return out
 
     def stream_begin(self, batch: ReadBatch, first: int, count: int, slot: int, threshold=10, unassigned_min=5, assigned_max=1,
-                     stripe: int = 0, n_owners: int = 1, owner: int = 0) -> np.ndarray:
+                     stripe: int = 0, n_owners: int = 1, owner: int = 0, resumable: bool = False) -> np.ndarray:
         """Start a streaming window; returns a live view of the decision records
-        (record j is complete once its "pad" field reads 1).  n_owners > 1: only the
+        (record j is complete once its "pad" field reads 1 — the record's generation, +1 per
+        stream_insert of a resumable window).  n_owners > 1: only the
         stripes of `owner` are worked on (grp_classify_stream_begin_striped)."""
         dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
         ptr = C.c_void_p()
-        if n_owners > 1:
+        if resumable:
+            self._check(self.lib.grp_classify_stream_begin_resumable(self._h, batch._h, first, count, C.byref(dp), slot, C.byref(ptr)))
+        elif n_owners > 1:
             self._check(self.lib.grp_classify_stream_begin_striped(self._h, batch._h, first, count, C.byref(dp), slot, stripe, n_owners, owner, C.byref(ptr)))
         else:
             self._check(self.lib.grp_classify_stream_begin(self._h, batch._h, first, count, C.byref(dp), slot, C.byref(ptr)))
@@ -455,8 +475,18 @@ class Engine:
 
     def stream_end(self, slot: int) -> int:
         n = C.c_uint32()
-        self._check(self.lib.grp_classify_stream_end(self._h, slot, C.byref(n)))
+        rc = self.lib.grp_classify_stream_end(self._h, slot, C.byref(n))
+        if rc == 1:
+            raise RuntimeError("grp_classify_stream_end: the insert posted last was not applied by the launch")
+        self._check(rc)
         return n.value
+
+    def stream_insert(self, slot: int, read_idx: int, tile_start: int, tile_end: int, block: int, first_id: int, id_offset: int) -> int:
+        """The window in `slot` applies this insert itself (it is parked at the read's record) and
+        carries on behind the read; returns the generation (.pad) of the records that follow."""
+        gen = C.c_uint32()
+        self._check(self.lib.grp_classify_stream_insert(self._h, slot, read_idx, tile_start, tile_end, block, first_id, id_offset, C.byref(gen)))
+        return gen.value
 
     def commit_loop(self, batch: ReadBatch, first: int, count: int, block: int = 10, threshold=10, unassigned_min=5, assigned_max=1, silver=False,
                     target_bases: int = 0, ids_inserted: int = 0, inserted_bases: int = 0, max_depth: int = 0, whole_tiles: bool = False):

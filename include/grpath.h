@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GRP_ABI_VERSION 2
+#define GRP_ABI_VERSION 3
 
 typedef enum
 {
@@ -50,7 +50,9 @@ typedef enum
   GRP_ERR_NO_DEVICE = -2, /* no usable HIP device (no CPU fallback exists) */
   GRP_ERR_HIP = -3,       /* a HIP runtime call failed */
   GRP_ERR_STATE = -4,     /* call not valid in the current phase */
-  GRP_ERR_NOMEM = -5
+  GRP_ERR_NOMEM = -5,
+  GRP_ERR_BUSY = -6       /* not now: the call would have to wait for the device while a resumable streaming
+                             window may be waiting for the caller (grp_classify_stream_begin*); repeat it later */
 } grp_status;
 
 typedef struct grp_ctx grp_ctx;     /* one miBF + its device, stream, scratch */
@@ -299,7 +301,8 @@ int grp_classify_reads_end(grp_ctx* ctx, uint32_t slot, grp_read_decision* decis
  * publishes the 32-byte record in host-visible memory at once, so the host commits
  * read j while the same launch works on the reads behind it.
  *   _begin  enqueues the window in slot 0 / 1 and returns the array the records appear
- *           in: (*decisions)[j].pad becomes 1 (release) when record j is complete;
+ *           in: (*decisions)[j].pad becomes non-zero (release) when record j is complete — the
+ *           record's generation, 1 until the window has applied an insert (_insert below);
  *           kind == 0 then means "take this read through grp_classify_reads" (a tile
  *           needed the worst-case table or the list arena was too small).  Records
  *           complete roughly in read order.  The window PARKS ITSELF behind the first
@@ -313,8 +316,31 @@ int grp_classify_reads_end(grp_ctx* ctx, uint32_t slot, grp_read_decision* decis
  *   _poll   1 when the launch has finished, 0 while it runs (a host spinning on .pad
  *           calls it now and then to notice a failed launch).
  *   _end    waits for the launch, frees the slot; *reads_decided = records completed.
+ *   _begin_resumable / _insert (round 3; one rank): a window begun this way does NOT end where
+ *           it parks — its workgroups wait for the host's word, _abort or _insert (one of the two
+ *           MUST follow a parking record; a window nobody answers gives up after ~30 s).
+ *           _insert: the host has committed the insert record the window parked at — read `read_idx`, tiles [tile_start, tile_end),
+ *           the block IDs of grp_insert_read — and the LAUNCH applies it: every workgroup collects
+ *           the read's ranks, they wait for each other, replay them (exactly grp_insert_read's
+ *           result), and the window carries on with the read behind it, without a launch
+ *           boundary (goldrush_path.cpp:988-990 / :1048-1049 followed by the next process_read).
+ *           Records of the reads behind `read_idx` that were complete before are stale: the
+ *           records that count carry .pad == *generation (1 for a fresh window, +1 per insert).
+ *           While a resumable window is in flight no call of this context may wait for the device
+ *           (the window may be waiting for the caller): a _begin in the other slot that would have
+ *           to grow its buffers returns GRP_ERR_BUSY instead — begin it when the window has ended.
+ *           GRP_ERR_STATE: this window cannot (not resumable; more than 64 ID blocks; GRP_STREAM_RESUME=off)
+ *           — the caller aborts it and issues grp_insert_read as before.
+ *   _end    returns 1 instead of GRP_OK when the launch ended WITHOUT applying the insert posted
+ *           last (an abort overtook it, or the launch's workgroups were not all resident — a
+ *           shared device — and the first grid-wide wait ran into its time limit): nothing was
+ *           inserted, the caller issues grp_insert_read for it.
  * Stream-ordered like every other call: an insert issued after _abort runs behind the
  * (draining) window.
+ * Memory ordering inside the launch (gfx942 / gfx950 only, checked at _begin): summaries, lists
+ * and counters move between workgroups as relaxed agent-scope accesses + s_waitcnt; the ID
+ * words an in-launch insert writes reach the queries behind it through a release fence, a
+ * grid-wide wait and an acquire fence (buffer_wbl2 / buffer_inv).
  */
 int grp_classify_stream_begin(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, const grp_read_decision** decisions);
 /* The same for a window shared by several ranks (one process per GPU, replicated miBF):
@@ -323,6 +349,8 @@ int grp_classify_stream_begin(grp_ctx* ctx, const grp_reads* reads, uint32_t fir
  * stripes stay at pad = 0), in window order, so that the ranks can exchange finished
  * stripes while their launches run.  n_owners = 1 is grp_classify_stream_begin. */
 int grp_classify_stream_begin_striped(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions);
+int grp_classify_stream_begin_resumable(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, const grp_read_decision** decisions);
+int grp_classify_stream_insert(grp_ctx* ctx, uint32_t slot, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset, uint32_t* generation);
 int grp_classify_stream_abort(grp_ctx* ctx, uint32_t slot);
 int grp_classify_stream_poll(grp_ctx* ctx, uint32_t slot);
 int grp_classify_stream_end(grp_ctx* ctx, uint32_t slot, uint32_t* reads_decided);
@@ -451,8 +479,9 @@ int grp_insert_read(grp_ctx* ctx,
  *      OWN insert — id_floor[j] = the first ID read j could allocate.  IDs grow with the read
  *      order: a probe returning an ID > id_floor[j] was written by read j or a later one, an ID
  *      equal to it by one of those or by the last ID block of the trimmed read in front
- *      (goldrush_path.cpp:1048-1049 / :1074: when (trim_end - trim_start + 1) is a multiple of
- *      block_tiles that block carries the next read's first ID): the caller sets bit 31 of
+ *      (goldrush_path.cpp:1048-1049 / :1074: with block_tiles == 1 the blocks of a trimmed read are
+ *      numbered first + 1 ... while the counter advances to first + (trim_end - trim_start), so the
+ *      last block carries the next read's first ID; with larger blocks nothing is shared): the caller sets bit 31 of
  *      id_floor[j] where the last insert in front of read j — inside the batch or before it — was
  *      such a read, and the engine then looks up who wrote the rank — hits / misses included;
  *      Any range of the window's reads may be asked for ([first, first + count) with first >= the
@@ -529,6 +558,12 @@ int grp_debug_locate(grp_ctx* ctx, const uint64_t* x, uint64_t n, uint64_t m, ui
 /* per-tile IDs / assigned flags after the smoothing passes of the LAST
  * grp_classify_reads window (tiles in window order); n_tiles = tiles of that window */
 int grp_debug_tile_states(grp_ctx* ctx, uint64_t n_tiles, uint32_t* ids, uint8_t* assigned);
+
+/* the decision kernel alone (the device instantiation of the host's threshold / smoothing passes /
+ * longest stretch / flank test, goldrush_path.cpp:628-889, :195-233, :341-527, :960-1040) on
+ * caller-provided tile summaries: read j owns tiles [tile0[j], tile0[j+1]) (tile0 has n_reads + 1
+ * entries), list_off indexes `lists`.  ids_out / asg_out (may be NULL): per-tile state after the passes. */
+int grp_debug_decide(grp_ctx* ctx, uint32_t n_reads, const uint64_t* tile0, const grp_tile_summary* tiles, const grp_id_count* lists, uint64_t n_lists, const grp_decide_params* params, grp_read_decision* decisions_out, uint32_t* ids_out, uint8_t* asg_out);
 
 /* ---- measurement ------------------------------------------------------------ */
 enum

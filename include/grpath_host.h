@@ -63,6 +63,11 @@ typedef struct
   int (*fastq_records)(void* fq, grp_fastq_record* out);
   int (*fastq_pack)(void* ctx, void* fq, const uint32_t* sel, uint32_t n_sel, void** reads_out);
   void (*fastq_free)(void* fq);
+  /* optional (both, with the stream_* members; round 3): a window that waits where it parks and
+   * applies the insert the host commits itself, grp_classify_stream_begin_resumable / _insert;
+   * stream_end may then return 1 (the insert posted last was not applied) */
+  int (*stream_begin_resumable)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, const grp_read_decision** decisions);
+  int (*stream_insert)(void* ctx, uint32_t slot, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset, uint32_t* generation);
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""ORACLE — TEST INFRASTRUCTURE ONLY (build-time helper of `make -C oracle ref`).
+
+Cuts the self-contained, libstdc++-only pieces of the reference's hot-path host logic out of
+/root/reference/goldrush_path — by text anchors, at build time, in the build container — into
+the git-ignored oracle/_ref/extract/*.inc, where oracle/ref_funcs_shim.cpp (ours: headers,
+`using namespace std`, extern "C" wrappers; no reference code) includes them and g++ compiles
+the reference's own lines.  Nothing of this is ever copied into the repository.
+
+  goldrush_path.cpp   log_tile_states        whole function
+                      sort_by_sec            whole function
+                      find_longest_stretch   whole function
+                      eval_flanks            whole function
+                      calc_num_assigned_tiles  the function's TAIL: everything behind the per-tile
+                                             query loop (threshold test, smoothing passes P1-P10,
+                                             final count, `return`, closing brace).  The loop in
+                                             front of it needs MIBloomFilter / sdsl and cannot be
+                                             built here; the shim opens a function whose
+                                             parameters carry the names of the locals the tail uses.
+                      main                   the hash-universe statements (HASH_UNIVERSE_COEFFICIENT ...)
+  MIBloomFilter.hpp   calcOptimalSize        whole (static member) function
+"""
+import os
+import re
+import sys
+
+
+def cut_function(text, signature_re):
+    """A top-level function: from the line(s) of its return type / name to the closing brace in column 0."""
+    m = re.search(signature_re, text, re.M)
+    assert m, signature_re
+    start = m.start()
+    end = text.index("\n}\n", m.end()) + 3
+    return text[start:end]
+
+
+def main():
+    ref, out = sys.argv[1], sys.argv[2]
+    os.makedirs(out, exist_ok=True)
+    gp = open(os.path.join(ref, "goldrush_path.cpp")).read()
+    mb = open(os.path.join(ref, "MIBloomFilter.hpp")).read()
+    pieces = {}
+    pieces["log_tile_states"] = cut_function(gp, r"^void\nlog_tile_states\(")
+    pieces["sort_by_sec"] = cut_function(gp, r"^bool\nsort_by_sec\(")
+    pieces["find_longest_stretch"] = cut_function(gp, r"^std::pair<ssize_t, ssize_t>\nfind_longest_stretch\(")
+    pieces["eval_flanks"] = cut_function(gp, r"^std::tuple<bool, size_t, size_t>\neval_flanks\(")
+    # tail of calc_num_assigned_tiles
+    f0 = re.search(r"^size_t\ncalc_num_assigned_tiles\(", gp, re.M)
+    assert f0
+    f_end = gp.index("\n}\n", f0.end()) + 3
+    body = gp[f0.start():f_end]
+    anchor = "    tiles_assigned_all_id_vec[i] = id_counts_vec;\n  }\n"
+    assert body.count(anchor) == 1
+    tail = body[body.index(anchor) + len(anchor):]
+    assert tail.lstrip().startswith("for (size_t i = 0; i < num_tiles; ++i) {") and tail.rstrip().endswith("return num_assigned_tiles;\n}")
+    assert "miBF" not in tail and "hashed_values" not in tail
+    pieces["smooth_tail"] = tail
+    # hash universe statements of main()
+    a = gp.index("      static const uint8_t BASES = 4;")
+    b = gp.index("hash_universe_base * HASH_UNIVERSE_COEFFICIENT * opt::hash_num;", a)
+    b = gp.index("\n", b) + 1
+    pieces["hash_universe"] = gp[a:b]
+    # calcOptimalSize
+    a = mb.index("  static size_t calcOptimalSize(size_t entries,")
+    b = mb.index("\n  }\n", a) + 5
+    pieces["calc_optimal_size"] = mb[a:b]
+    assert "log(1.0 - occupancy)" in pieces["calc_optimal_size"]
+    for name, txt in pieces.items():
+        with open(os.path.join(out, name + ".inc"), "w") as fp:
+            fp.write(txt)
+
+
+if __name__ == "__main__":
+    main()

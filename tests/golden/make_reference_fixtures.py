@@ -4,7 +4,7 @@ first-party translation units of /root/reference that build from their own sourc
 (oracle/Makefile, target `ref` -> oracle/_ref/): spaced_seeds.cpp (make_seed_pattern),
 calc_phred_average.cpp (calc_phred_average, sum_phred) and opt.cpp (process_options).
 Run in the build container (the GPU box has no /root/reference); the JSON holds inputs
-and the reference's outputs only."""
+and the reference's outputs only.  Round 3: reference_funcs.json too (make_funcs below)."""
 import ctypes as C
 import json
 import os
@@ -68,6 +68,51 @@ def main():
     with open(os.path.join(HERE, "reference_parts.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("seeds %d, phred %d, options %d" % (len(out["seeds"]), len(out["phred"]), len(out["options"])))
+    make_funcs()
+
+
+def make_funcs():
+    """tests/golden/reference_funcs.json: outputs of the reference's own find_longest_stretch,
+    eval_flanks, smoothing passes (tail of calc_num_assigned_tiles), calcOptimalSize and
+    hash-universe lines (oracle/_ref/libref_funcs.so) on seeded tile states."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ref_funcs
+
+    rf = ref_funcs.RefFuncs()
+    out = {"source": "bcgsc/goldrush goldrush_path/goldrush_path.cpp (find_longest_stretch, eval_flanks, sort_by_sec, tail of calc_num_assigned_tiles, "
+                     "hash-universe statements of main) and MIBloomFilter.hpp (calcOptimalSize): the reference's own lines, cut out at build time and compiled (oracle/Makefile `ref`)",
+           "tiles": [], "sizes": []}
+    rng = np.random.default_rng(20261003)
+    cases = []
+    for i in range(260):
+        n = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 14, 15, 16, 20, 25, 31, 60]))
+        ids, lists = ref_funcs.random_tiles(rng, n, wrap=(i % 13 == 0))
+        cases.append((ids, lists, int(rng.choice([10, 10, 10, 3, 11]))))
+    for n in (3, 4, 6, 9, 14, 15, 16, 25):  # run patterns: edges of P5 / P10 / find_longest_stretch
+        pats = ref_funcs.run_patterns(n)
+        for pat in pats[:: max(1, len(pats) // 22)]:
+            for step in (0, 1):
+                ids, lists = ref_funcs.tiles_from_pattern(pat, step=step)
+                cases.append((ids, lists, 10))
+    for ids, lists, x in cases:
+        o_ids, o_b, na = rf.smooth_tiles(ids, lists, x)
+        ls, le = rf.find_longest_stretch(o_b)
+        good, ts, te = rf.eval_flanks(ls, le, o_ids)
+        out["tiles"].append({"x": x, "ids": ids, "lists": [[list(e) for e in l] for l in lists], "out_ids": [int(v) for v in o_ids], "out_bools": [int(v) for v in o_b],
+                             "assigned": na, "stretch": [ls, le], "flanks": [int(good), ts, te]})
+    for w, g, h in [(16, 1_000_000, 3), (16, 100_000_000, 3), (16, 3_000_000_000, 3), (16, 3_000_000_000, 5), (12, 3_100_000_000, 3), (14, 123_456_789, 7), (16, 3_000_000_000, 1),
+                    (10, 5_000_000, 2), (16, 2_147_483_648, 3), (16, 2_147_483_649, 3), (20, 10**12, 8), (4, 7, 1)]:
+        u = rf.hash_universe(w, g, h)
+        for occ in (0.1, 0.05, 0.37, 0.5):
+            out["sizes"].append({"w": w, "g": g, "h": h, "universe": u, "occupancy": occ, "m": rf.calc_optimal_size(u, 1, occ)})
+    for entries in (1, 63, 64, 1000, 3_000_000, 6_442_450_944, 10_737_418_240, 2**40 + 12345):
+        for hn, occ in ((1, 0.1), (3, 0.1), (1, 0.9)):
+            out["sizes"].append({"entries": entries, "hash_num": hn, "occupancy": occ, "m": rf.calc_optimal_size(entries, hn, occ)})
+    with open(os.path.join(HERE, "reference_funcs.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("tile states %d, sizes %d" % (len(out["tiles"]), len(out["sizes"])))
 
 
 if __name__ == "__main__":

@@ -9,9 +9,14 @@ from goldrush_amd import host, native
 
 
 class OracleEngine:
-    def __init__(self, orc, m, seeds, tile, k, reads, pipelined=False, streaming=False, redo_every=0, batching=False, batch_crowded_above=0):
+    def __init__(self, orc, m, seeds, tile, k, reads, pipelined=False, streaming=False, redo_every=0, batching=False, batch_crowded_above=0,
+                 resume=False, resume_refuse_every=0, resume_lost_every=0):
         self.pipelined = pipelined
         self.streaming = streaming
+        self.resume = resume                          # stream_insert: the window applies the insert itself and carries on
+        self.resume_refuse_every = resume_refuse_every  # every n-th stream_insert is refused (GRP_ERR_STATE)
+        self.resume_lost_every = resume_lost_every      # every n-th one is accepted but never applied (the launch "timed out")
+        self.n_stream_inserts = self.n_stream_refused = self.n_stream_lost = 0
         self.batching = batching      # classify_reads / insert_read / batch_* (windows committed as batches)
         self.batch_crowded_above = batch_crowded_above  # batches of more inserts are refused (GRP_ERR_NOMEM)
         self.n_batches = self.n_batch_undone = self.n_batch_refused = 0
@@ -37,7 +42,12 @@ class OracleEngine:
         vt = host.grp_engine_vt()
         types = dict(host.VT_TYPES)
 
+        def _window(first, count):  # the largest window (in tiles) any call was handed
+            nt = sum(len(self.reads[r]) // self.tile for r in range(first, first + count))
+            self.max_window_tiles = max(getattr(self, "max_window_tiles", 0), nt)
+
         def query_tiles(ctx, reads, first, count, tiles_p, lists_p, cap, used_p, stats_p):
+            _window(first, count)
             self.n_queries += count
             res = []
             for r in range(first, first + count):
@@ -66,6 +76,7 @@ class OracleEngine:
         def classify_begin(ctx, reads, first, count, dp_p, slot):
             assert slot in (0, 1) and slot not in slots, "slot busy"
             dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
+            _window(first, count)
             self.n_queries += count
             self.n_begun += 1
             out = []
@@ -94,6 +105,7 @@ class OracleEngine:
         # streaming windows: all records are complete at _begin (decided against the state
         # at that moment, like a launch that ran to the end before the host looked)
         streams = {}
+        stream_info = {}
 
         def _decide(r, dp):
             res = self.mf.query_read(self.reads[r])
@@ -103,6 +115,16 @@ class OracleEngine:
             d.hits = sum(int(x[3][1]) for x in res)
             d.misses = sum(int(x[3][2]) for x in res)
             return d
+
+        def stream_begin_resumable(ctx, reads, first, count, dp_p, slot, out_pp):
+            if streams and self.resume_refuse_every:  # a window behind one in flight: "not now" every other time (GRP_ERR_BUSY)
+                self.n_busy_calls = getattr(self, "n_busy_calls", 0) + 1
+                if self.n_busy_calls % 2 == 1:
+                    self.n_stream_busy = getattr(self, "n_stream_busy", 0) + 1
+                    return native.GRP_ERR_BUSY
+            rc = stream_begin(ctx, reads, first, count, dp_p, slot, 0, 1, 0, out_pp)
+            stream_info[slot]["resumable"] = True
+            return rc
 
         def stream_begin(ctx, reads, first, count, dp_p, slot, stripe, n_owners, owner, out_pp):
             assert slot in (0, 1) and slot not in streams and slot not in slots, "slot busy"
@@ -125,7 +147,60 @@ class OracleEngine:
             self.n_queries += sum(1 for j in range(count) if arr[j].pad)
             self.n_streams += 1
             streams[slot] = (arr, count)
+            stream_info[slot] = dict(first=first, dp=(dp.threshold, dp.unassigned_min, dp.assigned_max), striped=n_owners > 1, gen=1, lost=False, resumable=False)
             C.cast(out_pp, C.POINTER(C.c_void_p))[0] = C.addressof(arr)
+            return 0
+
+        # grp_classify_stream_insert: the parked window applies the insert and decides the reads behind
+        # it again (new generation in .pad); older records stay where they are, stale
+        def stream_insert(ctx, slot, read_idx, ts, te, block, first_id, off, gen_p):
+            assert slot in streams
+            info = stream_info[slot]
+            arr, count = streams[slot]
+            x = read_idx - info["first"]
+            assert 0 <= x < count and arr[x].pad == info["gen"] and arr[x].kind in (2, 4), "the window is not parked at this read"
+            self.n_stream_insert_calls = getattr(self, "n_stream_insert_calls", 0) + 1
+            if not info["resumable"] or (self.resume_refuse_every and self.n_stream_insert_calls % self.resume_refuse_every == 0):
+                self.n_stream_refused += 1
+                return native.GRP_ERR_STATE
+            info["gen"] += 1
+            C.cast(gen_p, C.POINTER(C.c_uint32))[0] = info["gen"]
+            if self.resume_lost_every and self.n_stream_insert_calls % self.resume_lost_every == 0:
+                self.n_stream_lost += 1
+                info["lost"] = True  # accepted, never applied: no record of the new generation will come
+                return 0
+            insert_read(ctx, None, read_idx, ts, te, block, first_id, off)
+            self.n_stream_inserts += 1
+            dp = native.grp_decide_params(*info["dp"], 0)
+            parked = False
+            for j in range(x + 1, count):
+                if parked:
+                    break
+                self.n_stream_records = getattr(self, "n_stream_records", 0) + 1
+                if self.redo_every and self.n_stream_records % self.redo_every == 0:
+                    arr[j] = host.gr_read_decision()
+                    self.n_redo += 1
+                else:
+                    arr[j] = _decide(info["first"] + j, dp)
+                arr[j].pad = info["gen"]
+                self.n_queries += 1
+                parked = arr[j].kind in (0, 2, 4)
+            # a window queued behind this one has not started (it runs when this launch ends): it
+            # will see the insert — its records, computed eagerly at _begin here, are decided again
+            for o, (oarr, ocount) in streams.items():
+                if o == slot:
+                    continue
+                oinfo = stream_info[o]
+                assert oinfo["gen"] == 1 and oinfo["resumable"]
+                odp = native.grp_decide_params(*oinfo["dp"], 0)
+                parked = False
+                for j in range(ocount):
+                    oarr[j] = host.gr_read_decision()
+                    if parked:
+                        continue
+                    oarr[j] = _decide(oinfo["first"] + j, odp)
+                    oarr[j].pad = 1
+                    parked = oarr[j].kind in (0, 2, 4)
             return 0
 
         def stream_abort(ctx, slot):
@@ -139,11 +214,12 @@ class OracleEngine:
 
         def stream_end(ctx, slot, n_p):
             arr, count = streams.pop(slot)
+            info = stream_info.pop(slot)
             self._keep_last = getattr(self, "_keep_last", {})
             self._keep_last[slot] = arr  # valid until the slot's next _begin
             if n_p:
                 C.cast(n_p, C.POINTER(C.c_uint32))[0] = count
-            return 0
+            return 1 if info["lost"] else 0
 
         def insert_tiles(ctx, reads, ri, ts, te, id_):
             self.mf.insert_read_tiles(self.reads[ri], ts, te, id_)
@@ -160,6 +236,7 @@ class OracleEngine:
         def classify_reads(ctx, reads, first, count, dp_p, out_p):
             dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
             arr = C.cast(out_p, C.POINTER(host.gr_read_decision))
+            _window(first, count)
             self.n_queries += count
             for j in range(count):
                 arr[j] = _decide(first + j, dp)
@@ -238,6 +315,8 @@ class OracleEngine:
             impl.update({"classify_begin": classify_begin, "classify_end": classify_end})
         if self.streaming:
             impl.update({"stream_begin": stream_begin, "stream_abort": stream_abort, "stream_poll": stream_poll, "stream_end": stream_end})
+            if self.resume:
+                impl.update({"stream_begin_resumable": stream_begin_resumable, "stream_insert": stream_insert, "insert_read": insert_read})
         if self.batching:
             impl.update({"classify_reads": classify_reads, "insert_read": insert_read, "batch_insert": batch_insert, "batch_classify": batch_classify,
                          "batch_undo": batch_undo, "batch_end": batch_end})

@@ -46,3 +46,92 @@ def test_shared_memory_allgather_three_ranks():
         p.join(timeout=30)
     assert res == [(r, True) for r in range(world)]
     assert not os.path.exists("/dev/shm/grp_" + key)
+
+
+def _late_worker(rank, world, key, delay, q):
+    import time
+
+    sys.path.insert(0, ROOT)
+    from goldrush_amd import host
+
+    time.sleep(delay)
+    hl = host.load()
+    h = hl.gr_shm_allgather_open(world, rank, key.encode(), 30.0)
+    ok = bool(h)
+    got = None
+    if ok:
+        src = np.full(64, 0x10 + rank, dtype=np.uint8)
+        dst = np.zeros(64 * world, dtype=np.uint8)
+        ok = hl.gr_shm_allgather(h, src.ctypes.data_as(C.c_void_p), 64, dst.ctypes.data_as(C.c_void_p)) == 0
+        got = [int(dst[p * 64]) for p in range(world)]
+        hl.gr_shm_allgather_close(h)
+    q.put((rank, ok, got))
+
+
+def test_stale_file_of_a_crashed_run_is_never_joined():
+    """a run killed under `timeout` leaves /dev/shm/grp_<key> behind with its header
+    complete (every rank attached, round counters high, 0xEE payload).  The next run uses the same
+    key; rank 1 comes first and finds the stale file — it must end up in rank 0's NEW file."""
+    world = 2
+    key = "stale_%d" % os.getpid()
+    path = "/dev/shm/grp_" + key
+    size = 64 * 1024 + 2 * world * (1 << 20)
+    buf = np.full(size, 0xEE, dtype=np.uint8)
+    hdr = buf[: 64 * 1024].view(np.uint64)
+    hdr[:] = 0
+    hdr[0] = 0x47525053484d3032  # the header of a finished hand-shake
+    for r in range(world):
+        hdr[8 + r * 8 + 0] = 1000  # round
+        hdr[8 + r * 8 + 1] = 0x1234 + r  # token
+        hdr[8 + r * 8 + 3] = 0x1234 + r  # echo
+    buf.tofile(path)
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_late_worker, args=(1, world, key, 0.0, q)), ctx.Process(target=_late_worker, args=(0, world, key, 1.5, q))]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(timeout=30)
+        assert res == [(0, True, [0x10, 0x11]), (1, True, [0x10, 0x11])], res
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+def _leaver(rank, world, key, q):
+    sys.path.insert(0, ROOT)
+    from goldrush_amd import host
+
+    hl = host.load()
+    h = hl.gr_shm_allgather_open(world, rank, key.encode(), 30.0)
+    rc = None
+    if h:
+        src = np.zeros(32, dtype=np.uint8)
+        dst = np.zeros(32 * world, dtype=np.uint8)
+        rc = hl.gr_shm_allgather(h, src.ctypes.data_as(C.c_void_p), 32, dst.ctypes.data_as(C.c_void_p))
+        if rank == 0:  # the second round: rank 1 has left (an error on its side)
+            rc = hl.gr_shm_allgather(h, src.ctypes.data_as(C.c_void_p), 32, dst.ctypes.data_as(C.c_void_p))
+        hl.gr_shm_allgather_close(h)
+    q.put((rank, rc))
+
+
+def test_a_peer_that_left_is_reported_at_once():
+    """a rank waiting for a peer that has closed its handle gets an error (-3), not a
+    spin of hours."""
+    import time
+
+    world = 2
+    key = "leave_%d" % os.getpid()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_leaver, args=(r, world, key, q)) for r in range(world)]
+    t0 = time.time()
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert res == {0: -3, 1: 0}, res
+    assert time.time() - t0 < 60

@@ -101,6 +101,45 @@ def test_streaming_windows_match_serial_loop(oracle, native, max_window, redo_ev
     assert cls.state()["reads_committed"] == len(exp)
 
 
+@pytest.mark.parametrize("max_window,redo_every,refuse_every,lost_every", [(4096, 0, 0, 0), (32, 0, 0, 0), (40, 7, 0, 0), (4096, 0, 3, 0), (4096, 0, 0, 4), (32, 5, 2, 5)])
+def test_streaming_windows_apply_inserts_themselves(oracle, native, max_window, redo_every, refuse_every, lost_every, monkeypatch):
+    """Round 3: a streaming window parked at an insert record takes the insert from the host
+    (stream_insert) and carries on behind the read — records of an older generation are never
+    committed; an engine that refuses, or a launch that ends without applying the insert, falls
+    back to the classic abort + insert_read."""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine, serial_reference
+
+    monkeypatch.setenv("GRP_STREAM", "force")
+    monkeypatch.setenv("GRP_BATCH", "off")
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    reads = _workload()
+    m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block)  # golden-path mode: one path, no rollover
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads, streaming=True, redo_every=redo_every, resume=True, resume_refuse_every=refuse_every, resume_lost_every=lost_every)
+    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, max_window=max_window)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    skipped = np.zeros(len(reads), dtype=np.uint32)
+    skipped[5] = 2
+    cls.run(None, lens, skipped_before=skipped)
+    assert _strip(cls.commits) == exp
+    assert [c[8:10] for c in cls.commits] == [c[8:10] for c in _hits_misses(oracle, m, seeds, tile, k, reads, block, silver=False)]
+    assert np.array_equal(eng.mf.ids(), mf_ref.ids()) and np.array_equal(eng.mf.counts(), mf_ref.counts())
+    kinds = [e[1] for e in exp]
+    assert kinds.count(2) + kinds.count(4) >= 8
+    assert eng.n_stream_inserts >= (3 if not lost_every else 2)
+    if not (redo_every or refuse_every or lost_every) and max_window == 4096:
+        assert eng.n_streams == 1 and eng.n_stream_aborts == 0  # ONE launch for the whole range, inserts and all
+    assert (eng.n_stream_refused > 0) == (refuse_every > 0) and (eng.n_stream_lost > 0) == (lost_every > 0)
+    if lost_every:
+        # after a launch that could not apply its insert the windows end at inserts again
+        assert eng.n_stream_lost == 1
+    if refuse_every and max_window < 60:
+        assert getattr(eng, "n_stream_busy", 0) >= 1  # a next window the engine could not begin yet: begun when the current one had ended
+    assert cls.state()["reads_committed"] == len(exp)
+
+
 @pytest.mark.parametrize("max_window,crowded", [(2, 0), (5, 0), (64, 0), (4096, 0), (64, 3)])
 def test_batched_windows_match_serial_loop(oracle, native, max_window, crowded, monkeypatch):
     """Windows committed as batches (batch_insert / _classify / _undo / _end): the window's
@@ -135,13 +174,63 @@ def test_batched_windows_match_serial_loop(oracle, native, max_window, crowded, 
         assert eng.n_batch_refused >= 1 and st["batches_refused"] == eng.n_batch_refused
 
 
-def _hits_misses(oracle, m, seeds, tile, k, reads, block):
+@pytest.mark.parametrize("max_window", [5, 4096])
+def test_batches_with_one_tile_id_blocks(oracle, native, max_window, monkeypatch):
+    """-b 1: the only geometry where the last ID block of a trimmed read carries the next insert's
+    first ID (goldrush_path.cpp:1048-1049 / :1074) — the ambiguous floor of the batches' second
+    query (bit 31 of id_floor) is exercised against the serial loop."""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine, serial_reference
+
+    monkeypatch.setenv("GRP_BATCH", "force")
+    tile, k, h, block = 500, 22, 3, 1
+    seeds = default_seeds(h)
+    reads = _workload()
+    m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block)
+    assert sum(1 for e in exp if e[1] == 4) >= 3  # trimmed inserts in front of other inserts
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads, batching=True)
+    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, max_window=max_window)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    cls.run(None, lens, skipped_before=np.zeros(len(reads), dtype=np.uint32))
+    assert _strip(cls.commits) == exp
+    assert np.array_equal(eng.mf.ids(), mf_ref.ids()) and np.array_equal(eng.mf.counts(), mf_ref.counts())
+    assert cls.state()["batches"] >= 2
+
+
+@pytest.mark.parametrize("mode", ["sync", "pipeline", "batch"])
+def test_windows_are_capped_in_tiles(oracle, native, mode, monkeypatch):
+    """the engine takes 2^22 tiles per window; the classifier caps its windows in reads —
+    a small -t or very long reads must shrink the window, not abort the run (cap forced to 25 tiles here)."""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine, serial_reference
+
+    for key, val in {"sync": {"GRP_PIPELINE": "off", "GRP_BATCH": "off"}, "pipeline": {"GRP_PIPELINE": "force", "GRP_BATCH": "off"}, "batch": {"GRP_BATCH": "force"}}[mode].items():
+        monkeypatch.setenv(key, val)
+    monkeypatch.setenv("GRP_MAX_WINDOW_TILES", "25")
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    reads = _workload()
+    m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=90_000, max_paths=2)
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads, pipelined=(mode == "pipeline"), batching=(mode == "batch"))
+    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, target_bases=90_000, max_paths=2, silver_path=True, max_window=4096)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    cls.run(None, lens, skipped_before=np.zeros(len(reads), dtype=np.uint32))
+    assert _strip(cls.commits) == exp
+    assert 0 < eng.max_window_tiles <= max(25, max(len(r) // tile for r in reads))
+
+
+def _hits_misses(oracle, m, seeds, tile, k, reads, block, silver=True):
     """hits / misses per committed read as a window-of-one classifier reports them"""
     from goldrush_amd import host
     from oracle_engine import OracleEngine
 
     eng = OracleEngine(oracle, m, seeds, tile, k, reads)
-    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=3, target_bases=90_000, max_paths=2, silver_path=True, max_window=1)
+    if silver:
+        cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=3, target_bases=90_000, max_paths=2, silver_path=True, max_window=1)
+    else:
+        cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=3, max_window=1)
     lens = np.array([len(r) for r in reads], dtype=np.uint32)
     cls.run(None, lens, skipped_before=np.zeros(len(reads), dtype=np.uint32))
     return cls.commits

@@ -291,3 +291,32 @@ def test_batch_api_refuses_misuse(native):
     ids, counts = eng.export_ids()
     assert np.array_equal(ids, ids0) and np.array_equal(counts, counts0)
     eng.close()
+
+
+def test_batches_with_one_tile_id_blocks(oracle, native, monkeypatch):
+    """-b 1: the only geometry where a trimmed read's last ID block carries the next
+    insert's first ID — the ambiguous-floor path of k_query<.., VER> (bit 31 of id_floor, the
+    writer looked up through the batch's records) against the oracle's serial loop."""
+    from goldrush_amd import host, synth
+    from oracle_engine import serial_reference
+
+    monkeypatch.setenv("GRP_BATCH", "force")
+    tile, k, h, block = 500, 22, 3, 1
+    seeds = default_seeds(h)
+    g = synth.random_genome(150_000, 21)
+    reads = [r[1] for r in synth.make_reads(g, 120, mean_len=5000, min_len=3500, seed=22, max_len=9000)]
+    m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block)
+    assert sum(1 for e in exp if e[1] == 4) >= 5
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    assert eng.finalize() == mf_ref.pop
+    cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, k=k, h=h)
+    cls.run(b._h, b.lens)
+    eng.sync()
+    assert [c[:8] for c in cls.commits] == exp
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
+    assert cls.state()["batches"] >= 2
+    eng.close()
