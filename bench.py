@@ -250,6 +250,7 @@ def main():
     ap.add_argument("--stream-batch", type=int, default=-1, help="reads per resident batch (0: all resident; default: 2 M when the packed reads exceed 100 GB)")
     ap.add_argument("--max-window", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline-shaped", action="store_true", help="skip aux.pipeline_shaped (the silver-mode pass over the same reads after the timed region)")
     ap.add_argument("--trace", action="store_true", help="per-slice timing / speculation statistics on stderr")
     ap.add_argument("--no-kernel-timing", action="store_true", help="developer: no HIP events around the launches (roofline fields become meaningless)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo for single-GPU plumbing tests)")
@@ -513,15 +514,28 @@ def main():
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the
         # per-probe figure comes from the committed rocprofv3 --pmc pass of the same kernel
         # (newest profiles/r*_pmc_summary.json, tools/pmc_round.sh: TCC_EA0_RDREQ x 64 B = FETCH_SIZE x 1024 B)
+        # Only a summary taken on a build of exactly these engine sources counts (the summary stores
+        # the sha256 of goldrush_amd/csrc, tools/pmc_summary.py): a kernel change without a new PMC
+        # pass reports traffic: null instead of silently keeping the old bytes per probe.
         traffic = bytes_per_probe_moved = None
         pmc_file = _newest_profile("r*_pmc_summary.json")
+        pmc_note = "no PMC summary under profiles/"
         try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("_pmc_hash", os.path.join(ROOT, "tools", "csrc_hash.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
             pmc = json.load(open(pmc_file))
-            key = "k_query_all_variants" if "k_query_all_variants" in pmc else "k_query<3, 2, 0>"
-            bytes_per_probe_moved = pmc[key]["hbm_bytes_per_probe"]
-            traffic = bytes_per_probe_moved * probes_per_launch
-        except Exception:
-            pass
+            if pmc.get("csrc_tree_sha256") == mod.csrc_tree_hash():
+                key = "k_query_all_variants" if "k_query_all_variants" in pmc else "k_query<3, 2, 0>"
+                bytes_per_probe_moved = pmc[key]["hbm_bytes_per_probe"]
+                traffic = bytes_per_probe_moved * probes_per_launch
+                pmc_note = "rocprofv3 PMC passes of this build (%s), scaled by probes" % os.path.basename(pmc_file)
+            else:
+                pmc_note = "stale: %s was taken on other engine sources (csrc tree hash differs); run tools/pmc_round.sh" % os.path.basename(pmc_file)
+        except Exception as e:
+            pmc_note = "no usable PMC summary (%s)" % e
         # the measured random-64-B-line ceiling of this memory system (tools/gather_bench.hip,
         # archived by tools/profile_round.sh); null until a profile round has stored it
         ceiling = ceiling_file = None
@@ -561,7 +575,7 @@ def main():
                        "reads": n_reads, "reads_timed": reads_done, "reads_per_step": per_step, "genome": G, "filter_bits": m, "pop": pop,
                        "parallelism": ("one GPU: windows committed as batches where >= ~1 % of the reads insert, streaming windows elsewhere" if world == 1 else "replicated miBF on %d GPUs: batches on every rank where >= ~1 %% of the reads insert, streaming windows striped over the ranks elsewhere (32-B decisions all-gathered per stripe group)" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC pass of the same kernel, %s, scaled by probes)" % (os.path.basename(pmc_file) if pmc_file else "none"),
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch: " + pmc_note,
                          "kernel": kernel_name,
                          "launches": kq["launches"], "avg_launch_ms": avg_ms,
                          "probes_per_launch": probes_per_launch, "bytes_per_probe": 128,
@@ -583,7 +597,7 @@ def main():
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors OR-merged as reduce-scatter (all-to-all + OR) + all-gather" % world, "synth_s": t_synth,
                     "read_batches": rs.n_batches, "synth_in_timed_region_s": rs.synth_s - synth_before,
                     "warmup_s": t_warm, "warmup_mode": "%d steps of 512 reads on a throw-away engine (G=2e6)" % a.warmup,
-                    "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit", "batches", "batches_undone", "batch_reads")},
+                    "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit", "batches", "batches_undone", "batch_reads", "batches_fused", "stream_inserts")},
                     "query_Gprobes_per_s": gprobes,
                     "query_kernel_s": kq_s, "decide_kernel_s": ks["decide"]["ms"] * 1e-3, "decide_launches": ks["decide"]["launches"],
                     "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
@@ -594,6 +608,33 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rs, eng, cls, out["phases"], silver, n_reads, m, pop, seeds, k, tile, G)
+        if world == 1 and not silver and not a.no_pipeline_shaped:
+            # What bin/goldrush runs FIRST on the raw reads (bin/goldrush:253-260): --silver_path -M 5
+            # -r 0.9 — every silver path starts on empty ID arrays (goldrush_path.cpp:156-187), so the
+            # whole pass is the insert-heavy head regime, five times.  Same reads, same filter, IDs
+            # reset; not the headline (BASELINE's metric is the golden-path stream above).
+            eng.reset_ids()
+            eng.sync()
+            scls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
+                                   target_bases=int(0.9 * G), max_paths=5, silver_path=True, max_window=a.max_window, record=False)
+            t_s0 = time.perf_counter()
+            s_fin, pos = False, 0
+            while pos < n_reads and not s_fin:
+                for rb_, lens_, lo_, n_ in rs.pieces(pos, min(PHASE_SLICE * 16, n_reads - pos)):
+                    if not s_fin:
+                        s_fin = scls.run_range(rb_._h, lens_, lo_, n_)
+                pos += PHASE_SLICE * 16
+            eng.sync()
+            t_s = time.perf_counter() - t_s0
+            sst = scls.state()
+            if sst["hits"] + sst["misses"] != h * sst["queries"]:
+                raise SystemExit("bench: silver pass: hits + misses != h x queries")
+            out["aux"]["pipeline_shaped"] = {
+                "what": "the pipeline's first goldrush-path process on these reads: --silver_path -M 5 -r 0.9 (bin/goldrush:253-260), same filter, ID arrays reset; the run ends behind the fifth path",
+                "reads_consumed": int(sst["reads_committed"]), "seconds": t_s, "reads_per_s": sst["reads_committed"] / t_s if t_s > 0 else None,
+                "inserts": int(sst["inserts"]), "paths_completed": int(sst["curr_path"]) - 1 if s_fin else int(sst["curr_path"]) - 1, "finished": bool(s_fin),
+                "batches": int(sst["batches"]), "batches_undone": int(sst["batches_undone"]), "reads_queried": int(sst["reads_queried"])}
+            del scls
         print(json.dumps(out), flush=True)
     if world > 1:
         if shm:

@@ -38,7 +38,11 @@ struct DevSeeds
   uint32_t h;
   uint32_t k;    // base span
   uint32_t wmax; // max weight over seeds
-  uint32_t pad;
+  // Seeds built by make_seed_pattern (spaced_seeds.cpp:58-66) are seed 0 with i don't-care
+  // positions inserted at the centre: seed i = left || 0^i || right.  n_left > 0 says so (the
+  // number of care positions of the left part): the H hashes of a frame then share their halves
+  // (grp_kernels.inc, seed_halves), 16 table look-ups per frame instead of 16 per seed.
+  uint32_t n_left;
   uint32_t weight[GRP_DEV_MAX_H];
   uint32_t span[GRP_DEV_MAX_H];
   uint32_t shift[GRP_DEV_MAX_H][GRP_DEV_MAX_W]; // 2*q for care position q

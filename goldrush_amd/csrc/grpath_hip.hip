@@ -236,6 +236,9 @@ struct grp_ctx
   uint32_t* d_ir_counter = nullptr;
   uint64_t ir_cap = 0;
   uint32_t ir_parity = 0;
+  // RCCL communicator of a multi-GPU fill (grp_comm.inc), NULL on one GPU
+  void* comm = nullptr;
+  uint32_t comm_world = 1, comm_rank = 0;
   double* d_delog = nullptr; // 10^(-Q/10) table for the FASTQ ingest
   uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT);
   // timing
@@ -266,6 +269,8 @@ struct grp_reads
 };
 
 namespace {
+
+void comm_release(grp_ctx* c); // grp_comm.inc
 
 int
 set_err(const grp_ctx* ctx, int code, const char* fmt, ...)
@@ -576,6 +581,26 @@ build_seed_tables(grp_ctx* c)
       c->uniform_weight = 0;
     }
   }
+  // make_seed_pattern's family (spaced_seeds.cpp:58-66): seed i = left || "0" x i || right with
+  // left = the first k/2 positions of seed 0.  The query kernel then evaluates the halves once per
+  // frame (GRP_SHARED_HALVES=off: developer switch, every seed on its own as before).
+  sd.n_left = 0;
+  {
+    const char* e = getenv("GRP_SHARED_HALVES");
+    const std::string& s0 = c->seeds[0];
+    const size_t cut = s0.size() / 2;
+    bool family = sd.h >= 2 && !(e && !strcmp(e, "off"));
+    for (uint32_t s2 = 1; s2 < sd.h && family; ++s2) {
+      family = c->seeds[s2] == s0.substr(0, cut) + std::string(s2, '0') + s0.substr(cut);
+    }
+    uint32_t nl = 0;
+    for (size_t q = 0; q < cut; ++q) {
+      nl += s0[q] == '1';
+    }
+    if (family && nl > 0 && nl < sd.weight[0]) {
+      sd.n_left = nl;
+    }
+  }
   return GRP_OK;
 }
 
@@ -722,6 +747,7 @@ grp_destroy(grp_ctx* c)
   if (c->stream) {
     (void)hipStreamSynchronize(c->stream);
   }
+  comm_release(c);
   drain_events(c);
   for (auto& ep : c->free_events) {
     (void)hipEventDestroy(ep.a);
@@ -2625,3 +2651,4 @@ grp_stream(grp_ctx* c)
 #include "grp_batch.inc"
 #include "grp_ingest.inc"
 #include "grp_ntcard.inc"
+#include "grp_comm.inc"

@@ -75,6 +75,8 @@ Classifier::get_state(gr_classifier_state& s) const
   s.batches_undone = n_batch_undone_;
   s.batch_reads = n_batch_reads_;
   s.batches_refused = n_batch_refused_;
+  s.batches_fused = n_batch_fused_;
+  s.stream_inserts = n_stream_inserts_;
 }
 
 void
@@ -924,7 +926,15 @@ Classifier::batch_round(uint32_t& pos)
     const char* e = getenv("GRP_BATCH_MAX");
     return e ? (uint32_t)std::max(2l, atol(e)) : 4096u;
   }();
-  const uint32_t B = clamp_tiles(pos, std::min<uint32_t>({ batch_reads_, n - pos, p_.max_window, max_batch }), kMaxWindowTiles);
+  uint32_t B = clamp_tiles(pos, std::min<uint32_t>({ batch_reads_, n - pos, p_.max_window, max_batch }), kMaxWindowTiles);
+  // The second query of the previous batch ran on past its window (round 3): the reads behind
+  // it were decided in the same launch, against the state that batch left — this window's first
+  // decisions, if nothing has touched the filter since (the batch was confirmed in full).
+  const bool have_first = bnext_valid_ && bnext_base_ == base_ && bnext_pos_ == pos && bnext_inserts_ == n_inserts_ && bnext_path_ == curr_path_ && !bnext_.empty();
+  bnext_valid_ = false;
+  if (have_first) {
+    B = std::min<uint32_t>(B, (uint32_t)bnext_.size());
+  }
   const grp_decide_params dp{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
   auto fail = [&](const char* what, int rc) {
     err_ = std::string(what) + ": " + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
@@ -949,7 +959,10 @@ Classifier::batch_round(uint32_t& pos)
   bdec0_.resize(B);
   int rc = GRP_OK;
   const bool striped = world > 1 && allgather_cb_ && B >= stripe_min * world;
-  if (striped) {
+  if (have_first) {
+    std::copy(bnext_.begin(), bnext_.begin() + B, bdec0_.begin());
+    ++n_batch_fused_;
+  } else if (striped) {
     uint32_t q, lo, my;
     my_stripe(B, q, lo, my);
     dec_.assign(q, gr_read_decision{});
@@ -1064,8 +1077,25 @@ Classifier::batch_round(uint32_t& pos)
   if (rc != GRP_OK) {
     return fail("batch_insert", rc);
   }
-  bdec1_.resize(cnt);
-  uint32_t queried = cnt;
+  // One rank: the second query runs on past the window — the reads behind it are decided in the
+  // same launch (their floor is the largest ID: they see the filter as it is, with this batch's
+  // inserts) and become the next window's first decisions when this batch is confirmed in full.
+  // The launch is twice as large (better filled), and a confirmed batch costs one round trip less.
+  static const bool fuse_off = [] {
+    const char* e = getenv("GRP_BATCH_FUSE");
+    return e && !strcmp(e, "off");
+  }();
+  uint32_t extra = 0;
+  if (!striped && world == 1 && !fuse_off && cnt == B && pos + cnt < n) {
+    extra = clamp_tiles(pos, std::min<uint32_t>({ batch_reads_, n - pos - cnt, p_.max_window, max_batch }) + cnt, kMaxWindowTiles);
+    extra = extra > cnt ? extra - cnt : 0;
+  }
+  bdec1_.resize((size_t)cnt + extra);
+  if (extra) {
+    bfloor_.resize((size_t)cnt + extra);
+    std::fill(bfloor_.begin() + cnt, bfloor_.end(), 0x7FFFFFFFu);
+  }
+  uint32_t queried = cnt + extra;
   if (striped) {
     uint32_t q, lo, my;
     my_stripe(cnt, q, lo, my);
@@ -1083,7 +1113,7 @@ Classifier::batch_round(uint32_t& pos)
       std::copy(dec_all_.begin(), dec_all_.begin() + cnt, bdec1_.begin());
     }
   } else {
-    rc = vt_.batch_classify(ctx_, rg_.reads, base_ + pos, cnt, &dp, bfloor_.data(), bdec1_.data());
+    rc = vt_.batch_classify(ctx_, rg_.reads, base_ + pos, cnt + extra, &dp, bfloor_.data(), bdec1_.data());
   }
   if (rc == GRP_ERR_NOMEM) {
     // found on the device: the window's reads share too many ranks (they overlap each other);
@@ -1138,6 +1168,7 @@ Classifier::batch_round(uint32_t& pos)
     }
     batch_feedback(cnt, bad, exposure);
   }
+  const uint64_t path_at_query = curr_path_; // a rollover while committing resets the ID array: the decisions behind the window would be stale
   // the second decisions are the records (hits / misses against the state in front of each read)
   for (uint32_t j = 0; j < confirmed && rc == GRP_OK && !finished_; ++j) {
     (void)commit_one(pos + j, bdec1_[j], rc, bfirst_[j] != 0, bfirst_[j]);
@@ -1147,6 +1178,14 @@ Classifier::batch_round(uint32_t& pos)
   }
   n_batch_reads_ += confirmed;
   pos += confirmed;
+  if (extra && bad == cnt && !finished_ && curr_path_ == path_at_query) {
+    bnext_.assign(bdec1_.begin() + cnt, bdec1_.end());
+    bnext_valid_ = true;
+    bnext_base_ = base_;
+    bnext_pos_ = pos;
+    bnext_inserts_ = n_inserts_;
+    bnext_path_ = curr_path_;
+  }
   if (bad != cnt && !finished_) {
     if (bad_undecided) {
       batch_bypass_ = true;

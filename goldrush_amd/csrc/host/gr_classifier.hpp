@@ -150,6 +150,11 @@ private:
   std::vector<grp_id_count> lists_;
   std::vector<gr_read_decision> dec_, dec_all_, stripe_send_, stripe_recv_, bdec0_, bdec1_;
   std::vector<grp_batch_insert> bins_;
+  // decisions of the reads behind the last batch, taken by its second query's launch (batch_round)
+  std::vector<gr_read_decision> bnext_;
+  bool bnext_valid_ = false;
+  uint32_t bnext_base_ = 0, bnext_pos_ = 0;
+  uint64_t bnext_inserts_ = 0, bnext_path_ = 0, n_batch_fused_ = 0;
   std::vector<uint32_t> bfloor_, bfirst_;
   std::vector<TileWorkspace> ws_;
   std::string err_;

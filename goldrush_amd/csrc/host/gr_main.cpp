@@ -62,6 +62,12 @@ hip_engine()
     return grp_fastq_pack(static_cast<grp_ctx*>(c), static_cast<grp_fastq*>(fq), sel, n, reinterpret_cast<grp_reads**>(out));
   };
   vt.fastq_free = [](void* fq) { grp_fastq_free(static_cast<grp_fastq*>(fq)); };
+  vt.comm_unique_id = grp_comm_unique_id;
+  vt.comm_init = [](void* c, const void* id, uint32_t world, uint32_t rank) { return grp_comm_init(static_cast<grp_ctx*>(c), id, world, rank); };
+  vt.bv_merge_ranks = [](void* c) { return grp_bv_merge_ranks(static_cast<grp_ctx*>(c)); };
+  vt.bv_words = [](const void* c, uint64_t* n) { return grp_bv_words(static_cast<const grp_ctx*>(c), n); };
+  vt.bv_export_words = [](void* c, uint64_t first, uint64_t n, uint32_t* w) { return grp_bv_export_words(static_cast<grp_ctx*>(c), first, n, w); };
+  vt.bv_or_words = [](void* c, uint64_t first, uint64_t n, const uint32_t* w) { return grp_bv_or_words(static_cast<grp_ctx*>(c), first, n, w); };
   vt.stream_begin_resumable = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, const grp_read_decision** dec) {
     return grp_classify_stream_begin_resumable(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, slot, dec);
   };

@@ -20,6 +20,8 @@
 #include <iostream>
 #include <memory>
 #include <unordered_set>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #if defined(_OPENMP)
 #include <omp.h>
@@ -69,6 +71,12 @@ struct PathRun
   std::unordered_set<std::string> filter_out_reads;
   std::ofstream out;
   uint32_t world = 1, rank = 0; // ranks sharing the classification windows (one process per GPU)
+  // several ranks: every rank hashes the reads of its share of the batches into its bit vector, the
+  // vectors are OR-merged before the rank build (round 3: the CLI's fill is no longer replicated)
+  bool shard_fill = false;   // batch b belongs to rank b % world
+  bool merge_rccl = false;   // ... merged by RCCL inside the engine (else staged through host memory and /dev/shm)
+  void* shm = nullptr;       // gr_shm_allgather handle
+  int32_t device = -1;       // HIP device ordinal of this rank
 
   int fail_engine(const char* what)
   {
@@ -87,6 +95,7 @@ struct Rec
 struct Batch
 {
   const char* text = nullptr;
+  uint64_t base_off = 0;            // offset of text[0] in the (decompressed) input stream
   std::vector<Rec> rec;
   std::vector<uint32_t> avg, delta; // calc_phred_average, valid where stats() ran
   std::vector<uint8_t> non_acgt;    // find_first_not_of("ACGTacgt") != npos
@@ -208,6 +217,7 @@ public:
       if (tail_len_ && tail_off_) {
         memmove(buf_.data(), buf_.data() + tail_off_, tail_len_);
       }
+      base_off_ += tail_off_;
       size_t fill = tail_len_;
       tail_off_ = 0;
       while (!eof_ && fill < buf_.size()) {
@@ -248,6 +258,7 @@ public:
       meta_.resize(n_rec);
       run_.vt.fastq_records(fq_, meta_.data());
       b.text = buf_.data();
+      b.base_off = base_off_;
       b.rec.resize(n_rec);
       for (size_t i = 0; i < n_rec; ++i) {
         const grp_fastq_record& m = meta_[i];
@@ -294,6 +305,7 @@ private:
   InputFile in_;
   std::vector<char> buf_;
   size_t tail_off_ = 0, tail_len_ = 0;
+  uint64_t base_off_ = 0; // stream offset of buf_[0]
   bool eof_ = false, done_ = false, failed_ = false;
   void* fq_ = nullptr;
   std::vector<grp_fastq_record> meta_;
@@ -460,8 +472,80 @@ calc_min_phred_threshold(PathRun& run)
 }
 
 // goldrush_path.cpp:235-339
+// ---- reads kept on the device between the passes (round 3) -----------------------
+// The reference reads its input three times (Phred median, fill, classification:
+// goldrush_path.cpp:79-107, 235-339, 1210-1256).  Here the fill pass is the only full parse:
+// the packed reads it uploads stay in HBM (2 bits per base: 62.5 GB for C2's 10 M reads) and
+// the classification pass runs over those batches; the text of a read that is written out
+// (an inserted read) is fetched from the input file by offset.  Plain, seekable input without
+// a -f list only (gzip / pipes / --debug take the two-pass form); GRP_RESIDENT=off switches it
+// off, GRP_RESIDENT_MAX_GB caps the packed bytes kept (default 100).
+struct RecLoc
+{
+  uint64_t off;     // offset of the record's id in the input file
+  uint32_t id_len;
+  uint32_t seq_rel; // seq / qual relative to `off`
+  uint32_t seq_len;
+  uint64_t qual_rel;
+  uint32_t qual_len;
+};
+
+struct ResidentBatch
+{
+  void* reads = nullptr;
+  std::vector<uint32_t> lens, skipped_before;
+  uint32_t skipped_after = 0;
+  std::vector<RecLoc> loc;
+  std::vector<uint64_t> name_hash; // FNV-1a of the id: candidates for filter_out_reads (names are compared through the file)
+};
+
+uint64_t
+fnv1a(const char* p, size_t n)
+{
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) {
+    h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+  }
+  return h;
+}
+
+struct Resident
+{
+  bool on = false;
+  int fd = -1;
+  uint64_t packed_bytes = 0, max_bytes = 0;
+  std::vector<ResidentBatch> batches;
+  void drop(PathRun& run)
+  {
+    for (ResidentBatch& rb : batches) {
+      if (rb.reads) {
+        run.vt.reads_free(rb.reads);
+      }
+    }
+    batches.clear();
+    on = false;
+  }
+};
+
+// plain regular file (no gzip magic)?  Returns a descriptor for pread, -1 otherwise.
 int
-fill_bit_vector(PathRun& run)
+open_plain_input(const std::string& path)
+{
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) {
+    return -1;
+  }
+  struct stat st;
+  unsigned char magic[2] = { 0, 0 };
+  if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) {
+    close(fd);
+    return -1;
+  }
+  return fd;
+}
+
+int
+fill_bit_vector(PathRun& run, Resident& res)
 {
   const Opts& opt = run.opt;
   std::cerr << "inserting bit vector" << std::endl;
@@ -475,11 +559,16 @@ fill_bit_vector(PathRun& run)
   Batch b;
   void* prev = nullptr;
   std::vector<uint32_t> sel, lens;
+  uint32_t lead_skipped = 0;
+  uint64_t n_batches = 0;
   while (src->next(b)) {
     src->stats(b, opt.min_length, true);
     sel.clear();
+    ResidentBatch keep;
+    uint32_t skipped = 0;
     for (size_t i = 0; i < b.rec.size(); ++i) {
       ++num_reads;
+      ++skipped; // (taken back below when the record is selected)
       if (b.rec[i].seq_len < opt.min_length) { // :261-265
         ++by_length;
         continue;
@@ -504,6 +593,19 @@ fill_bit_vector(PathRun& run)
       }
       ++num_passed_reads;
       sel.push_back((uint32_t)i);
+      if (res.on) {
+        // what the classification pass needs of this read: it is classified iff it is long enough and
+        // not in filter_out_reads (read_hashing.cpp:35-42) — without a -f list exactly the reads selected here
+        const Rec& r = b.rec[i];
+        keep.skipped_before.push_back(skipped - 1);
+        keep.loc.push_back(RecLoc{ b.base_off + r.id_off, (uint32_t)r.id_len, (uint32_t)(r.seq_off - r.id_off), (uint32_t)r.seq_len, (uint64_t)(r.qual_off - r.id_off), (uint32_t)r.qual_len });
+        keep.name_hash.push_back(fnv1a(b.text + r.id_off, r.id_len));
+      }
+      skipped = 0;
+    }
+    if (res.on && sel.empty() && !res.batches.empty()) {
+      res.batches.back().skipped_after += skipped; // a batch without a single selected read
+      skipped = 0;
     }
     if (!sel.empty()) {
       void* h = nullptr;
@@ -515,11 +617,33 @@ fill_bit_vector(PathRun& run)
         prev = nullptr;
       }
       // multiLensfrHashIterator itr(record.seq, seeds); miBFCS.insertBV(itr)  (:304-305)
-      if (run.vt.bv_insert(run.ctx, h, 0, (uint32_t)sel.size()) != GRP_OK) {
+      const bool mine = !run.shard_fill || (n_batches % run.world) == run.rank;
+      ++n_batches;
+      if (mine && run.vt.bv_insert(run.ctx, h, 0, (uint32_t)sel.size()) != GRP_OK) {
         return run.fail_engine("bit-vector insert");
       }
-      prev = h;
+      if (res.on) {
+        for (uint32_t l : lens) {
+          res.packed_bytes += ((uint64_t)l + 15) / 16 * 4;
+        }
+        if (res.packed_bytes > res.max_bytes) {
+          res.drop(run); // too much to keep: the classification pass parses the input again
+          prev = h;
+        } else {
+          keep.reads = h;
+          keep.lens = lens;
+          keep.skipped_after = skipped;
+          res.batches.push_back(std::move(keep));
+        }
+      } else {
+        prev = h;
+      }
+    } else if (res.on && res.batches.empty()) {
+      lead_skipped += skipped; // records in front of the first selected read of the input
     }
+  }
+  if (res.on && !res.batches.empty() && lead_skipped) {
+    res.batches.front().skipped_before.front() += lead_skipped;
   }
   if (prev) {
     run.vt.reads_free(prev);
@@ -543,6 +667,36 @@ fill_bit_vector(PathRun& run)
   if (run.vt.sync(run.ctx) != GRP_OK) {
     return run.fail_engine("bit-vector insert");
   }
+  if (run.shard_fill) {
+    // the bitwise OR of the ranks' vectors (the fill is order-free)
+    if (run.merge_rccl) {
+      if (run.vt.bv_merge_ranks(run.ctx) != GRP_OK) {
+        return run.fail_engine("merging the bit vectors of the ranks (RCCL)");
+      }
+    } else {
+      uint64_t n_words = 0;
+      if (run.vt.bv_words(run.ctx, &n_words) != GRP_OK) {
+        return run.fail_engine("merging the bit vectors of the ranks");
+      }
+      const uint64_t chunk = (1u << 20) / 4; // words per exchange: one slot of the shared-memory all-gather
+      std::vector<uint32_t> mine(chunk), all((size_t)chunk * run.world);
+      for (uint64_t w0 = 0; w0 < n_words; w0 += chunk) {
+        const uint64_t n = std::min<uint64_t>(chunk, n_words - w0);
+        if (run.vt.bv_export_words(run.ctx, w0, n, mine.data()) != GRP_OK) {
+          return run.fail_engine("merging the bit vectors of the ranks");
+        }
+        if (gr_shm_allgather(run.shm, mine.data(), n * 4, all.data()) != 0) {
+          std::cerr << "goldrush-path: the exchange between the ranks failed" << std::endl;
+          return 1;
+        }
+        for (uint32_t p = 0; p < run.world; ++p) {
+          if (p != run.rank && run.vt.bv_or_words(run.ctx, w0, n, all.data() + (size_t)p * n) != GRP_OK) {
+            return run.fail_engine("merging the bit vectors of the ranks");
+          }
+        }
+      }
+    }
+  }
   std::cerr << "finished inserting bit vector" << std::endl;
   std::cerr << "in " << std::setprecision(4) << std::fixed << now_s() - s_time << "\n";
   return -1;
@@ -554,6 +708,10 @@ struct SinkState
   PathRun* run = nullptr;
   const Batch* batch = nullptr;
   const std::vector<uint32_t>* sel = nullptr;
+  // reads kept on the device: the record's text comes from the input file
+  const ResidentBatch* resident = nullptr;
+  int fd = -1;
+  std::vector<char> text;
   std::string upper;
   // --debug: the records that are not classified, in file order ({record, 1 = too short / 2 = filtered}),
   // and for every classified read the number of them in front of it
@@ -596,8 +754,27 @@ commit_sink(void* user, const gr_commit* c)
   if (c->dec.kind != DEC_INSERT_WHOLE && c->dec.kind != DEC_INSERT_TRIMMED) {
     return 0.0;
   }
-  const Batch& b = *st.batch;
-  const Rec& r = b.rec[(*st.sel)[c->read]];
+  Batch fetched; // resident mode: one record read back from the file
+  Rec fetched_rec{};
+  if (st.resident) {
+    const RecLoc& l = st.resident->loc[c->read];
+    const size_t n = (size_t)l.qual_rel + l.qual_len;
+    st.text.resize(n);
+    size_t got = 0;
+    while (got < n) {
+      const ssize_t k = pread(st.fd, st.text.data() + got, n - got, (off_t)(l.off + got));
+      if (k <= 0) {
+        std::cerr << "goldrush-path: cannot read the record back from " << run.opt.input << std::endl;
+        exit(1);
+      }
+      got += (size_t)k;
+    }
+    fetched.text = st.text.data();
+    fetched.seq_is_upper = false;
+    fetched_rec = Rec{ 0, l.id_len, l.seq_rel, l.seq_len, (size_t)l.qual_rel, l.qual_len };
+  }
+  const Batch& b = st.resident ? fetched : *st.batch;
+  const Rec& r = st.resident ? fetched_rec : b.rec[(*st.sel)[c->read]];
   const char first = run.opt.silver_path ? '@' : '>';
   const char* seq = b.text + r.seq_off;
   const char* qual = b.text + r.qual_off;
@@ -742,6 +919,7 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     gp.m = filter_size;
     gp.seeds = sp.data();
     gp.device = run.world > 1 ? (int32_t)env_u32("GRP_LOCAL_RANK", "LOCAL_RANK", run.rank) : -1;
+    run.device = gp.device;
     if (run.vt.create(&gp, &run.ctx) != GRP_OK) {
       std::cerr << "goldrush-path: cannot set up the MI355X engine: " << (run.vt.last_error ? run.vt.last_error(nullptr) : "") << std::endl;
       return 1;
@@ -768,6 +946,45 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     if (run.vt.set_filter_size(run.ctx, filter_size) != GRP_OK) {
       return run.fail_engine("allocating the bit vector");
     }
+  }
+  if (run.world > 1 && !getenv("GRP_REPLICATED_FILL")) {
+    // A sharded fill needs a way to merge: RCCL inside the engine (one GPU per rank), else the
+    // host-staged form (ranks sharing a device, engines without RCCL).  Every decision below is
+    // taken by ALL ranks alike (flags all-gathered through /dev/shm).
+    run.shm = shm.h;
+    auto all_agree = [&](bool mine) {
+      std::vector<uint8_t> one(64, mine ? 1 : 0), all(64 * run.world);
+      if (gr_shm_allgather(shm.h, one.data(), 64, all.data()) != 0) {
+        return false;
+      }
+      bool ok = true;
+      for (uint32_t p = 0; p < run.world; ++p) {
+        ok = ok && all[(size_t)p * 64] != 0;
+      }
+      return ok;
+    };
+    const bool staged_ok = all_agree(run.vt.bv_words && run.vt.bv_export_words && run.vt.bv_or_words);
+    bool rccl_ok = all_agree(run.vt.comm_unique_id && run.vt.comm_init && run.vt.bv_merge_ranks && !getenv("GRP_NO_RCCL"));
+    if (rccl_ok) { // one device per rank?  (RCCL refuses ranks that share a GPU)
+      std::vector<int32_t> dev(16, run.device), devs(16 * run.world);
+      rccl_ok = gr_shm_allgather(shm.h, dev.data(), 64, devs.data()) == 0;
+      for (uint32_t a = 0; a < run.world && rccl_ok; ++a) {
+        for (uint32_t b2 = a + 1; b2 < run.world; ++b2) {
+          rccl_ok = rccl_ok && devs[(size_t)a * 16] != devs[(size_t)b2 * 16];
+        }
+      }
+    }
+    if (rccl_ok) {
+      std::vector<char> id(128, 0), ids(128 * run.world);
+      const bool got = run.rank != 0 || run.vt.comm_unique_id(id.data(), id.size()) == GRP_OK;
+      const bool shared = gr_shm_allgather(shm.h, id.data(), 128, ids.data()) == 0;
+      rccl_ok = all_agree(got && shared);
+      if (rccl_ok) {
+        rccl_ok = all_agree(run.vt.comm_init(run.ctx, ids.data(), run.world, run.rank) == GRP_OK); // (ranks on one device: RCCL refuses, all take the staged form)
+      }
+    }
+    run.merge_rccl = rccl_ok;
+    run.shard_fill = rccl_ok || staged_ok;
   }
   ec = calc_min_phred_threshold(run);
   if (ec >= 0) {
@@ -803,7 +1020,30 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   std::cerr << "in " << std::setprecision(4) << std::fixed << now_s() - s_time << "\n";
   std::cerr << "opening: " << opt.input << std::endl;
 
-  ec = fill_bit_vector(run);
+  Resident res;
+  struct ResGuard
+  {
+    PathRun& run;
+    Resident& res;
+    ~ResGuard()
+    {
+      res.drop(run);
+      if (res.fd >= 0) {
+        close(res.fd);
+      }
+    }
+  } res_guard{ run, res };
+  {
+    const char* e = getenv("GRP_RESIDENT");
+    const bool gpu_ingest = run.vt.fastq_parse && run.vt.fastq_records && run.vt.fastq_pack && run.vt.fastq_free && !getenv("GRP_HOST_INGEST");
+    if (!(e && !strcmp(e, "off")) && gpu_ingest && !opt.debug) {
+      res.fd = open_plain_input(opt.input);
+      res.on = res.fd >= 0;
+      const char* cap = getenv("GRP_RESIDENT_MAX_GB");
+      res.max_bytes = (uint64_t)((cap ? atof(cap) : 100.0) * (double)(1ull << 30));
+    }
+  }
+  ec = fill_bit_vector(run, res);
   if (ec >= 0) {
     return ec;
   }
@@ -845,7 +1085,79 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     cls.set_debug(debug_sink);
   }
 
-  {
+  if (res.on) {
+    // the classification pass over the batches the fill pass left in HBM: no second parse
+    sink.fd = res.fd;
+    std::unordered_set<uint64_t> filtered_hash;
+    for (const std::string& name : run.filter_out_reads) {
+      filtered_hash.insert(fnv1a(name.data(), name.size()));
+    }
+    bool finished = false;
+    std::vector<uint32_t> sb;
+    std::string name;
+    for (size_t bi = 0; bi < res.batches.size() && !finished; ++bi) {
+      ResidentBatch& rb = res.batches[bi];
+      const uint32_t n = (uint32_t)rb.lens.size();
+      // reads named in filter_out_reads (a -f list, or a failing read of the same name) are not
+      // classified (read_hashing.cpp:35-42): they become skipped records of the run behind them
+      std::vector<uint8_t> drop(n, 0);
+      bool any_drop = false;
+      if (!filtered_hash.empty()) {
+        for (uint32_t i = 0; i < n; ++i) {
+          if (filtered_hash.count(rb.name_hash[i])) {
+            name.resize(rb.loc[i].id_len);
+            if (pread(res.fd, &name[0], name.size(), (off_t)rb.loc[i].off) == (ssize_t)name.size() && run.filter_out_reads.count(name)) {
+              drop[i] = 1;
+              any_drop = true;
+            }
+          }
+        }
+      }
+      sink.resident = &rb;
+      int rc = GRP_OK;
+      if (!any_drop) {
+        rc = cls.run(rb.reads, rb.lens.data(), 0, n, rb.skipped_before.data(), rb.skipped_after, finished);
+      } else {
+        // kept reads with the records skipped in front of each (dropped reads included), runs of
+        // consecutive kept reads go to the classifier one after the other
+        sb.assign(n, 0);
+        std::vector<uint32_t> idx;
+        uint32_t carry = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+          if (drop[i]) {
+            carry += rb.skipped_before[i] + 1;
+          } else {
+            sb[i] = rb.skipped_before[i] + carry;
+            carry = 0;
+            idx.push_back(i);
+          }
+        }
+        const uint32_t trailing = carry + rb.skipped_after;
+        if (idx.empty()) {
+          rc = cls.run(rb.reads, rb.lens.data(), 0, 0, sb.data(), trailing, finished);
+        }
+        for (size_t a = 0; a < idx.size() && rc == GRP_OK && !finished;) {
+          size_t e = a + 1;
+          while (e < idx.size() && idx[e] == idx[e - 1] + 1) {
+            ++e;
+          }
+          rc = cls.run(rb.reads, rb.lens.data(), idx[a], (uint32_t)(e - a), sb.data(), e == idx.size() ? trailing : 0u, finished);
+          a = e;
+        }
+      }
+      run.vt.reads_free(rb.reads);
+      rb.reads = nullptr;
+      if (rc != GRP_OK) {
+        std::cerr << "goldrush-path: " << cls.error() << std::endl;
+        return 1;
+      }
+    }
+    sink.resident = nullptr;
+    if (finished) {
+      run.out.flush();
+      return 0; // exit(0) inside silver_path_check (:173-176)
+    }
+  } else {
     auto src = open_source(run);
     Batch b;
     std::vector<uint32_t> sel, skipped_before, lens;

@@ -40,7 +40,7 @@ class gr_classifier_state(C.Structure):
                [("phred_sum_in_path", C.c_double), ("inserted_bases", C.c_uint64), ("curr_path", C.c_uint64), ("id", C.c_uint32), ("ids_inserted", C.c_uint32)] + \
                [(n, C.c_uint64) for n in ("windows", "reads_queried", "reads_committed", "inserts")] + \
                [("seconds_windows", C.c_double), ("seconds_commit", C.c_double)] + \
-               [(n, C.c_uint64) for n in ("batches", "batches_undone", "batch_reads", "batches_refused")]
+               [(n, C.c_uint64) for n in ("batches", "batches_undone", "batch_reads", "batches_refused", "batches_fused", "stream_inserts")]
 
 
 # engine function table: members typed exactly like include/grpath.h
@@ -82,6 +82,12 @@ VT_TYPES = [
     ("fastq_free", C.CFUNCTYPE(None, _vp)),
     ("stream_begin_resumable", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp)),
     ("stream_insert", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32))),
+    ("comm_unique_id", C.CFUNCTYPE(C.c_int, _vp, C.c_size_t)),
+    ("comm_init", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32)),
+    ("bv_merge_ranks", C.CFUNCTYPE(C.c_int, _vp)),
+    ("bv_words", C.CFUNCTYPE(C.c_int, _vp, C.POINTER(C.c_uint64))),
+    ("bv_export_words", C.CFUNCTYPE(C.c_int, _vp, C.c_uint64, C.c_uint64, _vp)),
+    ("bv_or_words", C.CFUNCTYPE(C.c_int, _vp, C.c_uint64, C.c_uint64, _vp)),
 ]
 
 

@@ -105,6 +105,11 @@ SIGNATURES = {
     "grp_classify_stream_abort": (C.c_int, [_vp, C.c_uint32]),
     "grp_classify_stream_poll": (C.c_int, [_vp, C.c_uint32]),
     "grp_classify_stream_end": (C.c_int, [_vp, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "grp_comm_unique_id": (C.c_int, [_vp, C.c_size_t]),
+    "grp_comm_init": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32]),
+    "grp_bv_merge_ranks": (C.c_int, [_vp]),
+    "grp_bv_export_words": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
+    "grp_bv_or_words": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
     "grp_debug_decide": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint64, C.POINTER(grp_decide_params), _vp, _vp, _vp]),
     "grp_classify_stream_begin_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.POINTER(C.c_void_p)]),
     "grp_classify_stream_insert": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),

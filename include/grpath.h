@@ -182,6 +182,23 @@ int grp_bv_merge_device(grp_ctx* ctx, const void* d_src);
  */
 int grp_words_or_device(grp_ctx* ctx, void* d_dst, const void* d_src, uint64_t n_words32);
 int grp_bv_import_device(grp_ctx* ctx, const void* d_src);
+/*
+ * The same merge INSIDE the engine (round 3), for a host that is not a framework with its own
+ * collectives (the goldrush-path binary, one process per GPU): RCCL straight from the library
+ * (librccl.so, loaded on first use) over xGMI, on the context's stream —
+ *   grp_comm_unique_id  rank 0: the 128 bytes of an ncclUniqueId, handed to the other ranks by the host
+ *   grp_comm_init       every rank: ncclCommInitRank on the context's device
+ *   grp_bv_merge_ranks  every rank, after its share of grp_bv_insert, before grp_finalize:
+ *                       bv = OR over all ranks (ncclAllToAll of the slices, OR, ncclAllGather)
+ * and, for ranks that cannot form a communicator (several ranks on ONE device: the plumbing tests of
+ * a one-GPU box), the host-staged form: words [first, first + n) of the plain bit vector out to /
+ * ORed in from host memory (first a multiple of 4), the exchange between the ranks being the host's.
+ */
+int grp_comm_unique_id(void* out, size_t cap);
+int grp_comm_init(grp_ctx* ctx, const void* unique_id, uint32_t world, uint32_t rank);
+int grp_bv_merge_ranks(grp_ctx* ctx);
+int grp_bv_export_words(grp_ctx* ctx, uint64_t first, uint64_t n_words32, uint32_t* words);
+int grp_bv_or_words(grp_ctx* ctx, uint64_t first, uint64_t n_words32, const uint32_t* words);
 
 /*
  * Replaces: miBFCS.setup(); miBFCS.getEmptyMIBF()

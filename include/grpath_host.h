@@ -68,6 +68,16 @@ typedef struct
    * stream_end may then return 1 (the insert posted last was not applied) */
   int (*stream_begin_resumable)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, const grp_read_decision** decisions);
   int (*stream_insert)(void* ctx, uint32_t slot, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset, uint32_t* generation);
+  /* optional (round 3): the fill sharded over the ranks of one node, the bit vectors OR-merged —
+   * through RCCL inside the engine (comm_unique_id / comm_init / bv_merge_ranks, all three or none)
+   * or, where the ranks cannot form a communicator, staged through host memory (bv_words /
+   * bv_export_words / bv_or_words, all three or none; the host exchanges the words) */
+  int (*comm_unique_id)(void* out, size_t cap);
+  int (*comm_init)(void* ctx, const void* unique_id, uint32_t world, uint32_t rank);
+  int (*bv_merge_ranks)(void* ctx);
+  int (*bv_words)(const void* ctx, uint64_t* n_words32);
+  int (*bv_export_words)(void* ctx, uint64_t first, uint64_t n_words32, uint32_t* words);
+  int (*bv_or_words)(void* ctx, uint64_t first, uint64_t n_words32, const uint32_t* words);
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */
@@ -198,6 +208,9 @@ typedef struct
   /* windows committed as batches (grp_batch_*): batches checked, batches ended early, reads committed through them */
   uint64_t batches, batches_undone, batch_reads;
   uint64_t batches_refused; /* batches the engine refused (GRP_ERR_NOMEM): committed the classic way */
+  /* round 3: batches whose first decisions came out of the previous batch's second-query launch; inserts a
+   * streaming window applied inside its own launch (grp_classify_stream_insert) */
+  uint64_t batches_fused, stream_inserts;
 } gr_classifier_state;
 void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
 

@@ -548,7 +548,27 @@ class OracleCliEngine:
             self.ctx["mf"] = orc.MiBF(m, self.ctx["seeds"], self.ctx["tile"], self.ctx["k"])
             return 0
 
-        impl = {"create": create, "destroy": destroy, "last_error": last_error, "reads_upload": reads_upload, "reads_free": reads_free, "bv_insert": bv_insert,
+        # the host-staged merge of a sharded fill: the oracle's plain bit vector as 32-bit words
+        def _bv32():
+            mf = self.ctx["mf"]
+            n = mf.lib.orcpy_mibf_n_words(mf._h)
+            return np.ctypeslib.as_array(C.cast(mf.lib.orcpy_mibf_bv(mf._h), C.POINTER(C.c_uint32)), shape=(2 * n,))
+
+        def bv_words(ctx, n_p):
+            n_p[0] = _bv32().size
+            return 0
+
+        def bv_export_words(ctx, first, n, words_p):
+            self.n_bv_exports = getattr(self, "n_bv_exports", 0) + 1
+            np.ctypeslib.as_array(C.cast(words_p, C.POINTER(C.c_uint32)), shape=(n,))[:] = _bv32()[first:first + n]
+            return 0
+
+        def bv_or_words(ctx, first, n, words_p):
+            _bv32()[first:first + n] |= np.ctypeslib.as_array(C.cast(words_p, C.POINTER(C.c_uint32)), shape=(n,))
+            return 0
+
+        impl = {"bv_words": bv_words, "bv_export_words": bv_export_words, "bv_or_words": bv_or_words,
+                "create": create, "destroy": destroy, "last_error": last_error, "reads_upload": reads_upload, "reads_free": reads_free, "bv_insert": bv_insert,
                 "finalize": finalize, "query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync,
                 "ntcard_begin": ntcard_begin, "ntcard_add": ntcard_add, "ntcard_finish": ntcard_finish, "set_filter_size": set_filter_size}
         for name, ftype in host.VT_TYPES:

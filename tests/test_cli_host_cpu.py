@@ -25,6 +25,8 @@ RUNNER = textwrap.dedent("""
     arr = (C.c_char_p * (len(args) + 1))(*args, None)
     rc = host.load().gr_path_main(len(args), arr, C.byref(eng.vt))
     sys.stdout.flush(); sys.stderr.flush()
+    if os.environ.get("GRP_TEST_MARK"):  # what the engine was asked to do (the ranks other than 0 must stay silent)
+        open(os.environ["GRP_TEST_MARK"] + "." + os.environ.get("GRP_RANK", "0"), "w").write(str(getattr(eng, "n_bv_exports", 0)))
     os._exit(rc)
 """)
 
@@ -70,12 +72,16 @@ def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_
     assert pick(rp.stderr) == pick(ro.stderr)
 
 
-@pytest.mark.parametrize("mode", ["silver", "golden"])
+@pytest.mark.parametrize("mode", ["silver", "golden", "golden_replicated_fill"])
 def test_two_ranks_of_the_host_program_write_what_one_rank_writes(oracle, native, tmp_path, mode):
     """goldrush-path as two processes (GRP_WORLD=2: one per GPU on a real node; here two
-    oracle-backed engines): the ranks share the query work of every window and exchange the
+    oracle-backed engines): every rank fills the bit vector from ITS share of the read batches and
+    the vectors are OR-merged (round 3; staged through host memory here, RCCL inside the engine on a
+    node with one GPU per rank), the ranks share the query work of every window and exchange the
     decisions through /dev/shm; rank 0 writes files identical to the oracle CLI's, rank 1
     writes nothing."""
+    replicated = mode.endswith("_replicated_fill")
+    mode = mode.split("_")[0]
     fq = os.path.join(GOLD, "tiny.fq")
     common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-i", fq, "--verbose"]
     args = common + (["-P0", "-r0.9", "--silver_path", "-M3", "-m1500"] if mode == "silver" else ["-P12", "-m0"])
@@ -88,7 +94,9 @@ def test_two_ranks_of_the_host_program_write_what_one_rank_writes(oracle, native
     key = "test_cli_%d_%s" % (os.getpid(), mode)
     procs = []
     for rank in range(2):
-        env = dict(os.environ, GRP_HOST_INGEST="1", OMP_NUM_THREADS="2", GRP_WORLD="2", GRP_RANK=str(rank), GRP_SHM_KEY=key, GRP_BATCH_RECORDS="9")
+        env = dict(os.environ, GRP_HOST_INGEST="1", OMP_NUM_THREADS="2", GRP_WORLD="2", GRP_RANK=str(rank), GRP_SHM_KEY=key, GRP_BATCH_RECORDS="9", GRP_TEST_MARK=str(tmp_path / "mark"))
+        if replicated:
+            env["GRP_REPLICATED_FILL"] = "1"
         procs.append(subprocess.Popen([sys.executable, str(script)] + args + ["-p", str(d_p / "out")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     outs = [p.communicate(timeout=900) for p in procs]
     assert [p.returncode for p in procs] == [ro.returncode, ro.returncode], [o[1][-2000:] for o in outs]
@@ -101,6 +109,8 @@ def test_two_ranks_of_the_host_program_write_what_one_rank_writes(oracle, native
     assert pick(outs[0][1]) == pick(ro.stderr)
     assert outs[1][1].strip() == "" and outs[1][0].strip() == ""  # rank 1 is silent
     assert not os.path.exists("/dev/shm/grp_" + key)
+    exports = [int(open(str(tmp_path / "mark") + "." + str(r)).read()) for r in range(2)]
+    assert all(e == 0 for e in exports) if replicated else all(e >= 1 for e in exports)  # the sharded fill was merged
 
 
 def test_a_garbage_line_ends_the_input_for_good_whatever_the_batching(oracle, native, tmp_path):

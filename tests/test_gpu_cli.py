@@ -269,3 +269,57 @@ def test_debug_dumps_match_the_oracle(oracle, host, tmp_path):
     po, pp = pick(ro.stderr), pick(rp.stderr)
     assert len(po) > 1000 and any(l.startswith("trimmed") for l in po)
     assert pp == po
+
+
+@pytest.mark.parametrize("env", [{}, {"GRP_RESIDENT": "off"}, {"GRP_RESIDENT_MAX_GB": "0.0002", "GRP_INGEST_CHUNK": "200000"}, {"GRP_INGEST_CHUNK": "30000"}])
+def test_reads_kept_on_the_device_between_the_passes(oracle, host, tmp_path, env):
+    """Round 3: the fill pass is the only full parse — its packed reads stay in HBM for the
+    classification pass, the text of the reads written out comes back from the file by offset.  With a
+    -f list (names compared through the file; one listed name is also a passing read's), a read whose
+    name equals a failing read's (the reference filters by NAME), records in front of the first and
+    behind the last classified read, a budget that runs out mid-file (fall back to the second parse),
+    and the switch off: always the oracle's files and counters."""
+    fq = tmp_path / "reads.fq"
+    recs = _mk_fastq(str(fq), 200_000, 300, 6000, 4000, seed=35, lower=True, with_n=13, short=8)
+    # a passing read that carries the name of a failing one (record 5 fails the delta filter)
+    names = [r[0].split()[0] for r in recs]
+    lines = fq.read_bytes().split(b"\n")
+    lines[4 * 40] = b"@" + names[5]
+    fq.write_bytes(b"\n".join(lines))
+    flt = tmp_path / "skip.txt"
+    flt.write_bytes(b"\n".join([names[2], names[100], names[101], names[299], b"not_a_read"]) + b"\n")
+    base = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j4", "-d5", "-x10", "-s1011011110110111101101", "-g200000", "-b4", "-H3000000", "-P10", "-m3500", "-i", str(fq), "--verbose"]
+    for tag, extra in (("silver", ["-r0.9", "--silver_path", "-M2"]), ("golden_f", ["-f", str(flt)])):
+        ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, base + extra, tag + str(len(env)), env=env)
+        assert _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+
+
+def test_two_ranks_share_the_fill_and_the_windows(oracle, host, tmp_path):
+    """goldrush-path as two processes on the one GPU of this box (GRP_WORLD=2, both on device 0):
+    each rank fills the bit vector from its share of the read batches, the vectors are OR-merged
+    (ranks sharing a device cannot form an RCCL communicator: the host-staged form through
+    /dev/shm; on a node with a GPU per rank the same step is ncclAllToAll + OR + ncclAllGather
+    inside the engine), the windows' query work is striped over the ranks.  Rank 0's files
+    equal the oracle's; rank 1 writes nothing."""
+    fq = str(tmp_path / "reads.fq")
+    _mk_fastq(fq, 200_000, 420, 6000, 4000, seed=45, lower=True, with_n=17, short=9)
+    for tag, extra in (("silver", ["-P0", "-r0.9", "--silver_path", "-M2", "-m3500"]), ("golden", ["-P10", "-m3500"])):
+        args = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j4", "-d5", "-x10", "-s1011011110110111101101", "-g200000", "-b4", "-H3000000", "-i", fq, "--verbose"] + extra
+        d_o, d_p = tmp_path / (tag + "_o"), tmp_path / (tag + "_p")
+        d_o.mkdir()
+        d_p.mkdir()
+        ro = oracle.run_cli(args + ["-p", str(d_o / "out")], timeout=900)
+        key = "gpu_cli_%d_%s" % (os.getpid(), tag)
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, GRP_WORLD="2", GRP_RANK=str(rank), GRP_LOCAL_RANK="0", GRP_SHM_KEY=key, GRP_STREAM_WGS_PER_CU="2", GRP_INGEST_CHUNK="400000")
+            procs.append(subprocess.Popen([host.CLI_PATH] + args + ["-p", str(d_p / "out")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+        outs = [p.communicate(timeout=900) for p in procs]
+        assert [p.returncode for p in procs] == [ro.returncode, ro.returncode], [o[1][-2000:] for o in outs]
+        fo = sorted(os.path.basename(p) for p in glob.glob(str(d_o / "*")))
+        fp = sorted(os.path.basename(p) for p in glob.glob(str(d_p / "*")))
+        assert fo == fp and fo, (fo, fp)
+        for f in fo:
+            assert filecmp.cmp(d_o / f, d_p / f, shallow=False), f"{f} differs"
+        assert _verbose_counters(outs[0][1]) == _verbose_counters(ro.stderr)
+        assert outs[1][0].strip() == "" and outs[1][1].strip() == ""

@@ -154,6 +154,69 @@ def test_filter_of_c2_size_matches_oracle(oracle, native):
     dr.free()
 
 
+def test_filter_of_c4_size_matches_oracle(oracle, native):
+    """BASELINE C4's filter at its own size: m = 101 911 215 744 (> 2^36, 12.7 GB of
+    bits, 1.6e9 buckets in 380 superbuckets), h = 5 designed-family seeds: bits, pop, ranks at set
+    bits beyond 2^36, five inserts, every ID and count, tile summaries — against the oracle — and
+    one silver-path rollover (grp_reset_ids) on that table."""
+    from goldrush_amd import host
+
+    hl = host.load()
+    h = 5
+    m = hl.gr_calc_optimal_size(hl.gr_hash_universe(16, 3_000_000_000, h), 1, 0.1)
+    assert m == 101911215744 and m > (1 << 36)
+    seeds = default_seeds(h, SEED22)
+    n_reads = 120
+    dr = native.synth_reads(n_reads, 3_000_000, mean_len=25000, min_len=20000, seed=11)
+    eng = native.Engine(K, h, TILE, m, seeds)
+    batch = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+    eng.bv_insert(batch)
+    oseeds = oracle.Seeds(seeds)
+    omf = oracle.MiBF(m, oseeds, TILE, K)
+    reads = dr.download(0, n_reads)
+    omf.bv_insert_reads(reads)
+    pop = eng.finalize()
+    assert pop == omf.finalize()
+    bits = eng.export_bits()
+    obits = _oracle_bits_view(omf)
+    assert bits.size == obits.size
+    nz = np.flatnonzero(bits)
+    assert np.array_equal(nz, np.flatnonzero(obits)) and np.array_equal(bits[nz], obits[nz])
+    assert int(nz[-1]) > (1 << 30)  # words beyond bit 2^36 are in use
+    del bits, nz
+    _check_rank_samples(eng, omf, m, 13, n=3000)
+    rng = np.random.default_rng(5)
+    ob = np.flatnonzero(obits)
+    high = ob[ob > (1 << 30)]
+    assert high.size > 1000
+    words = np.concatenate([rng.choice(ob, size=1000), rng.choice(high, size=1000)])
+    pos = np.array([int(w) * 64 + int(obits[w]).bit_length() - 1 for w in words], dtype=np.uint64)
+    bit, rank = eng.rank(pos)
+    for i in range(pos.size):
+        assert bit[i] == 1 and rank[i] == omf.rank(int(pos[i]))
+    assert int(pos.max()) > (1 << 36)
+    next_id = 0
+    for ri in (3, 40, 41, 77, 3):
+        next_id = _insert_whole(eng, omf, batch, reads, ri, next_id)
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts())
+    del ids, counts
+    _compare_queries(eng, omf, batch, reads, 0, 8)
+    _compare_queries(eng, omf, batch, reads, 76, 4)
+    # silver-path rollover: both arrays zeroed (goldrush_path.cpp:180-181), bits and ranks untouched
+    eng.reset_ids()
+    omf.reset_ids()
+    ids, counts = eng.export_ids()
+    assert not ids.any() and not counts.any()
+    del ids, counts
+    next_id = _insert_whole(eng, omf, batch, reads, 40, 0)
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts())
+    _compare_queries(eng, omf, batch, reads, 39, 3)
+    eng.close()
+    dr.free()
+
+
 def test_fill_larger_than_one_grid_equals_fill_in_slices(native):
     """1.4 M reads = 18 M fill workgroups = 4.7e9 work-items, more than one HIP grid holds
     (2^32): one grp_bv_insert call must set the same bits as many small calls."""

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""GPU box: the drop-in binary end to end.
+
+  tools/cli_end_to_end.py <out.json> [reads] [genome]
+
+Writes a FASTQ of `reads` synthetic ONT-like reads (default 100 000 x 25 kb, G = 100e6: C1's
+geometry, ~5 GB of text) and runs goldrush-path on it the way bin/goldrush does — process #1
+(--silver_path -M 5 -r 0.9 -m 20000, bin/goldrush:253-260) and process #2 (golden path on the
+silver reads, :240-248) — with the reads kept on the device between the passes (default) and with
+the second parse (GRP_RESIDENT=off).  Wall time, the program's own phase timers, reads/s
+FASTQ-inclusive; bench.py on the same geometry beside it."""
+import json
+import os
+import re
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CLI = os.path.join(ROOT, "goldrush_amd", "bin", "goldrush-path")
+SEED = "1011011110110111101101"
+
+
+def run_cli(args, env=None):
+    t0 = time.perf_counter()
+    r = subprocess.run([CLI] + args, capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+    dt = time.perf_counter() - t0
+    ins = [float(x) for x in re.findall(r"^in ([0-9.]+)$", r.stderr, re.M)]
+    visited = re.findall(r"Visited (\d+) reads", r.stderr)
+    return {"rc": r.returncode, "wall_s": dt, "phase_timers_s": ins, "visited": int(visited[-1]) if visited else None, "stderr_tail": r.stderr[-300:] if r.returncode else ""}
+
+
+def main():
+    out = sys.argv[1]
+    n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
+    genome = int(float(sys.argv[3])) if len(sys.argv) > 3 else 100_000_000
+    from goldrush_amd import synth
+
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    fq = os.path.join(tmp, "cli_e2e.fq")
+    t0 = time.perf_counter()
+    g = synth.random_genome(genome, 1)
+    with open(fq, "wb") as fh:
+        done = 0
+        while done < n_reads:  # in slices: the Python objects of 100 k reads would not fit comfortably
+            n = min(5000, n_reads - done)
+            for rid, seq, qual in synth.make_reads(g, n, mean_len=25000, min_len=20000, seed=2 + done):
+                fh.write(b"@r%d\n" % done + seq + b"\n+\n" + qual + b"\n")
+                done += 1
+    size = os.path.getsize(fq)
+    res = {"fastq_bytes": size, "reads": n_reads, "genome": genome, "fastq_written_s": time.perf_counter() - t0, "runs": {}}
+    base = ["-k22", "-w16", "-t1000", "-u5", "-a1", "-o0.1", "-h3", "-j16", "-P10", "-d5", "-x10", "-s" + SEED, "-g%d" % genome, "-b10", "--verbose"]
+    pdir = os.path.join(tmp, "cli_e2e_out")
+    os.makedirs(pdir, exist_ok=True)
+    for mode, env in (("resident", {}), ("second_parse", {"GRP_RESIDENT": "off"})):
+        for name, extra in (("silver_M5", ["-r0.9", "--silver_path", "-M5", "-m20000", "-i", fq, "-p", os.path.join(pdir, "sp_" + mode)]),
+                            ("golden_on_raw_reads", ["-m20000", "-i", fq, "-p", os.path.join(pdir, "gp_" + mode)])):
+            r = run_cli(base + extra, env)
+            r["reads_per_s_fastq_inclusive"] = (r["visited"] or n_reads) / r["wall_s"]
+            r["fastq_GB_per_s"] = size / r["wall_s"] / 1e9
+            res["runs"][name + "/" + mode] = r
+    # the outputs of the two forms are the same files
+    same = True
+    for f in sorted(os.listdir(pdir)):
+        if "_resident" in f:
+            a, b = os.path.join(pdir, f), os.path.join(pdir, f.replace("_resident", "_second_parse"))
+            same = same and os.path.exists(b) and open(a, "rb").read() == open(b, "rb").read()
+    res["outputs_identical"] = same
+    # the kernel path alone on the same geometry (GPU-resident synthetic reads, no text)
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C1", "--reads", str(n_reads), "--genome", str(genome), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-pipeline-shaped"], capture_output=True, text=True)
+    try:
+        line = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+        res["bench_same_geometry"] = {"reads_per_s": line["value"], "wall_s": line["aux"]["wall_s"], "fill_s": line["aux"]["fill_s"], "finalize_s": line["aux"]["finalize_s"]}
+    except Exception as e:
+        res["bench_same_geometry"] = {"error": str(e), "stderr": b.stderr[-500:]}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+    os.remove(fq)
+
+
+if __name__ == "__main__":
+    main()

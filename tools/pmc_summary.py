@@ -12,13 +12,18 @@ units of 1024 B and equals RDREQ x 64 B for this kernel's 64-byte random bucket 
 (the gfx950 halving only concerns wide 128-byte streaming requests)."""
 import csv
 import json
+import os
 import sys
+
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from csrc_hash import csrc_tree_hash  # noqa: E402
 
 out_path, bench_paths, csv_paths = sys.argv[1], [], []
 for a in sys.argv[2:]:
     (csv_paths if a.endswith(".csv") else bench_paths).append(a)
 assert len(bench_paths) == len(csv_paths), "one bench JSON line per counter pass"
-summary = {"note": __doc__.split("\n\n")[1].replace("\n", " "), "passes": []}
+summary = {"note": __doc__.split("\n\n")[1].replace("\n", " "), "csrc_tree_sha256": csrc_tree_hash(), "passes": []}
 per_kernel = {}
 for bp, cp in zip(bench_paths, csv_paths):
     line = [l for l in open(bp).read().splitlines() if l.startswith("{")][-1]
