@@ -240,6 +240,8 @@ struct grp_ctx
   void* comm = nullptr;
   uint32_t comm_world = 1, comm_rank = 0;
   double* d_delog = nullptr; // 10^(-Q/10) table for the FASTQ ingest
+  const char* reg_text = nullptr; // the caller's text buffer, page-locked by grp_fastq_parse
+  size_t reg_bytes = 0, reg_hint = 0;
   uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT);
   // timing
   bool timing = true;
@@ -748,6 +750,9 @@ grp_destroy(grp_ctx* c)
     (void)hipStreamSynchronize(c->stream);
   }
   comm_release(c);
+  if (c->reg_text) {
+    (void)hipHostUnregister(const_cast<char*>(c->reg_text));
+  }
   drain_events(c);
   for (auto& ep : c->free_events) {
     (void)hipEventDestroy(ep.a);

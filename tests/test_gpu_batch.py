@@ -320,3 +320,55 @@ def test_batches_with_one_tile_id_blocks(oracle, native, monkeypatch):
     assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
     assert cls.state()["batches"] >= 2
     eng.close()
+
+
+@pytest.mark.parametrize("collect3", [None])
+def test_large_batch_at_c2_filter_size_against_the_oracle(oracle, native, collect3, monkeypatch):
+    """ONE batch of 320 whole-read inserts on C2's own filter (m = 61 146 729 472:
+    65 GB of buckets) — 24 M (frame, seed) records, a collect grid of ~96 000 workgroups, thousands
+    of them in flight — against the ORACLE's serial inserts: every ID and count, the chained ranks
+    (reads of a 3 Mbp genome overlap each other heavily) and a partial take-back included."""
+    from goldrush_amd import host
+    from test_gpu_wide import _oracle_bits_view  # noqa: F401  (same helpers, same sizes)
+
+    if collect3:
+        monkeypatch.setenv("GRP_BATCH_COLLECT3", collect3)
+    hl = host.load()
+    k, h, tile, block = 22, 3, 1000, 10
+    m = hl.gr_calc_optimal_size(hl.gr_hash_universe(16, 3_000_000_000, h), 1, 0.1)
+    seeds = default_seeds(h)
+    n_reads = 320
+    dr = native_mod.synth_reads(n_reads, 3_000_000, mean_len=25000, min_len=20000, seed=19)
+    eng = native_mod.Engine(k, h, tile, m, seeds)
+    batch = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+    eng.bv_insert(batch)
+    reads = dr.download(0, n_reads)
+    omf = oracle.MiBF(m, oracle.Seeds(seeds), tile, k)
+    omf.bv_insert_reads(reads)
+    assert eng.finalize() == omf.finalize()
+    ins, next_id = [], 0
+    for ri, seq in enumerate(reads):
+        nt = len(seq) // tile
+        ins.append((ri, 0, nt, next_id + 1, 0))
+        for bs in range(0, nt, block):
+            omf.insert_read_tiles(seq, bs, min(bs + block, nt), next_id + 1 + bs // block)
+        next_id += 1 + len(seq) // (tile * block)
+    eng.batch_insert_reads(batch, ins, block, 0)
+    eng.batch_end()
+    ids, counts = eng.export_ids()
+    oi, oc = omf.ids(), omf.counts()
+    bad = np.flatnonzero((ids != oi) | (counts != oc))
+    assert bad.size == 0, (bad.size, bad[:10], ids[bad[:10]], oi[bad[:10]], counts[bad[:10]], oc[bad[:10]])
+    assert int((counts > 1).sum()) > 10_000  # ranks touched by several ID blocks: chains were replayed
+    # the same batch again on top, then the second half taken back: the state of the first half on top
+    ins2 = [(r, a, b2, fid + next_id, off) for (r, a, b2, fid, off) in ins]
+    half = n_reads // 2
+    for (r, a, b2, fid, off) in ins2[:half]:
+        for bs in range(0, b2, block):
+            omf.insert_read_tiles(reads[r], bs, min(bs + block, b2), fid + bs // block)
+    eng.batch_insert_reads(batch, ins2, block, 0)
+    eng.batch_undo(half, ins2[half][3])
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts())
+    eng.close()
+    dr.free()
