@@ -1089,6 +1089,13 @@ Classifier::batch_round(uint32_t& pos)
   if (!striped && world == 1 && !fuse_off && cnt == B && pos + cnt < n) {
     extra = clamp_tiles(pos, std::min<uint32_t>({ batch_reads_, n - pos - cnt, p_.max_window, max_batch }) + cnt, kMaxWindowTiles);
     extra = extra > cnt ? extra - cnt : 0;
+    // worth it while the query time thrown away with a batch that ends early (probability from the
+    // decayed count of such batches, ~50 batches of memory) stays below the round trip saved (~0.1 ms)
+    const double p_fail = std::min(1.0, bf_fail_ / 50.0);
+    const double t_query = (double)extra * avg_probes_per_read_ / 40e9;
+    if (p_fail * t_query > 1.0e-4) {
+      extra = 0;
+    }
   }
   bdec1_.resize((size_t)cnt + extra);
   if (extra) {
