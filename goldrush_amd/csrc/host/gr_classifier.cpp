@@ -199,10 +199,14 @@ Classifier::window_plan() const
     // streaming launch: no per-window round trip and a stale window is cut short by the
     // abort flag, so an insert costs one drain + relaunch (~120 us: resident workgroups
     // finish, insert kernels, ramp-up) whatever the window size
-    static const double t_abort = [] { // developer hook: what an insert costs a streaming launch (us)
+    static const double t_abort_env = [] { // developer hook: what an insert costs a streaming launch (us)
       const char* e = getenv("GRP_T_ABORT_US");
-      return (e ? atof(e) : 400.0) * 1e-6; // 120 us on C1, ~300 us on C2 (tools/abort_matrix.sh)
+      return e ? atof(e) * 1e-6 : 0.0;
     }();
+    // a window that ends at the insert: drain + insert kernels + relaunch, ~400 us on C2 (tools/abort_matrix.sh);
+    // a window that applies the insert itself (round 3): ~240 us until the first record behind it, ~100 us of
+    // device time — 200 us fitted on C2's transition zone (tools/dev/r3_thresholds.sh)
+    const double t_abort = t_abort_env > 0.0 ? t_abort_env : (can_resume() ? 200e-6 : 400e-6);
     // the window size does not matter to an abort (only the resident workgroups are lost),
     // so the launches are as long as allowed.  Several ranks: every rank works on its own
     // stripe of the current group, an insert also discards about half a group; the
@@ -278,7 +282,7 @@ Classifier::launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, 
   // One rank, golden-path mode: a window that waits where it parks and applies the insert the
   // host commits inside its own launch (stream_round); a silver-path run resets the ID array
   // at a rollover, several ranks share a window in stripes: those windows end where they park.
-  const bool resumable = vt_.stream_begin_resumable && vt_.stream_insert && vt_.insert_read && p_.world == 1 && !p_.silver_path && !resume_disabled_;
+  const bool resumable = can_resume();
   int rc = resumable ? vt_.stream_begin_resumable(ctx_, reads, base_ + pos, S, &dp, slot, &dec) : vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, stripe_reads(), p_.world, p_.rank, &dec);
   if (rc != GRP_OK) {
     err_ = std::string("stream_begin: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
@@ -862,15 +866,25 @@ Classifier::want_batch() const
   // a batch costs two queries per read whatever the insert rate (~4.5 us on C2); the classic
   // windows cost one query per read plus ~80-400 us per insert: measured on C2 (bench.py --trace)
   // the batch wins down to ~1 % inserting reads
-  static const double p_in = [] {
+  static const double p_in_env = [] {
     const char* v = getenv("GRP_BATCH_ENTER");
-    return v ? atof(v) : 0.012;
+    return v ? atof(v) : 0.0;
   }();
-  static const double p_out = [] {
+  static const double p_out_env = [] {
     const char* v = getenv("GRP_BATCH_LEAVE");
-    return v ? atof(v) : 0.007;
+    return v ? atof(v) : 0.0;
   }();
+  // (windows that apply inserts themselves are cheaper per insert: the batches take over later)
+  const double p_in = p_in_env > 0.0 ? p_in_env : (can_resume() ? 0.020 : 0.012);
+  const double p_out = p_out_env > 0.0 ? p_out_env : (can_resume() ? 0.012 : 0.007);
   return p_insert_mid_ >= (in_batch_ ? p_out : p_in);
+}
+
+// one rank, golden-path mode, an engine with the entry points: streaming windows apply inserts inside their launch
+bool
+Classifier::can_resume() const
+{
+  return vt_.stream_begin_resumable && vt_.stream_insert && vt_.insert_read && p_.world == 1 && !p_.silver_path && !resume_disabled_;
 }
 
 // The size of the next batch.  A read decides differently in a batch when it overlaps a read

@@ -73,6 +73,7 @@ private:
   int end_stream(StreamFlight& f);
   int wait_record(const StreamFlight& f, uint32_t j);
   bool can_stream() const;
+  bool can_resume() const;
   bool commit_one(uint32_t r, const gr_read_decision& d, int& rc, bool engine_inserted = false, uint32_t engine_first_id = 0);
   bool can_loop() const;
   bool want_loop() const; // the insert rate calls for the device-side commit loop
