@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <sstream>
 #include "gr_tiles.hpp"
+#include "gr_fastq.hpp"
 
 #include <cstring>
 #include <new>
@@ -240,6 +241,24 @@ void
 gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out)
 {
   c->impl.get_state(*out);
+}
+
+uint64_t
+gr_input_read(const char* path, uint64_t request_bytes, char* dst, uint64_t cap)
+{
+  gr::InputFile in(path ? path : "");
+  if (!in.ok()) {
+    return UINT64_MAX;
+  }
+  uint64_t got = 0;
+  while (got < cap) {
+    const size_t k = in.read(dst + got, (size_t)std::min<uint64_t>(std::max<uint64_t>(request_bytes, 1), cap - got));
+    if (k == 0) {
+      break;
+    }
+    got += k;
+  }
+  return got;
 }
 
 } // extern "C"

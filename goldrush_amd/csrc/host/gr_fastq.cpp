@@ -2,13 +2,35 @@
 
 #include <algorithm>
 #include <cctype>
+#include <cerrno>
+#include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <zlib.h>
 
 namespace gr {
 
+// A plain regular file is read with pread: large requests are cut into slices that several
+// threads copy out of the page cache at once (one thread moves ~6 GB/s, the GPU ingest
+// behind it parses > 20 GB/s).  Everything else — gzip data, pipes — goes through zlib.
 InputFile::InputFile(const std::string& path)
 {
+  const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+  if (fd >= 0) {
+    struct stat st;
+    unsigned char magic[2] = { 0, 0 };
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !getenv("GRP_ZLIB_READER")) {
+      const ssize_t k = pread(fd, magic, 2, 0);
+      if (k >= 0 && !(k == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
+        fd_ = fd;
+        return;
+      }
+    }
+    ::close(fd);
+  }
   gzFile f = gzopen(path.c_str(), "rb");
   if (f) {
     gzbuffer(f, 1u << 20);
@@ -21,11 +43,59 @@ InputFile::~InputFile()
   if (f_) {
     gzclose(static_cast<gzFile>(f_));
   }
+  if (fd_ >= 0) {
+    ::close(fd_);
+  }
+}
+
+static size_t
+pread_all(int fd, char* dst, size_t n, uint64_t off)
+{
+  size_t got = 0;
+  while (got < n) {
+    const ssize_t r = pread(fd, dst + got, n - got, (off_t)(off + got));
+    if (r < 0 && errno == EINTR) {
+      continue;
+    }
+    if (r <= 0) {
+      break;
+    }
+    got += (size_t)r;
+  }
+  return got;
 }
 
 size_t
 InputFile::read(char* dst, size_t n)
 {
+  if (fd_ >= 0) {
+    constexpr size_t kSlice = size_t(16) << 20;
+    size_t threads = std::min<size_t>(n / kSlice, std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())));
+    size_t got = 0;
+    if (threads < 2) {
+      got = pread_all(fd_, dst, n, off_);
+    } else {
+      // slice i covers [i * per, (i + 1) * per); the data ends in the first short slice
+      const size_t per = (n + threads - 1) / threads;
+      std::vector<size_t> part(threads, 0);
+      std::vector<std::thread> pool;
+      for (size_t i = 1; i < threads; ++i) {
+        pool.emplace_back([&, i] { part[i] = pread_all(fd_, dst + i * per, std::min(per, n - i * per), off_ + i * per); });
+      }
+      part[0] = pread_all(fd_, dst, per, off_);
+      for (auto& t : pool) {
+        t.join();
+      }
+      for (size_t i = 0; i < threads; ++i) {
+        got += part[i];
+        if (part[i] < std::min(per, n - i * per)) {
+          break;
+        }
+      }
+    }
+    off_ += got;
+    return got;
+  }
   size_t got = 0;
   while (f_ && got < n) { // gzread takes an unsigned length
     const unsigned want = (unsigned)std::min<size_t>(n - got, 1u << 30);
@@ -41,6 +111,10 @@ InputFile::read(char* dst, size_t n)
 int
 InputFile::peek()
 {
+  if (fd_ >= 0) {
+    unsigned char c;
+    return pread(fd_, &c, 1, (off_t)off_) == 1 ? (int)c : -1;
+  }
   if (!f_) {
     return -1;
   }

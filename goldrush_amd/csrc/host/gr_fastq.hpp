@@ -12,7 +12,8 @@
 
 namespace gr {
 
-// the input file, plain or gzip'ed (gzread passes plain files through)
+// the input file: a plain regular file (pread, large requests by several threads) or anything
+// zlib reads — gzip data, pipes (GRP_ZLIB_READER=1 sends plain files through zlib too)
 class InputFile
 {
 public:
@@ -20,12 +21,14 @@ public:
   ~InputFile();
   InputFile(const InputFile&) = delete;
   InputFile& operator=(const InputFile&) = delete;
-  bool ok() const { return f_ != nullptr; }
+  bool ok() const { return f_ != nullptr || fd_ >= 0; }
   size_t read(char* dst, size_t n); // 0 at the end of the data (or on a read error)
   int peek();                      // next byte without consuming it, -1 at the end
 
 private:
   void* f_ = nullptr; // gzFile
+  int fd_ = -1;       // plain regular file
+  uint64_t off_ = 0;  // ... and the read position in it
 };
 
 struct RecordRef

@@ -128,6 +128,7 @@ SIGNATURES = {
     "gr_classifier_error": (C.c_char_p, [_vp]),
     "gr_classifier_get_state": (None, [_vp, C.POINTER(gr_classifier_state)]),
     "gr_path_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(grp_engine_vt)]),
+    "gr_input_read": (C.c_uint64, [C.c_char_p, C.c_uint64, _vp, C.c_uint64]),
 }
 
 _lib = None

@@ -214,6 +214,13 @@ typedef struct
 } gr_classifier_state;
 void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
 
+/* ---- the input reader (what btllib::SeqReader's file handling is to goldrush_path.cpp:235-339) --
+ * Reads `path` (plain text by pread — requests of >= 32 MiB by several threads — or gzip / a pipe
+ * through zlib) in requests of `request_bytes` into dst[0..cap).  Returns the bytes delivered
+ * (the whole input if it fits cap), UINT64_MAX if the file cannot be opened.  Test hook of the
+ * CLI's chunk reader. */
+uint64_t gr_input_read(const char* path, uint64_t request_bytes, char* dst, uint64_t cap);
+
 /* ---- the CLI as a function (main of goldrush_path.cpp:1096-1275) ----------- */
 int gr_path_main(int argc, char** argv, const grp_engine_vt* vt);
 

@@ -192,3 +192,33 @@ def test_ntcard_host_arithmetic(oracle, host):
         assert lib.gr_ntcard_f0(int(z[s][0]), int(z[s][1]), sbits) == nc.f0(s)
     assert lib.gr_ntcard_f0(1 << 27, 1 << 27, 7) == 0
     nc.close()
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_input_reader_delivers_the_file_whatever_the_request_size(host, tmp_path, gz):
+    """The CLI's chunk reader: plain files by pread (requests >= 32 MiB by several threads),
+    gzip data through zlib — the same bytes in the same order for every request size, a short
+    last slice and a file that ends inside a request included."""
+    import ctypes as C
+    import gzip
+
+    hl = host.load()
+    rng = np.random.default_rng(5)
+    n = (70 << 20) + 12345 if not gz else (3 << 20) + 77
+    data = rng.integers(0, 256, size=n, dtype=np.uint8)
+    p = tmp_path / ("in.gz" if gz else "in.txt")
+    if gz:
+        with gzip.open(p, "wb", compresslevel=1) as f:
+            f.write(data.tobytes())
+    else:
+        p.write_bytes(data.tobytes())
+    for req in (1 << 30, (64 << 20) + 1, 33 << 20, 1 << 20, 4097):
+        if gz and req < (1 << 20):
+            continue
+        dst = np.zeros(n + 4096, dtype=np.uint8)
+        got = hl.gr_input_read(str(p).encode(), req, dst.ctypes.data_as(C.c_void_p), dst.size)
+        assert got == n, (req, got)
+        assert np.array_equal(dst[:n], data), req
+    assert hl.gr_input_read(str(tmp_path / "missing").encode(), 1 << 20, None, 0) == 2**64 - 1
+    (tmp_path / "empty").write_bytes(b"")
+    assert hl.gr_input_read(str(tmp_path / "empty").encode(), 1 << 20, dst.ctypes.data_as(C.c_void_p), dst.size) == 0

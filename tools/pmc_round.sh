@@ -8,7 +8,7 @@ tag=${1:-rXX}
 out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-args="--no-cpu-baseline --steps 4 --warmup 0 --reads 2000000"
+args="--no-cpu-baseline --no-pipeline-shaped --steps 4 --warmup 0 --reads 2000000"
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $out/${tag}_pmcA -o a -- python3 bench.py $args > $out/${tag}_pmcA_bench.json 2> $out/${tag}_pmcA.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/${tag}_pmcB -o b -- python3 bench.py $args > $out/${tag}_pmcB_bench.json 2> $out/${tag}_pmcB.err
 A=$(find $out/${tag}_pmcA -name "*counter_collection.csv" | head -1)

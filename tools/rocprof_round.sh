@@ -7,7 +7,7 @@ out=gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
 # kernel trace of the default command (no CPU baseline leg: it only adds host time)
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o ${tag} -- python3 bench.py --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o ${tag} -- python3 bench.py --no-cpu-baseline --no-pipeline-shaped > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof.err
 find $out/${tag}_prof -name "*kernel_stats.csv" -exec cp {} $out/${tag}_kernel_stats.csv \;
 # the bench line's roofline is over the throughput forms of k_query in the timed region: the same
 # dispatches from the per-dispatch trace (streaming + large windows; the warm-up engine's launches
