@@ -501,10 +501,10 @@ def main():
 
     if rank == 0:
         kq = ks["query"]
-        kernel_name = "k_query, throughput forms (streaming windows k_query<h,1,0,true,false>; large windows and the first query of a batch k_query<h,2,0,false,false>; the second query of a batch, through the batch's records, k_query<h,2,0,false,true>); the few latency windows are in aux.query_latency"
+        kernel_name = "k_query, throughput forms (streaming windows k_query<h,1,0,true,false>; large windows and the first query of a batch k_query<h,F,0,false,false>; the second query of a batch, through the batch's records, k_query<h,F,0,false,true>; F = 2 frames per lane up to h = 3, 1 beyond); the few latency windows are in aux.query_latency"
         if kq["units"] == 0:  # a run that never left the insert-heavy head: the latency form is all there is
             kq = ks["query_latency"]
-            kernel_name = "k_query, latency form (k_query<h,2,16,false>: windows of a few reads; the run never left the insert-heavy head)"
+            kernel_name = "k_query, windows of a few reads (k_query<h,F,0,false>; the run never left the insert-heavy head)"
         reads_done = st1["reads_committed"] - st0["reads_committed"]  # silver mode stops behind the last path
         avg_ms = kq["ms"] / max(kq["launches"], 1)
         probes_per_launch = kq["units"] / max(kq["launches"], 1)
@@ -602,7 +602,7 @@ def main():
                     "query_kernel_s": kq_s, "decide_kernel_s": ks["decide"]["ms"] * 1e-3, "decide_launches": ks["decide"]["launches"],
                     "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
                     "query_latency": {"launches": ks["query_latency"]["launches"], "kernel_s": ks["query_latency"]["ms"] * 1e-3, "probes": ks["query_latency"]["units"],
-                                      "what": "k_query<h,2,16,false> on windows of a few reads, summaries written straight to host memory"},
+                                      "what": "k_query<h,F,0,false> on windows of a few reads, summaries written straight to host memory"},
                     "commit_loop": {"launches": ks["loop"]["launches"], "kernel_s": ks["loop"]["ms"] * 1e-3, "probes": ks["loop"]["units"]},
                     "wall_s": dt},
         }

@@ -502,8 +502,12 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), d_tile_idx ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, stream_ctl ? *stream_ctl : DevStreamCtl{}, c->view ? *c->view : DevBatchView{});
     return GRP_OK;
   };
+  // The synchronous forms (large windows, the two queries of a batch): two frames per lane and pass
+  // up to h = 3; from h = 4 on one frame per lane with the software-pipelined pass (222 -> 171 VGPRs
+  // at h = 5; C4 geometry +4 %, h = 3 -3 %: measured, tools/dev/r3_fr1.sh)
+  constexpr int SFR = (HH <= 3) ? 2 : 1;
   if (c->view && !stream_ctl) { // grp_batch_classify: every read sees the state in front of its own insert
-    return go(k_query<HH, 2, 0, false, true>);
+    return go(k_query<HH, SFR, 0, false, true>);
   }
   if (stream_ctl) {
     // persistent workgroups: exactly what is resident at once
@@ -529,16 +533,10 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     n_launch = std::min<uint64_t>(n_launch, resident);
     return go(kern);
   }
-  // 2 frames per lane and pass: 2*H*4 quad reads in flight per lane (measured best on MI355X).
-  // latency windows (a few reads on an otherwise idle device): a wave's time is the chain of
-  // its own instructions; the unrolled care loop shortens it — up to h = 3, beyond that the
-  // unrolled form runs out of registers (h = 5: 512 VGPRs + 110 spilled to scratch, round 2)
-  if constexpr (HH <= 3) {
-    if (c->uniform_weight == 16 && n_launch <= SMALL_TILES) {
-      return go(k_query<HH, 2, 16, false>);
-    }
-  }
-  return go(k_query<HH, 2, 0, false>);
+  // (round 2 had a second form for windows of a few reads, the care loop unrolled for weight-16
+  // seeds: 346 VGPRs + 14 spilled at h = 3.  With the shared halves the hash is a third of the
+  // instructions it was and the batches took the insert-heavy phases over: the form is gone.)
+  return go(k_query<HH, SFR, 0, false>);
 }
 
 int
