@@ -117,7 +117,8 @@ struct BatchRun
   uint32_t* d_counters = nullptr;
   uint32_t* d_ins = nullptr;
   uint64_t ins_cap = 0;
-  unsigned long long* d_keys = nullptr; // collect: rank -> owner's record (zeroed behind every collect pass)
+  ulonglong2* d_keys = nullptr;         // collect: rank -> owner's record + what the second query needs of it (zeroed behind every collect pass)
+  bool short_cut = false;               // the table's value halves are filled in (not by the developer form of the collect kernel)
   uint64_t tab_cap = 0, cur_cap = 0;    // allocated slots / slots the current batch uses (both tables)
   unsigned long long* d_rec_key = nullptr; // records, one per (frame, seed) of the inserted tiles
   unsigned long long* d_rec_loc = nullptr;
@@ -240,8 +241,8 @@ struct grp_ctx
   void* comm = nullptr;
   uint32_t comm_world = 1, comm_rank = 0;
   double* d_delog = nullptr; // 10^(-Q/10) table for the FASTQ ingest
-  const char* reg_text = nullptr; // the caller's text buffer, page-locked by grp_fastq_parse
-  size_t reg_bytes = 0, reg_hint = 0;
+  const char* reg_text = nullptr; // the caller's text buffer, page-locked by grp_fastq_pin
+  size_t reg_bytes = 0;
   uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT);
   // timing
   bool timing = true;

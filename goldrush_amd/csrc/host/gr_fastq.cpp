@@ -26,6 +26,7 @@ InputFile::InputFile(const std::string& path)
       const ssize_t k = pread(fd, magic, 2, 0);
       if (k >= 0 && !(k == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
         fd_ = fd;
+        size_ = (uint64_t)st.st_size;
         return;
       }
     }

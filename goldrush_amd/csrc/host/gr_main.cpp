@@ -68,6 +68,8 @@ hip_engine()
   vt.bv_words = [](const void* c, uint64_t* n) { return grp_bv_words(static_cast<const grp_ctx*>(c), n); };
   vt.bv_export_words = [](void* c, uint64_t first, uint64_t n, uint32_t* w) { return grp_bv_export_words(static_cast<grp_ctx*>(c), first, n, w); };
   vt.bv_or_words = [](void* c, uint64_t first, uint64_t n, const uint32_t* w) { return grp_bv_or_words(static_cast<grp_ctx*>(c), first, n, w); };
+  vt.fastq_pin = [](void* c, const char* b, uint64_t n) { return grp_fastq_pin(static_cast<grp_ctx*>(c), b, n); };
+  vt.fastq_unpin = [](void* c) { return grp_fastq_unpin(static_cast<grp_ctx*>(c)); };
   vt.stream_begin_resumable = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, const grp_read_decision** dec) {
     return grp_classify_stream_begin_resumable(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, slot, dec);
   };

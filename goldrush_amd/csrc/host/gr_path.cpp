@@ -18,7 +18,10 @@
 #include <functional>
 #include <iomanip>
 #include <iostream>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <unordered_set>
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -197,7 +200,12 @@ private:
   std::vector<uint64_t> word_off_;
 };
 
-// raw text chunks parsed, filtered and packed on the GPU (grpath_ingest.h)
+// raw text chunks parsed, filtered and packed on the GPU (grpath_ingest.h).
+// A reader thread keeps the NEXT chunk of the file coming (InputFile: parallel pread of a plain
+// file, zlib for gzip data) while the caller works on the current one — upload, parse, pack, fill
+// or classify — so a pass costs max(read, GPU) per chunk instead of their sum.  Two slots in ONE
+// page-locked buffer; every slot has room in front of the bytes read for the unconsumed tail of
+// the chunk before it (a partial record), which is copied there before the parse.
 class GpuSource : public RecordSource
 {
 public:
@@ -205,50 +213,93 @@ public:
     : run_(run)
     , in_(run.opt.input)
   {
-    buf_.resize(ingest_chunk_bytes());
+    chunk_ = std::max<size_t>(ingest_chunk_bytes(), 64);
+    if (in_.plain_size() != 0) { // a small file: one slot holds it all, no 2 x 256 MiB to allocate and page-lock
+      chunk_ = std::min<size_t>(chunk_, std::max<size_t>((size_t)in_.plain_size() + 1, size_t(1) << 16));
+    }
+    front_ = std::min<size_t>(std::max<size_t>(chunk_ / 16, 4096), size_t(16) << 20);
+    buf_.resize(2 * (front_ + chunk_));
+    const char* pin_min = getenv("GRP_PIN_MIN_BYTES"); // tests: page-lock small buffers too
+    if (run_.vt.fastq_pin && run_.vt.fastq_unpin && buf_.size() >= (pin_min ? (size_t)atoll(pin_min) : (size_t(8) << 20))) {
+      pinned_ = run_.vt.fastq_pin(run_.ctx, buf_.data(), buf_.size()) == GRP_OK;
+    }
   }
-  ~GpuSource() override { release(); }
+  ~GpuSource() override
+  {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    if (reader_.joinable()) {
+      reader_.join();
+    }
+    release();
+    if (pinned_) {
+      run_.vt.fastq_unpin(run_.ctx); // before the buffer goes away: the engine cannot know when the host frees memory
+    }
+  }
   bool ok() const override { return in_.ok(); }
-  bool is_fastq() override { return in_.peek() == '@'; }
+  bool is_fastq() override { return in_.peek() == '@'; } // (asked before the first chunk is read)
   bool next(Batch& b) override
   {
     release();
+    if (!reader_.joinable() && !done_) {
+      reader_ = std::thread([this] { read_loop(); });
+    }
     while (!done_) {
-      if (tail_len_ && tail_off_) {
-        memmove(buf_.data(), buf_.data() + tail_off_, tail_len_);
-      }
-      base_off_ += tail_off_;
-      size_t fill = tail_len_;
-      tail_off_ = 0;
-      while (!eof_ && fill < buf_.size()) {
-        const size_t got = in_.read(buf_.data() + fill, buf_.size() - fill);
-        if (got == 0) {
-          eof_ = true;
+      // the slot handed out by the previous call goes back to the reader, the next one is awaited
+      Slot* sl = nullptr;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        if (held_ >= 0) {
+          slot_[held_].state = Slot::FREE;
+          held_ = -1;
+          cv_.notify_all();
         }
-        fill += got;
+        cv_.wait(g, [&] { return slot_[take_].state == Slot::READY; });
+        sl = &slot_[take_];
+        held_ = take_;
+        take_ ^= 1;
       }
+      const bool eof = sl->eof;
+      char* data = slot_data(held_);
+      // the tail of the chunk before, in front of what was read
+      char* text = nullptr;
+      size_t fill = carry_.size() + sl->n;
+      if (carry_.size() <= front_) {
+        text = data - carry_.size();
+        if (!carry_.empty()) {
+          memcpy(text, carry_.data(), carry_.size());
+        }
+      } else {
+        // a record longer than a chunk: assembled in a buffer of its own (pageable; rare)
+        big_.resize(fill);
+        memcpy(big_.data(), carry_.data(), carry_.size());
+        memcpy(big_.data() + carry_.size(), data, sl->n);
+        text = big_.data();
+      }
+      const uint64_t text_off = sl->file_off - carry_.size(); // stream offset of text[0]
       if (fill == 0) {
         done_ = true;
         break;
       }
       uint64_t n_rec = 0, used = 0;
       int stopped = 0;
-      if (run_.vt.fastq_parse(run_.ctx, buf_.data(), fill, eof_ ? 1 : 0, &fq_, &n_rec, &used, &stopped) != GRP_OK) {
+      if (run_.vt.fastq_parse(run_.ctx, text, fill, eof ? 1 : 0, &fq_, &n_rec, &used, &stopped) != GRP_OK) {
         std::cerr << "goldrush-path: FASTQ ingest: " << (run_.vt.last_error ? run_.vt.last_error(run_.ctx) : "failed") << std::endl;
         failed_ = true;
         done_ = true;
         break;
       }
-      if (n_rec == 0 && !eof_ && !stopped) {
-        // a record longer than the buffer: enlarge and retry with the same bytes
+      if (n_rec == 0 && !eof && !stopped) {
+        // not one complete record yet: everything is carried into the next chunk
         release();
-        tail_len_ = fill;
-        buf_.resize(buf_.size() * 2);
+        carry_.assign(text, text + fill);
         continue;
       }
-      tail_off_ = (size_t)used;
-      tail_len_ = fill - (size_t)used;
-      if (eof_ || stopped) {
+      carry_.assign(text + used, text + fill);
+      if (eof || stopped) {
         done_ = true;
       }
       if (n_rec == 0) {
@@ -257,8 +308,8 @@ public:
       }
       meta_.resize(n_rec);
       run_.vt.fastq_records(fq_, meta_.data());
-      b.text = buf_.data();
-      b.base_off = base_off_;
+      b.text = text;
+      b.base_off = text_off;
       b.rec.resize(n_rec);
       for (size_t i = 0; i < n_rec; ++i) {
         const grp_fastq_record& m = meta_[i];
@@ -294,6 +345,48 @@ public:
   bool failed() const { return failed_; }
 
 private:
+  struct Slot
+  {
+    enum State { FREE, READY } state = FREE;
+    size_t n = 0;          // bytes read
+    uint64_t file_off = 0; // stream offset of the first of them
+    bool eof = false;      // the data ends with this chunk
+  };
+  char* slot_data(int i) { return buf_.data() + (size_t)i * (front_ + chunk_) + front_; }
+  void read_loop()
+  {
+    uint64_t off = 0;
+    for (int i = 0;; i ^= 1) {
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return stop_ || slot_[i].state == Slot::FREE; });
+        if (stop_) {
+          return;
+        }
+      }
+      size_t got = 0;
+      bool eof = false;
+      while (!eof && got < chunk_) {
+        const size_t k = in_.read(slot_data(i) + got, chunk_ - got);
+        if (k == 0) {
+          eof = true;
+        }
+        got += k;
+      }
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        slot_[i].n = got;
+        slot_[i].file_off = off;
+        slot_[i].eof = eof;
+        slot_[i].state = Slot::READY;
+      }
+      cv_.notify_all();
+      off += got;
+      if (eof) {
+        return;
+      }
+    }
+  }
   void release()
   {
     if (fq_) {
@@ -303,10 +396,19 @@ private:
   }
   PathRun& run_;
   InputFile in_;
-  std::vector<char> buf_;
-  size_t tail_off_ = 0, tail_len_ = 0;
-  uint64_t base_off_ = 0; // stream offset of buf_[0]
-  bool eof_ = false, done_ = false, failed_ = false;
+  std::vector<char> buf_;  // [slot 0: front | chunk][slot 1: front | chunk]
+  std::vector<char> carry_; // unconsumed tail of the chunk before
+  std::vector<char> big_;
+  size_t chunk_ = 0, front_ = 0;
+  bool pinned_ = false;
+  std::thread reader_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  Slot slot_[2];
+  int take_ = 0;  // the slot the next chunk arrives in
+  int held_ = -1; // the slot the caller's current batch lives in
+  bool stop_ = false;
+  bool done_ = false, failed_ = false;
   void* fq_ = nullptr;
   std::vector<grp_fastq_record> meta_;
 };

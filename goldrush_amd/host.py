@@ -88,6 +88,8 @@ VT_TYPES = [
     ("bv_words", C.CFUNCTYPE(C.c_int, _vp, C.POINTER(C.c_uint64))),
     ("bv_export_words", C.CFUNCTYPE(C.c_int, _vp, C.c_uint64, C.c_uint64, _vp)),
     ("bv_or_words", C.CFUNCTYPE(C.c_int, _vp, C.c_uint64, C.c_uint64, _vp)),
+    ("fastq_pin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64)),
+    ("fastq_unpin", C.CFUNCTYPE(C.c_int, _vp)),
 ]
 
 

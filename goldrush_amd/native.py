@@ -164,6 +164,8 @@ SIGNATURES.update({
     "grp_fastq_records": (C.c_int, [_vp, _vp]),
     "grp_fastq_pack": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(_vp)]),
     "grp_fastq_free": (None, [_vp]),
+    "grp_fastq_pin": (C.c_int, [_vp, _vp, C.c_uint64]),
+    "grp_fastq_unpin": (C.c_int, [_vp]),
 })
 
 _lib = None
@@ -336,6 +338,23 @@ class Engine:
 
     def fastq_free(self, fq_handle):
         self.lib.grp_fastq_free(fq_handle)
+
+    def fastq_pin(self, buf: np.ndarray):
+        """Page-lock `buf` (a uint8 array the caller keeps alive) for the uploads of fastq_parse; unpin before freeing it."""
+        self._check(self.lib.grp_fastq_pin(self._h, _ptr(buf), buf.size))
+
+    def fastq_unpin(self):
+        self._check(self.lib.grp_fastq_unpin(self._h))
+
+    def fastq_parse_at(self, buf: np.ndarray, n_bytes: int, final_chunk: bool = True):
+        """fastq_parse on the first n_bytes of a caller-owned uint8 array (no copy: what a pinned chunk buffer needs)."""
+        out = C.c_void_p()
+        n_rec, used, stopped = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._check(self.lib.grp_fastq_parse(self._h, _ptr(buf), n_bytes, 1 if final_chunk else 0, C.byref(out), C.byref(n_rec), C.byref(used), C.byref(stopped)))
+        rec = np.zeros(n_rec.value, dtype=fastq_record_dtype)
+        if n_rec.value:
+            self._check(self.lib.grp_fastq_records(out, _ptr(rec)))
+        return out, rec, used.value, bool(stopped.value)
 
     # -- phase 0 (--ntcard)
     def ntcard_begin(self, sbits: int = 7):

@@ -78,6 +78,9 @@ typedef struct
   int (*bv_words)(const void* ctx, uint64_t* n_words32);
   int (*bv_export_words)(void* ctx, uint64_t first, uint64_t n_words32, uint32_t* words);
   int (*bv_or_words)(void* ctx, uint64_t first, uint64_t n_words32, const uint32_t* words);
+  /* optional: page-lock / release the chunk buffer handed to fastq_parse (grp_fastq_pin / _unpin) */
+  int (*fastq_pin)(void* ctx, const char* buffer, uint64_t n_bytes);
+  int (*fastq_unpin)(void* ctx);
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */

@@ -42,7 +42,7 @@ typedef struct
 #define GRP_FQ_NON_ACGT 1u
 
 /*
- * Upload and parse `n_bytes` of FASTQ text (host memory; pinned memory is faster).
+ * Upload and parse `n_bytes` of FASTQ text (host memory; pinned memory — grp_fastq_pin — is faster).
  * final_chunk != 0: the text ends the file (a last line without newline is a line).
  * Returns the number of complete records and how many bytes they span; the caller
  * re-submits the unconsumed tail at the start of its next chunk.  *stopped is set
@@ -59,6 +59,14 @@ int grp_fastq_records(grp_fastq* fq, grp_fastq_record* out);
  */
 int grp_fastq_pack(grp_ctx* ctx, grp_fastq* fq, const uint32_t* sel, uint32_t n_sel, grp_reads** out);
 void grp_fastq_free(grp_fastq* fq);
+/*
+ * Optional: page-lock the caller's chunk buffer (hipHostRegister) so that grp_fastq_parse's upload
+ * of text inside [buffer, buffer + n_bytes) is one DMA.  One buffer per context; _pin replaces the
+ * previous one.  The caller MUST call grp_fastq_unpin (or grp_destroy) BEFORE it frees or
+ * reallocates the buffer.  GRP_ERR_HIP: the buffer could not be locked — parse works all the same.
+ */
+int grp_fastq_pin(grp_ctx* ctx, const char* buffer, uint64_t n_bytes);
+int grp_fastq_unpin(grp_ctx* ctx);
 
 #ifdef __cplusplus
 }

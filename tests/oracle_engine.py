@@ -417,8 +417,12 @@ class OracleCliEngine:
     run without a GPU.  No ingest / classify / stream entry points: the host takes its
     plain paths; the --ntcard entry points restate the kernel's rule with oracle hashes."""
 
-    def __init__(self, orc):
+    def __init__(self, orc, ingest=False):
         self.orc = orc
+        self.ingest = ingest  # also offer the FASTQ ingest entry points (a Python restatement of grpath_ingest.h):
+                              # the host then takes its chunked source (GpuSource), reader thread and all
+        self.pins = []        # what the host pinned / unpinned, in order
+        self.n_parse = 0
         self.ctx = None       # one context at a time is enough for the CLI
         self.batches = {}     # handle -> list of reads (bytes)
         self._next = 1
@@ -567,10 +571,89 @@ class OracleCliEngine:
             _bv32()[first:first + n] |= np.ctypeslib.as_array(C.cast(words_p, C.POINTER(C.c_uint32)), shape=(n,))
             return 0
 
+        # ---- FASTQ ingest (include/grpath_ingest.h), restated: lines by '\n' (a last line without one
+        # counts in the final chunk), four per record, extents without trailing CR / blank / tab, id up to
+        # the first whitespace, a header that is empty or does not start with '@' ends the input
+        rec_dtype = np.dtype([("id_off", "<u8"), ("seq_off", "<u8"), ("qual_off", "<u8"), ("id_len", "<u4"), ("seq_len", "<u4"),
+                              ("qual_len", "<u4"), ("flags", "<u4"), ("phred_sum", "<f8"), ("phred_first", "<f8")])
+        parsed = {}
+
+        def fastq_parse(ctx, text_p, n, final, out_pp, nrec_p, used_p, stopped_p):
+            hl = host.load()
+            self.n_parse += 1
+            text = C.string_at(text_p, n) if n else b""
+            lines, pos = [], 0
+            while pos < len(text):
+                nl = text.find(b"\n", pos)
+                if nl < 0:
+                    if final:
+                        lines.append((pos, len(text)))
+                    break
+                lines.append((pos, nl))
+                pos = nl + 1
+            recs, seqs, stopped = [], [], 0
+            used = 0
+            for r in range(len(lines) // 4):
+                ext = []
+                for a, e in lines[4 * r: 4 * r + 4]:
+                    while e > a and text[e - 1:e] in (b"\r", b" ", b"\t"):
+                        e -= 1
+                    ext.append((a, e))
+                (hs, he), (ss, se), _, (qs, qe) = ext
+                if he == hs or text[hs:hs + 1] != b"@":
+                    stopped = 1
+                    break
+                ie = hs + 1
+                while ie < he and not text[ie:ie + 1].isspace():
+                    ie += 1
+                seq, qual = text[ss:se], text[qs:qe]
+                half = qual[: len(qual) // 2]
+                recs.append((hs + 1, ss, qs, ie - hs - 1, se - ss, qe - qs, 1 if seq.translate(None, b"ACGTacgt") else 0,
+                             hl.gr_sum_phred(qual, len(qual)), hl.gr_sum_phred(half, len(half)) if len(qual) >= 2 else 0.0))
+                seqs.append(seq.upper())
+                used = min(lines[4 * r + 3][1] + 1, len(text))
+            if final and not stopped:
+                used = len(text)
+            hnd = self._next
+            self._next += 1
+            parsed[hnd] = (np.array(recs, dtype=rec_dtype), seqs)
+            out_pp[0] = hnd
+            nrec_p[0] = len(recs)
+            used_p[0] = used
+            stopped_p[0] = stopped
+            return 0
+
+        def fastq_records(fq, out_p):
+            rec = parsed[fq][0]
+            C.memmove(out_p, rec.ctypes.data, rec.nbytes)
+            return 0
+
+        def fastq_pack(ctx, fq, sel_p, n_sel, out_pp):
+            sel = np.ctypeslib.as_array(C.cast(sel_p, C.POINTER(C.c_uint32)), shape=(max(n_sel, 1),))[:n_sel]
+            hnd = self._next
+            self._next += 1
+            self.batches[hnd] = [parsed[fq][1][int(i)] for i in sel]
+            out_pp[0] = hnd
+            return 0
+
+        def fastq_free(fq):
+            parsed.pop(fq, None)
+
+        def fastq_pin(ctx, buf, n):
+            self.pins.append(("pin", buf, n))
+            return 0
+
+        def fastq_unpin(ctx):
+            self.pins.append(("unpin",))
+            return 0
+
         impl = {"bv_words": bv_words, "bv_export_words": bv_export_words, "bv_or_words": bv_or_words,
                 "create": create, "destroy": destroy, "last_error": last_error, "reads_upload": reads_upload, "reads_free": reads_free, "bv_insert": bv_insert,
                 "finalize": finalize, "query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync,
                 "ntcard_begin": ntcard_begin, "ntcard_add": ntcard_add, "ntcard_finish": ntcard_finish, "set_filter_size": set_filter_size}
+        if self.ingest:
+            impl.update({"fastq_parse": fastq_parse, "fastq_records": fastq_records, "fastq_pack": fastq_pack, "fastq_free": fastq_free,
+                         "fastq_pin": fastq_pin, "fastq_unpin": fastq_unpin})
         for name, ftype in host.VT_TYPES:
             if name in impl:
                 cb = ftype(impl[name])

@@ -20,11 +20,17 @@ RUNNER = textwrap.dedent("""
     import orc
     from goldrush_amd import host
     from oracle_engine import OracleCliEngine
-    eng = OracleCliEngine(orc)
+    eng = OracleCliEngine(orc, ingest=bool(os.environ.get("ORACLE_ENGINE_INGEST")))
     args = [b"goldrush_path"] + [a.encode() for a in sys.argv[1:]]
     arr = (C.c_char_p * (len(args) + 1))(*args, None)
     rc = host.load().gr_path_main(len(args), arr, C.byref(eng.vt))
     sys.stdout.flush(); sys.stderr.flush()
+    if os.environ.get("ORACLE_ENGINE_INGEST"):  # every pin answered by an unpin before the next one / the end
+        ops = [p[0] for p in eng.pins]
+        assert eng.n_parse > 0, "the host did not take its chunked source"
+        if os.environ.get("EXPECT_PINS"):
+            assert "pin" in ops
+        assert ops.count("pin") <= ops.count("unpin") and all(a != b for a, b in zip(ops, ops[1:]) if a == "pin"), ops
     if os.environ.get("GRP_TEST_MARK"):  # what the engine was asked to do (the ranks other than 0 must stay silent)
         open(os.environ["GRP_TEST_MARK"] + "." + os.environ.get("GRP_RANK", "0"), "w").write(str(getattr(eng, "n_bv_exports", 0)))
     os._exit(rc)
@@ -70,6 +76,46 @@ def test_host_program_over_oracle_engine_matches_oracle_cli(oracle, native, tmp_
             "\tminimum average phred", "num_", "Total reads skipped")
     pick = lambda text: [l for l in text.splitlines() if l.startswith(keep)]  # noqa: E731
     assert pick(rp.stderr) == pick(ro.stderr)
+
+
+@pytest.mark.parametrize("mode,chunk", [("silver", 0), ("silver", 30000), ("golden", 9000), ("golden", 100000), ("gz", 50000), ("silver", 4097)])
+def test_chunked_source_with_reader_thread_matches_oracle_cli(oracle, native, tmp_path, mode, chunk):
+    """The host's chunked FASTQ source (reader thread, two slots, the partial record carried into the
+    next chunk, records longer than a chunk) over a Python restatement of the ingest entry points:
+    chunk sizes from smaller than a record to larger than the file, plain and gzip input, the packed
+    reads kept between the passes or parsed again."""
+    fq = os.path.join(GOLD, "tiny.fq")
+    common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-i", fq, "--verbose"]
+    args = common + (["-P0", "-r0.9", "--silver_path", "-M3", "-m1500"] if mode in ("silver", "gz") else ["-P12", "-m0"])
+    args_p = list(args)
+    if mode == "gz":
+        import gzip
+
+        gz = str(tmp_path / "reads.fq.gz")
+        with open(fq, "rb") as src, gzip.open(gz, "wb") as dst:
+            dst.write(src.read())
+        args_p[args_p.index(fq)] = gz
+    d_o = tmp_path / "o"
+    d_o.mkdir()
+    ro = oracle.run_cli(args + ["-p", str(d_o / "out")], timeout=600)
+    script = tmp_path / "runner.py"
+    script.write_text(RUNNER.format(root=ROOT))
+    for resident in ("on", "off"):
+        d_p = tmp_path / ("p_" + resident)
+        d_p.mkdir()
+        env = dict(os.environ, ORACLE_ENGINE_INGEST="1", OMP_NUM_THREADS="2", GRP_RESIDENT=resident, **({"GRP_INGEST_CHUNK": str(chunk)} if chunk else {}))
+        if chunk == 30000:  # the chunk buffer page-locked: every pin released before the next one and at the end
+            env.update(GRP_PIN_MIN_BYTES="1", EXPECT_PINS="1")
+        env.pop("GRP_HOST_INGEST", None)
+        rp = subprocess.run([sys.executable, str(script)] + args_p + ["-p", str(d_p / "out")], capture_output=True, text=True, timeout=900, env=env)
+        assert rp.returncode == ro.returncode, (rp.returncode, ro.returncode, rp.stderr[-3000:])
+        fo, fp = sorted(os.listdir(d_o)), sorted(os.listdir(d_p))
+        assert fo == fp and fo, (fo, fp)
+        for f in fo:
+            assert filecmp.cmp(d_o / f, d_p / f, shallow=False), (f, resident)
+        keep = ("Visited", "Saw:", "Assigned:", "Unassigned:", "Total queries", "Total hits", "Total misses", "Num reads", "m_filterSize", "num_", "Total reads skipped")
+        pick = lambda text: [l for l in text.splitlines() if l.startswith(keep)]  # noqa: E731
+        assert pick(rp.stderr) == pick(ro.stderr)
 
 
 @pytest.mark.parametrize("mode", ["silver", "golden", "golden_replicated_fill"])

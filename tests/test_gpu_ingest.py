@@ -154,3 +154,26 @@ def test_ingest_matches_the_oracle_reader(oracle, native, tmp_path, kw):
     eng.fastq_free(fq)
     lib.orc_reads_free(C.byref(reads))
     eng.close()
+
+
+def test_pinned_chunk_buffer_over_several_passes(native):
+    """grp_fastq_pin / _unpin: the same records from a page-locked chunk buffer, and — the fault this
+    API replaced — a buffer that is freed and allocated again at (possibly) the same address between
+    the passes is never taken for a registered one (the engine keeps no registration of its own)."""
+    eng = native.Engine(22, 3, 1000, 1 << 20, default_seeds(3))
+    text = _mk_text(21, n=900)
+    fq, ref, used_ref, _ = eng.fastq_parse(text)
+    eng.fastq_free(fq)
+    for rounds in range(4):
+        buf = np.empty(len(text) + (1 << 20), dtype=np.uint8)
+        buf[: len(text)] = np.frombuffer(text, dtype=np.uint8)
+        if rounds != 2:  # one pass on pageable memory in between
+            eng.fastq_pin(buf)
+        fq, rec, used, stopped = eng.fastq_parse_at(buf, len(text))
+        assert used == used_ref and not stopped and np.array_equal(rec, ref)
+        eng.fastq_free(fq)
+        eng.fastq_unpin()  # before the buffer goes away (a second unpin is harmless)
+        eng.fastq_unpin()
+        del buf
+    with pytest.raises(native.GrpError):
+        eng.fastq_pin(np.zeros(0, dtype=np.uint8))

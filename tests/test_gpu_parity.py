@@ -181,7 +181,7 @@ def test_flagged_tiles_are_redone_with_the_worst_case_table(oracle, native):
     eng.stream_end(0)
 
 
-@pytest.mark.parametrize("h,tile", [(1, 1000), (5, 1000), (3, 500), (2, 64)])
+@pytest.mark.parametrize("h,tile", [(1, 1000), (5, 1000), (3, 500), (2, 64), (4, 1000), (6, 250), (7, 1000), (4, 190)])
 def test_other_geometries(oracle, native, h, tile):
     k = 22
     seeds = default_seeds(h)
