@@ -117,8 +117,7 @@ struct BatchRun
   uint32_t* d_counters = nullptr;
   uint32_t* d_ins = nullptr;
   uint64_t ins_cap = 0;
-  ulonglong2* d_keys = nullptr;         // collect: rank -> owner's record + what the second query needs of it (zeroed behind every collect pass)
-  bool short_cut = false;               // the table's value halves are filled in (not by the developer form of the collect kernel)
+  unsigned long long* d_keys = nullptr; // collect: rank -> owner's record (zeroed behind every collect pass)
   uint64_t tab_cap = 0, cur_cap = 0;    // allocated slots / slots the current batch uses (both tables)
   unsigned long long* d_rec_key = nullptr; // records, one per (frame, seed) of the inserted tiles
   unsigned long long* d_rec_loc = nullptr;
@@ -536,7 +535,8 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
   }
   // (round 2 had a second form for windows of a few reads, the care loop unrolled for weight-16
   // seeds: 346 VGPRs + 14 spilled at h = 3.  With the shared halves the hash is a third of the
-  // instructions it was and the batches took the insert-heavy phases over: the form is gone.)
+  // instructions it was and the batches took the insert-heavy phases over: the form is gone — the
+  // CLI's silver run takes the same time with and without it, tools/dev/r3_latform.sh.)
   return go(k_query<HH, SFR, 0, false>);
 }
 

@@ -7,7 +7,7 @@ Writes a FASTQ of `reads` synthetic ONT-like reads (default 100 000 x 25 kb, G =
 geometry, ~5 GB of text) and runs goldrush-path on it the way bin/goldrush does — process #1
 (--silver_path -M 5 -r 0.9 -m 20000, bin/goldrush:253-260) and process #2 (golden path on the
 silver reads, :240-248) — with the reads kept on the device between the passes (default) and with
-the second parse (GRP_RESIDENT=off).  Wall time, the program's own phase timers, reads/s
+the second parse (GRP_RESIDENT=off); every run twice, the faster one counts.  Wall time, the program's own phase timers, reads/s
 FASTQ-inclusive; bench.py on the same geometry beside it."""
 import json
 import os
@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CLI = os.path.join(ROOT, "goldrush_amd", "bin", "goldrush-path")
 SEED = "1011011110110111101101"
+REPEATS = int(os.environ.get("CLI_E2E_REPEATS", "2"))
 
 
 def run_cli(args, env=None):
@@ -56,7 +57,9 @@ def main():
     for mode, env in (("resident", {}), ("second_parse", {"GRP_RESIDENT": "off"})):
         for name, extra in (("silver_M5", ["-r0.9", "--silver_path", "-M5", "-m20000", "-i", fq, "-p", os.path.join(pdir, "sp_" + mode)]),
                             ("golden_on_raw_reads", ["-m20000", "-i", fq, "-p", os.path.join(pdir, "gp_" + mode)])):
-            r = run_cli(base + extra, env)
+            runs = [run_cli(base + extra, env) for _ in range(REPEATS)]  # the first run on a fresh box also pays the code-object load
+            r = min(runs, key=lambda x: x["wall_s"])
+            r["wall_s_all"] = [round(x["wall_s"], 3) for x in runs]
             r["reads_per_s_fastq_inclusive"] = (r["visited"] or n_reads) / r["wall_s"]
             r["fastq_GB_per_s"] = size / r["wall_s"] / 1e9
             res["runs"][name + "/" + mode] = r
