@@ -5,7 +5,7 @@
 # fused batch queries) and with every seed hashed on its own: aux.counters and pop must be identical.
 cfg=${1:-C2}
 reads=${2:-700000}
-run() { env "$@" python3 bench.py --config $cfg --reads $reads --steps 4 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1; }
+run() { env "$@" python3 bench.py --config $cfg --reads $reads --steps 4 --no-cpu-baseline --no-pipeline-shaped 2>/dev/null | grep '^{' | tail -1; }
 run X=1 > /tmp/m1.json
 run X=2 > /tmp/m2.json
 run GRP_BATCH=off > /tmp/m3.json
