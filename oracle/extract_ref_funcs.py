@@ -17,6 +17,12 @@ the reference's own lines.  Nothing of this is ever copied into the repository.
                                              front of it needs MIBloomFilter / sdsl and cannot be
                                              built here; the shim opens a function whose
                                              parameters carry the names of the locals the tail uses.
+                      calc_num_assigned_tiles  two statement ranges INSIDE the per-tile loop that touch only
+                                             std::set / std::map locals: the tabulation of a frame's unique
+                                             IDs into the tile's count table, and the selection behind the
+                                             frame loop (highest count, ties to the smallest ID; the list of
+                                             IDs seen more than twice; its sort).  What feeds them — atRank,
+                                             getData, the saturation bit — needs MIBloomFilter and stays restated.
                       main                   the hash-universe statements (HASH_UNIVERSE_COEFFICIENT ...)
   MIBloomFilter.hpp   calcOptimalSize        whole (static member) function
 """
@@ -55,6 +61,20 @@ def main():
     assert tail.lstrip().startswith("for (size_t i = 0; i < num_tiles; ++i) {") and tail.rstrip().endswith("return num_assigned_tiles;\n}")
     assert "miBF" not in tail and "hashed_values" not in tail
     pieces["smooth_tail"] = tail
+    # inside the per-tile loop: tabulation of a frame's unique IDs, and the selection behind the frame loop
+    a = body.index("      for (const auto& unique_id :")
+    b = body.index("    uint32_t curr_id = 0;\n", a)
+    tab = body[a:b]
+    assert tab.rstrip().endswith("}\n    }") or tab.rstrip().endswith("}")
+    # the range ends with the closing brace of the frame loop: keep only the `for (unique_id ...) { ... }` statement
+    tab = tab[: tab.rindex("    }")]
+    assert tab.count("id_counts") >= 3 and "miBF" not in tab and tab.strip().endswith("}")
+    pieces["vote_tabulate"] = tab
+    c = body.index("    sort(id_counts_vec.begin(), id_counts_vec.end(), sort_by_sec);\n", b)
+    c = body.index("\n", c) + 1
+    sel = body[b:c]
+    assert "miBF" not in sel and "curr_id_count" in sel and "id_counts_vec.emplace_back" in sel
+    pieces["vote_select"] = sel
     # hash universe statements of main()
     a = gp.index("      static const uint8_t BASES = 4;")
     b = gp.index("hash_universe_base * HASH_UNIVERSE_COEFFICIENT * opt::hash_num;", a)

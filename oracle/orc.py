@@ -103,6 +103,7 @@ def load():
         "orcpy_mibf_data": (vp, [vp]), "orcpy_mibf_counts": (vp, [vp]), "orcpy_mibf_m": (u64, [vp]),
         "orcpy_sizeof_opts": (sz, []), "orcpy_sizeof_decision": (sz, []),
         "orc_query_tile": (sz, [vp, vp, sz, C.c_uint, C.POINTER(u32), C.POINTER(u32), vp, sz, vp]),
+        "orc_vote_tile": (sz, [vp, vp, sz, C.POINTER(u32), C.POINTER(u32), vp, sz]),
         "orc_smooth_tiles": (sz, [sz, vp, vp, vp, vp, sz, vp]),
         "orc_find_longest_stretch": (None, [vp, sz, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "orc_eval_flanks": (C.c_int, [C.c_long, C.c_long, vp, sz, C.POINTER(sz), C.POINTER(sz)]),
@@ -291,6 +292,21 @@ class MiBF:
             self.close()
         except Exception:
             pass
+
+
+def vote_tile(frames):
+    """The per-tile vote given every frame's IDs (goldrush_path.cpp:597-622).  frames: list of ID lists.
+    -> (top_id, top_count, [(id, count), ...] with count > 2, count descending then ID ascending)"""
+    lib = load()
+    off = np.zeros(len(frames) + 1, dtype=np.uint64)
+    for i, f in enumerate(frames):
+        off[i + 1] = off[i] + len(f)
+    ids = np.array([x for f in frames for x in f] + [0], dtype=np.uint32)
+    cap = max(int(off[-1]), 1)
+    lst = np.zeros(cap, dtype=id_count_dtype)
+    tid, tc = C.c_uint32(), C.c_uint32()
+    n = lib.orc_vote_tile(_p(ids), _p(off), len(frames), C.byref(tid), C.byref(tc), _p(lst), cap)
+    return tid.value, tc.value, [(int(a), int(c)) for a, c in lst[:n]]
 
 
 def smooth_tiles(ids, lists, threshold: int):

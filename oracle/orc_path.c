@@ -620,6 +620,68 @@ cmp_idcount_desc(const void* a, const void* b)
   return (x->id > y->id) - (x->id < y->id);
 }
 
+/* the tile's vote over every (frame, unique id) occurrence (:597-622): std::map order = ascending IDs,
+ * strict '>' keeps the smallest ID among equal counts, IDs seen more than twice go to the list,
+ * sorted by count (sort_by_sec).  Sorts `occ` in place. */
+static size_t
+vote_occurrences(uint32_t* occ, size_t n_occ, uint32_t* top_id, uint32_t* top_count, orc_id_count* list, size_t list_cap)
+{
+  qsort(occ, n_occ, sizeof(uint32_t), cmp_u32);
+  uint32_t curr_id = 0, curr_id_count = 0; /* :607-608 */
+  size_t n_list = 0;
+  for (size_t i = 0; i < n_occ;) {
+    size_t j = i;
+    while (j < n_occ && occ[j] == occ[i]) {
+      ++j;
+    }
+    uint32_t cnt = (uint32_t)(j - i);
+    if (cnt > curr_id_count) { /* :612-615 */
+      curr_id = occ[i];
+      curr_id_count = cnt;
+    }
+    if (cnt > 2) { /* :616-619 */
+      if (n_list < list_cap) {
+        list[n_list].id = occ[i];
+        list[n_list].count = cnt;
+      }
+      ++n_list;
+    }
+    i = j;
+  }
+  qsort(list, n_list < list_cap ? n_list : list_cap, sizeof(orc_id_count), cmp_idcount_desc); /* :622 */
+  *top_id = curr_id;
+  *top_count = curr_id_count;
+  return n_list;
+}
+
+/* The vote alone, given every frame's IDs (saturation bit stripped, no zeros; duplicates inside a
+ * frame count once, the reference's std::set): what tests/test_reference_funcs.py holds against
+ * the reference's own statements (oracle/_ref/libref_funcs.so: ref_vote_tile). */
+size_t
+orc_vote_tile(const uint32_t* ids, const uint64_t* frame_off, size_t n_frames, uint32_t* top_id, uint32_t* top_count, orc_id_count* list, size_t list_cap)
+{
+  const size_t n_all = (size_t)frame_off[n_frames];
+  uint32_t* occ = (uint32_t*)malloc((n_all ? n_all : 1) * sizeof(uint32_t));
+  size_t n_occ = 0;
+  for (size_t fr = 0; fr < n_frames; ++fr) {
+    const size_t first = n_occ;
+    for (uint64_t i = frame_off[fr]; i < frame_off[fr + 1]; ++i) {
+      int seen = 0;
+      for (size_t u = first; u < n_occ; ++u) {
+        if (occ[u] == ids[i]) {
+          seen = 1;
+        }
+      }
+      if (!seen) {
+        occ[n_occ++] = ids[i];
+      }
+    }
+  }
+  const size_t n_list = vote_occurrences(occ, n_occ, top_id, top_count, list, list_cap);
+  free(occ);
+  return n_list;
+}
+
 size_t
 orc_query_tile(const orc_mibf* f,
                const uint64_t* hashes,
@@ -677,32 +739,8 @@ orc_query_tile(const orc_mibf* f,
       occ[n_occ++] = unique_ids[u];
     }
   }
-  qsort(occ, n_occ, sizeof(uint32_t), cmp_u32);
-  uint32_t curr_id = 0, curr_id_count = 0; /* :607-608 */
-  size_t n_list = 0;
-  for (size_t i = 0; i < n_occ;) {
-    size_t j = i;
-    while (j < n_occ && occ[j] == occ[i]) {
-      ++j;
-    }
-    uint32_t cnt = (uint32_t)(j - i);
-    if (cnt > curr_id_count) { /* :612-615 */
-      curr_id = occ[i];
-      curr_id_count = cnt;
-    }
-    if (cnt > 2) { /* :616-619 */
-      if (n_list < list_cap) {
-        list[n_list].id = occ[i];
-        list[n_list].count = cnt;
-      }
-      ++n_list;
-    }
-    i = j;
-  }
-  qsort(list, n_list < list_cap ? n_list : list_cap, sizeof(orc_id_count), cmp_idcount_desc); /* :622 */
+  const size_t n_list = vote_occurrences(occ, n_occ, top_id, top_count, list, list_cap);
   free(occ);
-  *top_id = curr_id;
-  *top_count = curr_id_count;
   if (counters) {
     counters[0] += q;
     counters[1] += hits;

@@ -141,6 +141,12 @@ size_t orc_query_tile(const orc_mibf* f,
                       size_t list_cap,
                       uint64_t counters[3]);
 
+/* The vote of orc_query_tile alone, given every frame's IDs: frame f holds ids[frame_off[f] ..
+ * frame_off[f+1]) — saturation bit stripped, no zeros; duplicates inside a frame count once
+ * (std::set, :569).  Pinned against the reference's own statements (:597-622,
+ * tests/test_reference_funcs.py). */
+size_t orc_vote_tile(const uint32_t* ids, const uint64_t* frame_off, size_t n_frames, uint32_t* top_id, uint32_t* top_count, orc_id_count* list, size_t list_cap);
+
 /* ---- threshold + smoothing passes (:628-889) ----------------------------- */
 /*
  * In: per-tile top id (ids[]), per-tile count>2 lists (lists[i], list_n[i]).

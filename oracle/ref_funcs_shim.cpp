@@ -3,8 +3,10 @@
 // oracle/extract_ref_funcs.py cuts them out of /root/reference at build time into the
 // git-ignored oracle/_ref/extract/*.inc (whole functions: log_tile_states, sort_by_sec,
 // find_longest_stretch, eval_flanks, MIBloomFilter::calcOptimalSize; the tail of
-// calc_num_assigned_tiles behind its per-tile query loop; the hash-universe statements of
-// main) and this file compiles them unchanged.  The reference's own opt.cpp is compiled next
+// calc_num_assigned_tiles behind its per-tile query loop and, inside that loop, the two statement
+// ranges that only touch std::set / std::map locals — a frame's unique IDs tabulated into the tile's
+// count table, the selection of the tile's ID and list; the hash-universe statements of main) and
+// this file compiles them unchanged.  The reference's own opt.cpp is compiled next
 // to it for the opt:: variables those lines read.  This file contains no reference code.
 #include "opt.hpp"
 
@@ -14,6 +16,7 @@
 #include <cstdio>
 #include <iostream>
 #include <map>
+#include <set>
 #include <string>
 #include <sys/types.h>
 #include <tuple>
@@ -81,6 +84,29 @@ ref_smooth_tiles(size_t n, uint32_t* ids, uint8_t* bools_out, const uint64_t* li
     bools_out[i] = bool_vec[i];
   }
   return r;
+}
+
+// The per-tile vote given every frame's IDs (goldrush_path.cpp: the statements of the per-tile loop
+// behind getData): frame f holds ids[frame_off[f] .. frame_off[f+1]) — already stripped of the
+// saturation bit, no zeros; duplicates inside a frame allowed (the std::set removes them, as in the
+// reference).  Returns the tile's ID; *top_count its count; the (id, count) pairs with count > 2 in
+// the reference's order (std::sort with sort_by_sec) in list_ids / list_counts.
+uint32_t
+ref_vote_tile(const uint32_t* ids, const uint64_t* frame_off, size_t n_frames, uint32_t* top_count, uint32_t* list_ids, uint32_t* list_counts, size_t list_cap, size_t* list_n)
+{
+  std::map<uint32_t, std::pair<uint32_t, uint32_t>> id_counts;
+  for (size_t fr = 0; fr < n_frames; ++fr) {
+    std::set<uint32_t> unique_ids(ids + frame_off[fr], ids + frame_off[fr + 1]);
+#include "_ref/extract/vote_tabulate.inc"
+  }
+#include "_ref/extract/vote_select.inc"
+  *top_count = curr_id_count;
+  *list_n = id_counts_vec.size();
+  for (size_t i = 0; i < id_counts_vec.size() && i < list_cap; ++i) {
+    list_ids[i] = id_counts_vec[i].first;
+    list_counts[i] = id_counts_vec[i].second;
+  }
+  return curr_id;
 }
 
 uint64_t

@@ -82,7 +82,7 @@ def make_funcs():
 
     rf = ref_funcs.RefFuncs()
     out = {"source": "bcgsc/goldrush goldrush_path/goldrush_path.cpp (find_longest_stretch, eval_flanks, sort_by_sec, tail of calc_num_assigned_tiles, "
-                     "hash-universe statements of main) and MIBloomFilter.hpp (calcOptimalSize): the reference's own lines, cut out at build time and compiled (oracle/Makefile `ref`)",
+                     "the vote statements inside its per-tile loop, hash-universe statements of main) and MIBloomFilter.hpp (calcOptimalSize): the reference's own lines, cut out at build time and compiled (oracle/Makefile `ref`)",
            "tiles": [], "sizes": []}
     rng = np.random.default_rng(20261003)
     cases = []
@@ -110,9 +110,17 @@ def make_funcs():
     for entries in (1, 63, 64, 1000, 3_000_000, 6_442_450_944, 10_737_418_240, 2**40 + 12345):
         for hn, occ in ((1, 0.1), (3, 0.1), (1, 0.9)):
             out["sizes"].append({"entries": entries, "hash_num": hn, "occupancy": occ, "m": rf.calc_optimal_size(entries, hn, occ)})
+    # the per-tile vote given the frames' IDs (the statements of the per-tile loop behind getData)
+    out["votes"] = []
+    rng = np.random.default_rng(20261004)
+    for i in range(160):
+        frames = ref_funcs.random_frames(rng, max_frames=(400 if i % 20 == 0 else 60))
+        tid, tc, lst = rf.vote_tile(frames)
+        assert all(lst[j][1] >= lst[j + 1][1] for j in range(len(lst) - 1))  # sort_by_sec: count descending
+        out["votes"].append({"frames": frames, "id": tid, "count": tc, "list": [list(e) for e in ref_funcs.canon_vote((tid, tc, lst))[2]]})
     with open(os.path.join(HERE, "reference_funcs.json"), "w") as f:
         json.dump(out, f, separators=(",", ":"))
-    print("tile states %d, sizes %d" % (len(out["tiles"]), len(out["sizes"])))
+    print("tile states %d, sizes %d, votes %d" % (len(out["tiles"]), len(out["sizes"]), len(out["votes"])))
 
 
 if __name__ == "__main__":

@@ -24,7 +24,21 @@ class RefFuncs:
         lib.ref_calc_optimal_size.argtypes = [C.c_uint64, C.c_uint, C.c_double]
         lib.ref_hash_universe.restype = C.c_uint64
         lib.ref_hash_universe.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        lib.ref_vote_tile.restype = C.c_uint32
+        lib.ref_vote_tile.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32), vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         self.lib = lib
+
+    def vote_tile(self, frames):
+        """The reference's own vote statements on the frames' IDs -> (id, count, [(id, count) ...] in ITS order)."""
+        off = np.zeros(len(frames) + 1, dtype=np.uint64)
+        for i, f in enumerate(frames):
+            off[i + 1] = off[i] + len(f)
+        ids = np.array([x for f in frames for x in f] + [0], dtype=np.uint32)
+        cap = max(int(off[-1]), 1)
+        li, lc = np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32)
+        tc, n = C.c_uint32(), C.c_size_t()
+        tid = self.lib.ref_vote_tile(ids.ctypes.data, off.ctypes.data, len(frames), C.byref(tc), li.ctypes.data, lc.ctypes.data, cap, C.byref(n))
+        return int(tid), int(tc.value), [(int(li[i]), int(lc[i])) for i in range(n.value)]
 
     def smooth_tiles(self, ids, lists, threshold):
         """ids: top ID per tile; lists: per tile [(id, count), ...] count descending.  -> (ids, bools, assigned)"""
@@ -108,3 +122,25 @@ def tiles_from_pattern(pat, id0=7, step=0, count_hi=40, count_lo=4):
         ids.append(tid)
         lists.append([(tid, count_hi if p else count_lo)])
     return ids, lists
+
+
+def random_frames(rng, max_frames=120):
+    """The IDs each frame of a tile returns (after the saturation bit is stripped, zeros dropped): a small
+    pool, so that counts tie, sit at the `> 2` border of the list and repeat inside a frame (the
+    reference's std::set counts a frame once per ID)."""
+    pool = [int(v) for v in rng.integers(1, 40, size=int(rng.integers(1, 7)))]
+    if rng.random() < 0.2:
+        pool += [0xFFFFFFFF, 0x7FFFFFFF]
+    n = int(rng.integers(0, max_frames + 1))
+    frames = []
+    for _ in range(n):
+        k = int(rng.choice([0, 0, 1, 1, 2, 3, 5]))
+        frames.append([int(pool[i]) for i in rng.integers(0, len(pool), size=k)])
+    return frames
+
+
+def canon_vote(res):
+    """(id, count, list) with the list in the canonical order count descending, ID ascending (the reference's
+    std::sort leaves equal counts in an unspecified order; only list[0].second and membership are consumed)"""
+    tid, tc, lst = res
+    return tid, tc, sorted(((int(a), int(c)) for a, c in lst), key=lambda t: (-t[1], t[0]))

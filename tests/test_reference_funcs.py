@@ -1,7 +1,9 @@
 """The oracle AND the product host (and, under -m gpu, the device's decision kernel) against the
 reference's OWN lines for the libstdc++-only part of the hot path's host logic:
 find_longest_stretch, eval_flanks, sort_by_sec, the tail of calc_num_assigned_tiles (threshold
-test + smoothing passes P1..P10 + final count), MIBloomFilter::calcOptimalSize and the
+test + smoothing passes P1..P10 + final count), the vote statements inside its per-tile loop
+(tabulation of a frame's unique IDs, selection of the tile's ID and list),
+MIBloomFilter::calcOptimalSize and the
 hash-universe arithmetic of main — cut out of /root/reference at build time and compiled
 unchanged (oracle/Makefile `ref`, oracle/extract_ref_funcs.py, oracle/ref_funcs_shim.cpp).
 
@@ -96,6 +98,25 @@ def test_filter_sizing_matches_the_reference(gold, oracle, host):
     assert seen >= 60
 
 
+def test_tile_vote_matches_the_reference(gold, oracle):
+    """The per-tile vote (goldrush_path.cpp:597-622: a frame's unique IDs tabulated into the tile's
+    std::map, the highest count with ties to the smallest ID, the list of IDs seen more than twice) —
+    the oracle's restatement, which the device's k_query is held against in the -m gpu parity tests,
+    on the frames' IDs of the fixture, against what the reference's own statements return."""
+    assert len(gold["votes"]) >= 150
+    ties = big = 0
+    for c in gold["votes"]:
+        got = ref_funcs.canon_vote(oracle.vote_tile(c["frames"]))
+        assert got == (c["id"], c["count"], [tuple(e) for e in c["list"]]), c["frames"]
+        counts = {}
+        for f in c["frames"]:
+            for i in set(f):
+                counts[i] = counts.get(i, 0) + 1
+        ties += sum(1 for v in counts.values() if v == c["count"]) > 1
+        big += len(c["list"]) >= 2
+    assert ties >= 10 and big >= 30  # the fixture does exercise ties for the maximum and multi-entry lists
+
+
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="/root/reference is only present in the build container")
 def test_fixture_is_what_the_reference_computes_now(gold, oracle, host):
     """Rebuild the library from the reference's lines, re-derive the committed fixture, and compare
@@ -110,6 +131,14 @@ def test_fixture_is_what_the_reference_computes_now(gold, oracle, host):
         if "w" in c:
             assert rf.hash_universe(c["w"], c["g"], c["h"]) == c["universe"]
             assert rf.calc_optimal_size(c["universe"], 1, c["occupancy"]) == c["m"]
+    for c in gold["votes"][::5]:
+        assert ref_funcs.canon_vote(rf.vote_tile(c["frames"])) == (c["id"], c["count"], [tuple(e) for e in c["list"]])
+    rng = np.random.default_rng(98)
+    for i in range(3000):  # the vote, live: oracle against the reference's statements
+        frames = ref_funcs.random_frames(rng, max_frames=(600 if i % 50 == 0 else 80))
+        raw = rf.vote_tile(frames)
+        assert all(raw[2][j][1] >= raw[2][j + 1][1] for j in range(len(raw[2]) - 1))
+        assert ref_funcs.canon_vote(oracle.vote_tile(frames)) == ref_funcs.canon_vote(raw), frames
     rng = np.random.default_rng(99)
 
     def live(ids, lists, x):
