@@ -190,3 +190,53 @@ def test_device_decision_kernel_matches_the_reference(gold, native):
             got = (int(dec[i]["kind"]), int(dec[i]["trim_start"]) if dec[i]["kind"] == 4 else 0, int(dec[i]["trim_end"]) if dec[i]["kind"] == 4 else 0)
             assert got == want and int(dec[i]["num_assigned"]) == c["assigned"] and int(dec[i]["num_tiles"]) == b - a, (i, c["ids"], c["lists"])
     eng.close()
+
+
+@pytest.mark.gpu
+def test_device_vote_matches_the_reference_statements(native, oracle):
+    """k_query's per-tile vote against the reference's OWN vote statements (goldrush_path.cpp:597-622,
+    oracle/_ref/libref_funcs.so — the compiled library travels to the GPU box; without it the oracle's
+    restatement, which the CPU suite pins to the same statements, stands in): the filter is filled from
+    random reads, every set bit gets an ID from a small pool (ties, counts at the `> 2` border, saturated
+    values, empty slots), the frames' IDs are read back rank by rank (device hashes and ranks) and voted
+    on by the reference; the kernel's tile summary — ID, count, the count > 2 list — must be that vote."""
+    from helpers import canon_list, default_seeds, random_reads
+
+    rf = ref_funcs.RefFuncs() if os.path.exists(ref_funcs.LIB) else None
+    k, tile = 22, 1000
+    for h, pool_size in ((3, 3), (3, 40), (5, 12), (1, 5)):
+        m = oracle.load().orc_calc_optimal_size(250_000, 1, 0.1)
+        eng = native.Engine(k, h, tile, m, default_seeds(h))
+        reads = random_reads(5, 2300, 4800, seed=60 + h + pool_size)
+        b = eng.upload(reads)
+        eng.bv_insert(b)
+        pop = eng.finalize()
+        rng = np.random.default_rng(h * 100 + pool_size)
+        ids = rng.integers(0, pool_size + 1, size=pop, dtype=np.uint32)  # 0 = empty
+        sat = rng.random(pop) < 0.08
+        ids[sat] |= np.uint32(0x80000000)  # includes the bare saturation bit
+        eng.import_ids(0, ids=ids, counts=np.zeros(pop, dtype=np.uint32))
+        tiles, lists, _ = eng.query_tiles(b)
+        ti = 0
+        for ri, seq in enumerate(reads):
+            for t in range(len(seq) // tile):
+                hv = eng.tile_hashes(b, ri, t).reshape(-1, h)  # [frame][seed]
+                bit, rank = eng.rank((hv % np.uint64(m)).ravel())
+                bit, rank = bit.reshape(-1, h), rank.reshape(-1, h)
+                frames = []
+                for fr in range(hv.shape[0]):
+                    if not bit[fr].all():  # atRank: one clear bit and the frame counts nothing
+                        frames.append([])
+                        continue
+                    d = ids[rank[fr]]
+                    # goldrush_path.cpp:573-594: only values ABOVE the mask are stripped — the bare saturation bit
+                    # (0x80000000, "saturated, no ID") is neither above it nor zero and is counted as an ID
+                    d = np.where(d > 0x80000000, d & 0x7FFFFFFF, d)
+                    frames.append([int(x) for x in d if x != 0])
+                want = ref_funcs.canon_vote(rf.vote_tile(frames) if rf else oracle.vote_tile(frames))
+                got = tiles[ti]
+                glist = [(int(a), int(c)) for a, c in lists[got["list_off"]: got["list_off"] + got["list_n"]]]
+                assert (int(got["top_id"]), int(got["top_count"]), glist) == (want[0], want[1], canon_list(want[2])), (h, pool_size, ri, t)
+                ti += 1
+        assert ti == len(tiles)
+        eng.close()
