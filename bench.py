@@ -165,7 +165,7 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
     mh = p.mibf_handle()
     assert lib.orcpy_mibf_pop(mh) == pop, "the oracle's rank build disagrees with the GPU's"
 
-    def timed(first, count):
+    def timed(first, count, budget_s=budget_s):
         t0 = time.time()
         done = ins = 0
         for i in range(first, first + count):
@@ -176,7 +176,7 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
                 break
         return done, ins, time.time() - t0
 
-    h_done, h_ins, h_dt = timed(0, n_s)
+    h_done, h_ins, h_dt = timed(0, n_s, 2.0 * budget_s)  # the slow regime (~10 reads/s at C2) gets two thirds of the ~30 s
     if silver:  # every silver path is an insert-heavy head: no steady state to compare
         p.close()
         for f in os.listdir(tmp):
