@@ -400,6 +400,19 @@ class Engine:
     def bv_import_device(self, d_ptr: int):
         self._check(self.lib.grp_bv_import_device(self._h, C.c_void_p(d_ptr)))
 
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = self.lib.grp_comm_unique_id(buf, 128)
+        if rc != 0:
+            raise GrpError(rc, "grp_comm_unique_id failed (librccl.so missing?)")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, world: int, rank: int):
+        self._check(self.lib.grp_comm_init(self._h, unique_id, world, rank))
+
+    def bv_merge_ranks(self):
+        self._check(self.lib.grp_bv_merge_ranks(self._h))
+
     def finalize(self) -> int:
         pop = C.c_uint64()
         self._check(self.lib.grp_finalize(self._h, C.byref(pop)))

@@ -548,3 +548,33 @@ def test_bit_vector_merge_primitives(native):
     a.close()
     b.close()
     dr.free()
+
+
+def test_rccl_merge_entry_points_on_a_communicator_of_one(native):
+    """grp_comm_unique_id / grp_comm_init / grp_bv_merge_ranks — the engine's own RCCL calls (dlopen of
+    librccl.so, ncclCommInitRank with the by-value id, ncclAllToAll, the OR pass, ncclAllGather on the
+    engine's stream) — as far as ONE GPU can run them: a communicator of one rank, whose merge must leave
+    the bit vector as it is (a vector whose word count is not a multiple of the slice padding included).
+    Two ranks on one device are refused by RCCL and take the staged merge (tests/test_gpu_cli.py)."""
+    seeds = default_seeds(3)
+    dr = native.synth_reads(300, 2_000_000, mean_len=8000, min_len=6000)
+    for m in (150_000_000, 150_000_067):
+        eng = native.Engine(K, 3, TILE, m, seeds)
+        b = eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
+        eng.bv_insert(b)
+        eng.sync()
+        before = eng.export_bits()
+        uid = eng.comm_unique_id()
+        assert len(uid) == 128 and any(uid)
+        eng.comm_init(uid, 1, 0)
+        with pytest.raises(native.GrpError):
+            eng.comm_init(uid, 1, 0)  # one communicator per context
+        eng.bv_merge_ranks()
+        eng.bv_merge_ranks()
+        assert np.array_equal(eng.export_bits(), before)
+        pop = eng.finalize()
+        assert pop == int(np.unpackbits(before.view(np.uint8)).sum())
+        with pytest.raises(native.GrpError):
+            eng.bv_merge_ranks()  # only between the fill and grp_finalize
+        eng.close()
+    dr.free()
