@@ -187,7 +187,8 @@ int grp_bv_import_device(grp_ctx* ctx, const void* d_src);
  * collectives (the goldrush-path binary, one process per GPU): RCCL straight from the library
  * (librccl.so, loaded on first use) over xGMI, on the context's stream —
  *   grp_comm_unique_id  rank 0: the 128 bytes of an ncclUniqueId, handed to the other ranks by the host
- *   grp_comm_init       every rank: ncclCommInitRank on the context's device
+ *   grp_comm_init       every rank: ncclCommInitRank on the context's device (world >= 1: a communicator
+ *                       of one rank is valid, its merge leaves the vector as it is)
  *   grp_bv_merge_ranks  every rank, after its share of grp_bv_insert, before grp_finalize:
  *                       bv = OR over all ranks (ncclAllToAll of the slices, OR, ncclAllGather)
  * and, for ranks that cannot form a communicator (several ranks on ONE device: the plumbing tests of
