@@ -138,6 +138,12 @@ struct BatchRun
   uint64_t log_cap = 0;
   uint32_t* d_floor = nullptr;    // grp_batch_classify: per read of the window
   uint64_t floor_cap = 0;
+  // grp_batch_verify: the window's tiles with records, then the tiles queried again; per read its insert entry
+  std::vector<uint32_t> h_vf_tiles, h_vf_read_ins;
+  uint32_t* d_vf_tiles = nullptr;
+  uint64_t vf_tiles_cap = 0;
+  uint32_t* d_vf_read_ins = nullptr;
+  uint64_t vf_read_ins_cap = 0;
   uint32_t first_read = 0;        // reads are numbered from here in the log
 };
 
@@ -198,6 +204,7 @@ struct grp_ctx
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
 
   uint64_t n_flagged_tiles = 0; // statistics
+  uint64_t n_verify_tiles = 0, n_verify_queried = 0, n_verify_flagged = 0, n_verify_fallbacks = 0, n_verify_uncertified = 0, n_verify_unpatched = 0; // grp_batch_verify: tiles patched from records / queried again / patched tiles redone / calls that took the second query
   uint64_t n_direct_windows = 0, n_direct_fallbacks = 0, n_general_windows = 0, n_redo_launches = 0; // GRP_DEBUG_STATS
   uint64_t n_chunks = 0; // rank-build chunks
   uint64_t* d_super = nullptr;
@@ -215,6 +222,17 @@ struct grp_ctx
   // host commits the first (grp_classify_reads_begin / _end)
   QuerySlot slot[2];
   QuerySlot* q = &slot[0];
+  // first decisions kept for grp_batch_verify: slot `slot` holds, from tile `tile_off` of its buffers on, the plain
+  // tile summaries of reads [first, first + count) of `reads` against the filter as it is (as it was in front of the
+  // batch, between grp_batch_insert_reads and grp_batch_end / _undo).  Dropped by whatever changes the filter or the slot.
+  struct Carry
+  {
+    bool valid = false;
+    uint32_t slot = 0;
+    const grp_reads* reads = nullptr;
+    uint32_t first = 0, count = 0;
+    uint64_t tile_off = 0;
+  } carry;
   const DevBatchView* view = nullptr; // set while grp_batch_classify enqueues its window
   grp_tile_summary* h_tiles = nullptr; // pinned staging
   uint64_t h_tiles_cap = 0;
@@ -242,7 +260,7 @@ struct grp_ctx
   double* d_delog = nullptr; // 10^(-Q/10) table for the FASTQ ingest
   const char* reg_text = nullptr; // the caller's text buffer, page-locked by grp_fastq_pin
   size_t reg_bytes = 0;
-  uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT);
+  uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT) | (1u << GRP_K_VERIFY);
   // timing
   bool timing = true;
   std::vector<EventPair> pending;
@@ -491,7 +509,10 @@ query_geom(const grp_ctx* c, bool full)
 
 template<int HH>
 int
-launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, const uint32_t* d_tile_idx, const QueryGeom& g, uint64_t list_cap, grp_tile_summary* out_tiles = nullptr, grp_id_count* out_lists = nullptr, uint32_t direct_stride = 0, const DevStreamCtl* stream_ctl = nullptr)
+launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, const uint32_t* d_tile_idx, const QueryGeom& g, uint64_t list_cap, grp_tile_summary* out_tiles = nullptr, grp_id_count* out_lists = nullptr, uint32_t direct_stride = 0, const DevStreamCtl* stream_ctl = nullptr,
+             uint32_t blk0 = 0,          // no tile list: the launch covers tiles [blk0, blk0 + n_launch) of the window
+             bool list_flags = false,    // a tile list that is NOT the redo of flagged tiles: flagged tiles are collected as without a list
+             bool plain = false)         // the plain query even while a batch view is set (the reads behind the batch)
 {
   if (!out_tiles) {
     out_tiles = c->q->d_tiles;
@@ -502,14 +523,14 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     if (rc != GRP_OK) {
       return rc;
     }
-    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), d_tile_idx ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, stream_ctl ? *stream_ctl : DevStreamCtl{}, c->view ? *c->view : DevBatchView{});
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, blk0, stream_ctl ? *stream_ctl : DevStreamCtl{}, (c->view && !plain) ? *c->view : DevBatchView{});
     return GRP_OK;
   };
   // The synchronous forms (large windows, the two queries of a batch): two frames per lane and pass
   // up to h = 3; from h = 4 on one frame per lane with the software-pipelined pass (222 -> 171 VGPRs
   // at h = 5; C4 geometry +4 %, h = 3 -3 %: measured, tools/dev/r3_fr1.sh)
   constexpr int SFR = (HH <= 3) ? 2 : 1;
-  if (c->view && !stream_ctl) { // grp_batch_classify: every read sees the state in front of its own insert
+  if (c->view && !stream_ctl && !plain) { // grp_batch_classify: every read sees the state in front of its own insert
     return go(k_query<HH, SFR, 0, false, true>);
   }
   if (stream_ctl) {
@@ -849,6 +870,8 @@ grp_destroy(grp_ctx* c)
     (void)hipFree(b.d_log_next);
     (void)hipFree(b.d_log_slot);
     (void)hipFree(b.d_floor);
+    (void)hipFree(b.d_vf_tiles);
+    (void)hipFree(b.d_vf_read_ins);
   }
   (void)hipFree(c->d_ntc);
   (void)hipFree(c->d_ntc_chunks);
@@ -1395,6 +1418,9 @@ grp_query_tiles(grp_ctx* c,
                 uint64_t* list_used,
                 grp_query_stats* stats)
 {
+  if (c) {
+    c->carry.valid = false;
+  }
   if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads) {
     return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: bad range");
   }
@@ -1649,8 +1675,9 @@ classify_enqueue(grp_ctx* c, QuerySlot& sl, bool side)
 
 extern "C" {
 
+// the slot's buffers and fields for a window of reads [first, first + count); nothing is enqueued
 static int
-classify_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, bool side)
+classify_setup(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot)
 {
   if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads || !dp || slot > 1) {
     return set_err(c, GRP_ERR_INVALID, "grp_classify_reads_begin: bad argument");
@@ -1706,7 +1733,20 @@ classify_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, c
     sl.d_dec_cap = cap;
   }
   sl.list_cap = std::max<uint64_t>(sl.d_lists_cap, 4 * nt + 4096);
-  return classify_enqueue(c, sl, side);
+  return GRP_OK;
+}
+
+static int
+classify_begin(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, bool side)
+{
+  int rc = classify_setup(c, r, first, count, dp, slot);
+  if (rc != GRP_OK || count == 0) {
+    return rc;
+  }
+  if (c) {
+    c->carry.valid = false; // the slot's summaries are about to be replaced
+  }
+  return classify_enqueue(c, c->slot[slot], side);
 }
 
 int
@@ -1782,7 +1822,17 @@ grp_classify_reads(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t coun
     }
     return rc;
   }
-  return grp_classify_reads_end(c, 0, out);
+  rc = grp_classify_reads_end(c, 0, out);
+  if (rc == GRP_OK && !c->view && count) {
+    // plain summaries of [first, first + count) stay in slot 0: grp_batch_verify patches them instead of asking again
+    c->carry.valid = true;
+    c->carry.slot = 0;
+    c->carry.reads = r;
+    c->carry.first = first;
+    c->carry.count = count;
+    c->carry.tile_off = 0;
+  }
+  return rc;
 }
 
 // ---- streaming window --------------------------------------------------------------
@@ -1843,6 +1893,9 @@ grp_classify_stream_begin_resumable(grp_ctx* c, const grp_reads* r, uint32_t fir
 static int
 stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions, bool want_resumable)
 {
+  if (c) {
+    c->carry.valid = false;
+  }
   if (!c || !r || r->ctx != c || (uint64_t)first + count > r->n_reads || !dp || slot > 1 || !decisions || n_owners == 0 || owner >= n_owners ||
       (n_owners > 1 && stripe_reads == 0)) {
     return set_err(c, GRP_ERR_INVALID, "grp_classify_stream_begin: bad argument");
@@ -2150,6 +2203,9 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
 int
 grp_classify_stream_insert(grp_ctx* c, uint32_t slot, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset, uint32_t* generation)
 {
+  if (c) {
+    c->carry.valid = false;
+  }
   if (!c || slot > 1 || !c->slot[slot].busy || !c->slot[slot].streaming || block_tiles == 0 || id_offset > 1 || !generation) {
     return set_err(c, GRP_ERR_STATE, "grp_classify_stream_insert: no streaming window in this slot / bad argument");
   }
@@ -2220,6 +2276,9 @@ grp_classify_stream_insert(grp_ctx* c, uint32_t slot, uint32_t read_idx, uint32_
 int
 grp_insert_tiles(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t id)
 {
+  if (c) {
+    c->carry.valid = false;
+  }
   if (!c || !r || r->ctx != c || read_idx >= r->n_reads) {
     return set_err(c, GRP_ERR_INVALID, "grp_insert_tiles: bad read index");
   }
@@ -2265,6 +2324,9 @@ grp_insert_tiles(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t til
 int
 grp_insert_read(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset)
 {
+  if (c) {
+    c->carry.valid = false;
+  }
   if (!c || !r || r->ctx != c || read_idx >= r->n_reads || block_tiles == 0 || id_offset > 1) {
     return set_err(c, GRP_ERR_INVALID, "grp_insert_read: bad argument");
   }
@@ -2318,6 +2380,9 @@ grp_insert_read(grp_ctx* c, const grp_reads* r, uint32_t read_idx, uint32_t tile
 int
 grp_reset_ids(grp_ctx* c)
 {
+  if (c) {
+    c->carry.valid = false;
+  }
   if (!c || !c->finalized) {
     return set_err(c, GRP_ERR_STATE, "grp_reset_ids before grp_finalize");
   }
@@ -2438,6 +2503,9 @@ grp_export_ids(grp_ctx* c, uint64_t first, uint64_t n, uint32_t* ids, uint32_t* 
 int
 grp_import_ids(grp_ctx* c, uint64_t first, uint64_t n, const uint32_t* ids, const uint32_t* counts)
 {
+  if (c) {
+    c->carry.valid = false;
+  }
   if (!c || !c->finalized || first + n > c->f.pop) {
     return set_err(c, GRP_ERR_INVALID, "grp_import_ids: bad range");
   }
@@ -2656,6 +2724,7 @@ grp_stream(grp_ctx* c)
 
 #include "grp_loop_host.inc"
 #include "grp_batch.inc"
+#include "grp_verify.inc"
 #include "grp_ingest.inc"
 #include "grp_ntcard.inc"
 #include "grp_comm.inc"

@@ -1133,6 +1133,10 @@ Classifier::batch_round(uint32_t& pos)
       }
       std::copy(dec_all_.begin(), dec_all_.begin() + cnt, bdec1_.begin());
     }
+  } else if (vt_.batch_verify) {
+    // round 4: the inserted tiles are patched from the batch's own records, only the tiles the batch did
+    // not insert are queried again; the reads behind the batch take the plain query (include/grpath.h)
+    rc = vt_.batch_verify(ctx_, rg_.reads, base_ + pos, cnt, extra, &dp, bfloor_.data(), bdec1_.data());
   } else {
     rc = vt_.batch_classify(ctx_, rg_.reads, base_ + pos, cnt + extra, &dp, bfloor_.data(), bdec1_.data());
   }

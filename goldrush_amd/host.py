@@ -90,6 +90,7 @@ VT_TYPES = [
     ("bv_or_words", C.CFUNCTYPE(C.c_int, _vp, C.c_uint64, C.c_uint64, _vp)),
     ("fastq_pin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64)),
     ("fastq_unpin", C.CFUNCTYPE(C.c_int, _vp)),
+    ("batch_verify", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp)),
 ]
 
 

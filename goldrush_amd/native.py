@@ -21,8 +21,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libgrpath_hip.so")
 
 GRP_OK = 0
 GRP_ERR_INVALID, GRP_ERR_NO_DEVICE, GRP_ERR_HIP, GRP_ERR_STATE, GRP_ERR_NOMEM, GRP_ERR_BUSY = -1, -2, -3, -4, -5, -6
-GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_LOOP, GRP_K_QUERY_LAT, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8
-KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard", "loop", "query_latency")
+GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_LOOP, GRP_K_QUERY_LAT, GRP_K_VERIFY, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard", "loop", "query_latency", "verify")
 GRP_LOOP_RUNNING, GRP_LOOP_DONE, GRP_LOOP_ROLLOVER, GRP_LOOP_HANDBACK, GRP_LOOP_STOPPED, GRP_LOOP_TIMEOUT = 0, 1, 2, 3, 4, 5
 
 
@@ -119,6 +119,8 @@ SIGNATURES = {
     "grp_commit_loop_end": (C.c_int, [_vp, C.POINTER(grp_loop_result)]),
     "grp_batch_insert_reads": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_batch_classify": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp, _vp]),
+    "grp_batch_verify": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp, _vp]),
+    "grp_debug_verify_stats": (C.c_int, [_vp, _vp]),
     "grp_batch_undo": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "grp_batch_end": (C.c_int, [_vp]),
     "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -551,6 +553,21 @@ class Engine:
         dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
         self._check(self.lib.grp_batch_classify(self._h, batch._h, first, count, C.byref(dp), _ptr(fl), _ptr(out)))
         return out
+
+    def batch_verify(self, batch: ReadBatch, first: int, count: int, extra: int, id_floor, threshold=10, unassigned_min=5, assigned_max=1):
+        """the second decisions of the batch's reads [first, first + count) from the batch's records (and `extra`
+        reads behind them through the plain query); id_floor: count + extra entries"""
+        out = np.zeros(count + extra, dtype=decision_dtype)
+        fl = np.ascontiguousarray(id_floor, dtype=np.uint32)
+        assert fl.shape[0] == count + extra
+        dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
+        self._check(self.lib.grp_batch_verify(self._h, batch._h, first, count, extra, C.byref(dp), _ptr(fl), _ptr(out)))
+        return out
+
+    def verify_stats(self) -> dict:
+        out = np.zeros(7, dtype=np.uint64)
+        self._check(self.lib.grp_debug_verify_stats(self._h, _ptr(out)))
+        return dict(zip(("patched", "queried", "flagged", "fallbacks", "uncertified", "unpatched", "window_flagged"), (int(x) for x in out)))
 
     def batch_undo(self, from_read: int, id_floor: int):
         """takes back the inserts of reads >= from_read (batch index); id_floor = the first ID read from_read could allocate"""

@@ -528,6 +528,28 @@ typedef struct
 
 int grp_batch_insert_reads(grp_ctx* ctx, const grp_reads* reads, const grp_batch_insert* inserts, uint32_t n_inserts, uint32_t block_tiles, uint32_t first_read);
 int grp_batch_classify(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, const uint32_t* id_floor, grp_read_decision* decisions_out);
+/*
+ * Step 3 without the second query of the tiles the batch inserted (round 4).  The collect pass of
+ * grp_batch_insert_reads has visited every probe of every inserted tile and knows which of their ranks
+ * a second (read, ID block) of the batch touches; every other probe reads, in front of its own read's
+ * insert, what the first query read in front of the batch.  grp_batch_verify therefore takes the FIRST
+ * decisions' tile summaries — kept by the engine: of the grp_classify_reads call that produced them, or
+ * of the previous grp_batch_verify's `extra` reads — evaluates only the frames with a probe on such a
+ * rank (through the same log as grp_batch_classify, in front of the batch and in front of the read's own
+ * insert) and patches the summaries with what those frames lost and gained; a tile whose new top ID
+ * cannot be certified from what the summary holds is queried again.  Tiles without records (reads that
+ * do not insert, the rest of a trimmed read) are queried again as by grp_batch_classify.
+ *   first         the batch's first read (= first_read of grp_batch_insert_reads)
+ *   count         reads of the batch to decide again
+ *   extra         reads right behind them, decided against the filter as it is now (the plain query):
+ *                 the next window's first decisions if this batch is confirmed in full — their
+ *                 summaries stay with the engine for the next grp_batch_verify
+ *   id_floor, decisions_out   count + extra entries (floor of an extra read: 0x7FFFFFFF)
+ * Results are those of grp_batch_classify over the same count + extra reads, bit for bit.  Falls back
+ * to that call by itself when the first decisions' summaries are gone (something else used the engine
+ * in between) or GRP_BATCH_VERIFY=off is set.
+ */
+int grp_batch_verify(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, uint32_t extra, const grp_decide_params* params, const uint32_t* id_floor, grp_read_decision* decisions_out);
 int grp_batch_undo(grp_ctx* ctx, uint32_t from_read, uint32_t id_floor);
 int grp_batch_end(grp_ctx* ctx);
 
@@ -583,6 +605,14 @@ int grp_debug_tile_states(grp_ctx* ctx, uint64_t n_tiles, uint32_t* ids, uint8_t
  * entries), list_off indexes `lists`.  ids_out / asg_out (may be NULL): per-tile state after the passes. */
 int grp_debug_decide(grp_ctx* ctx, uint32_t n_reads, const uint64_t* tile0, const grp_tile_summary* tiles, const grp_id_count* lists, uint64_t n_lists, const grp_decide_params* params, grp_read_decision* decisions_out, uint32_t* ids_out, uint8_t* asg_out);
 
+/* grp_batch_verify's counters since grp_create: [0] tiles patched from the batch's records, [1] tiles of those
+ * calls queried again (no records), [2] tiles of those calls redone with the worst-case table (flagged by the
+ * query kernels or given up by the patch), [3] calls that fell back to grp_batch_classify (the first decisions'
+ * summaries were gone), [4] patches given up because the old top ID lost frames and no count > 2 was left,
+ * [5] patches given up for another reason (delta table full, shared first ID, flagged first summary),
+ * [6] flagged tiles redone by the synchronous windows (grp_classify_reads / grp_batch_classify / grp_query_tiles) */
+int grp_debug_verify_stats(const grp_ctx* ctx, uint64_t out[7]);
+
 /* ---- measurement ------------------------------------------------------------ */
 enum
 {
@@ -595,7 +625,8 @@ enum
   GRP_K_LOOP = 6,     /* ordered commit loop (query + decision + insert; units = probes queried) */
   GRP_K_QUERY_LAT = 7, /* the query kernel in its latency form: windows of a few reads written straight to
                           host memory (insert-heavy stretches); GRP_K_QUERY holds the throughput forms */
-  GRP_K_COUNT = 8
+  GRP_K_VERIFY = 8,   /* grp_batch_verify: inserted tiles patched from the batch's records (units = their probes) */
+  GRP_K_COUNT = 9
 };
 
 typedef struct

@@ -81,6 +81,9 @@ typedef struct
   /* optional: page-lock / release the chunk buffer handed to fastq_parse (grp_fastq_pin / _unpin) */
   int (*fastq_pin)(void* ctx, const char* buffer, uint64_t n_bytes);
   int (*fastq_unpin)(void* ctx);
+  /* optional (with the batch_* members; round 4): the second decisions of a batch from the batch's own
+   * records instead of a second query, grp_batch_verify */
+  int (*batch_verify)(void* ctx, const void* reads, uint32_t first, uint32_t count, uint32_t extra, const grp_decide_params* params, const uint32_t* id_floor, grp_read_decision* out);
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */

@@ -25,6 +25,17 @@ the reference's own lines.  Nothing of this is ever copied into the repository.
                                              getData, the saturation bit — needs MIBloomFilter and stays restated.
                       main                   the hash-universe statements (HASH_UNIVERSE_COEFFICIENT ...)
   MIBloomFilter.hpp   calcOptimalSize        whole (static member) function
+Round 4 (what process_read does around the miBF, and what an insert does to a rank):
+  MIBloomFilter.hpp   s_mask, setData        the constant's declaration and the whole member function
+  MIBFConstructSupport.hpp  insertMIBF (the hash_vec overload)  the `for` statement over the unique ranks: count,
+                                             the reservoir test, the call of setData (:271-282)
+  goldrush_path.cpp   log_info_struct        the struct
+                      log_path_stat          whole function
+                      silver_path_check      whole function
+                      process_read           the function's BODY (everything behind the signature); the shim opens a
+                                             function with the same parameter names over capture classes named like
+                                             the reference's own (MIBloomFilter / MIBFConstructSupport: record the
+                                             calls, hold m_data / m_counts for the reference's own setData and loop)
 """
 import os
 import re
@@ -85,6 +96,51 @@ def main():
     b = mb.index("\n  }\n", a) + 5
     pieces["calc_optimal_size"] = mb[a:b]
     assert "log(1.0 - occupancy)" in pieces["calc_optimal_size"]
+    # ---- round 4 -------------------------------------------------------------------------------------------
+    cs = open(os.path.join(ref, "MIBFConstructSupport.hpp")).read()
+    a = mb.index("  static const T s_mask = ")
+    pieces["s_mask_decl"] = mb[a:mb.index("\n", a) + 1]
+    a = mb.index("  void setData(uint64_t pos, T id)")
+    pieces["set_data"] = mb[a:mb.index("\n  }\n", a) + 5]
+    assert "__sync_bool_compare_and_swap(&m_data[pos], oldValue, id)" in pieces["set_data"] and "s_mask" in pieces["set_data"]
+    a = cs.index("const std::vector<std::vector<uint64_t>>& hash_vec,")
+    a = cs.index("#if _OPENMP\n#pragma omp parallel for\n#endif\n    for (size_t i = 0; i < unique_values.size(); ++i) {", a)
+    b = cs.index("\n    }\n", a) + 7
+    pieces["reservoir_loop"] = cs[a:b]
+    assert "__sync_add_and_fetch(&m_counts[rank], 1)" in pieces["reservoir_loop"] and "miBF.setData(rank, id)" in pieces["reservoir_loop"] and "std::hash<T>{}" in pieces["reservoir_loop"]
+    a = gp.index("struct log_info_struct {")
+    pieces["log_info_struct"] = gp[a:gp.index("};\n", a) + 3]
+    pieces["log_path_stat"] = cut_function(gp, r"^void\nlog_path_stat\(")
+    pieces["silver_path_check"] = cut_function(gp, r"^void\nsilver_path_check\(")
+    f = cut_function(gp, r"^inline void\nprocess_read\(")
+    sig_end = f.index("log_info_struct& log_info)\n{\n") + len("log_info_struct& log_info)\n{\n")
+    body = f[sig_end:]
+    assert body.lstrip().startswith("if (record.seq.size() < min_seq_len) {") and body.rstrip().endswith("}")
+    assert body.count("miBFCS.insertMIBF(") == 2 and body.count("silver_path_check(") == 2 and "calc_num_assigned_tiles(*miBF," in body
+    pieces["process_read_body"] = body
+    # the members / functions the mini reference (ref_mini_main.cpp) is made of, whole
+    def member(text, start_marker, nth=0):
+        a = -1
+        for _ in range(nth + 1):
+            a = text.index(start_marker, a + 1)
+        if text[a:].split("\n", 1)[0].rstrip().endswith("}"):  # a one-line member
+            return text[a:text.index("\n", a) + 1]
+        return text[a:text.index("\n  }\n", a) + 5]
+    a = mb.index("  static const T s_antiMask = ")
+    pieces["s_antimask_decl"] = mb[a:mb.index("\n", a) + 1]
+    pieces["at_rank_vec"] = member(mb, "  bool atRank(const vector<uint64_t>& hashes, vector<uint64_t>& rankPos) const")
+    pieces["get_rank_pos_hash"] = member(mb, "  uint64_t getRankPos(const uint64_t hash) const")
+    pieces["get_hash_num"] = member(mb, "  unsigned getHashNum() const")
+    pieces["size_fn"] = member(mb, "  size_t size() const")
+    pieces["get_data_vec"] = member(mb, "  vector<T> getData(const vector<uint64_t>& rankPos) const")
+    pieces["reset_id_vector"] = member(mb, "  void reset_ID_vector()")
+    for k_ in ("at_rank_vec", "get_rank_pos_hash", "get_data_vec"):
+        assert "m_rankSupport" in pieces[k_] or "m_data" in pieces[k_]
+    a = cs.index("  void insertMIBF(MIBloomFilter<T>& miBF,\n                  const std::vector<std::vector<uint64_t>>& hash_vec,")
+    pieces["insert_mibf_whole"] = cs[a:cs.index("\n  }\n", a) + 5]
+    assert "size_t vec_size = hash_vec[0].size();" in pieces["insert_mibf_whole"] and "values.set_empty_key(miBF.size());" in pieces["insert_mibf_whole"]
+    pieces["reset_counts"] = member(cs, "  void reset_counts()")
+    pieces["calc_num_assigned_tiles"] = cut_function(gp, r"^size_t\ncalc_num_assigned_tiles\(")
     for name, txt in pieces.items():
         with open(os.path.join(out, name + ".inc"), "w") as fp:
             fp.write(txt)

@@ -123,5 +123,38 @@ def make_funcs():
     print("tile states %d, sizes %d, votes %d" % (len(out["tiles"]), len(out["sizes"]), len(out["votes"])))
 
 
+def make_mini():
+    """tests/golden/reference_mini.json: sha256 of the files the MINI REFERENCE (oracle/_ref/ref_mini: the reference's
+    own calc_num_assigned_tiles / process_read body / silver_path_check / insertMIBF / setData ... around the oracle's
+    hashes and bit vector, tests/ref_mini.py) writes for the cases of ref_mini.CASES, and its end-state counters."""
+    import sys
+    import tempfile
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, ROOT)
+    import orc
+    import ref_mini
+
+    orc.build()
+    out = {"source": "bcgsc/goldrush goldrush_path/{goldrush_path.cpp, MIBloomFilter.hpp, MIBFConstructSupport.hpp, opt.cpp, calc_phred_average.cpp}: the reference's own text compiled into "
+                     "oracle/_ref/ref_mini (oracle/ref_mini_main.cpp lists what is the reference's and what is ours), run on scenarios written by tests/ref_mini.py", "cases": {}}
+    for name, spec, flags in ref_mini.CASES:
+        with tempfile.TemporaryDirectory() as d:
+            fq = ref_mini.make_fastq(spec, os.path.join(d, "reads.fq"))
+            pre = os.path.join(d, "ref")
+            p, _ = ref_mini.write_scenario(orc, flags + ["-i", fq], os.path.join(d, "scenario.bin"), pre)
+            p.close()
+            ref_mini.run_mini(os.path.join(d, "scenario.bin"))
+            st, ids, counts = ref_mini.mini_state(pre)
+            out["cases"][name] = {"input_sha256": ref_mini.sha(fq), "flags": flags, "files": ref_mini.outputs(pre), "state": st,
+                                  "ids_sha256": __import__("hashlib").sha256(ids.tobytes()).hexdigest(), "counts_sha256": __import__("hashlib").sha256(counts.tobytes()).hexdigest(),
+                                  "max_count": int(counts.max()) if counts.size else 0}
+            print(name, out["cases"][name]["files"].keys(), st)
+    with open(os.path.join(HERE, "reference_mini.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 if __name__ == "__main__":
     main()
+    make_mini()

@@ -10,7 +10,9 @@ from goldrush_amd import host, native
 
 class OracleEngine:
     def __init__(self, orc, m, seeds, tile, k, reads, pipelined=False, streaming=False, redo_every=0, batching=False, batch_crowded_above=0,
-                 resume=False, resume_refuse_every=0, resume_lost_every=0):
+                 resume=False, resume_refuse_every=0, resume_lost_every=0, batch_verify=True):
+        self.batch_verify = batch_verify  # with batching: the engine has grp_batch_verify (the second decisions + the reads behind the batch)
+        self.n_verifies = 0
         self.pipelined = pipelined
         self.streaming = streaming
         self.resume = resume                          # stream_insert: the window applies the insert itself and carries on
@@ -284,6 +286,13 @@ class OracleEngine:
                     insert_read(ctx, reads, int(e[0]), int(e[1]), int(e[2]), bt["block"], int(e[3]), int(e[4]))
             return 0
 
+        def batch_verify(ctx, reads, first, count, extra, dp_p, floor_p, out_p):
+            # the same answers as batch_classify over count + extra reads (the reads behind the last insert see the
+            # filter as the batch leaves it); what the GPU engine does differently is HOW it gets them
+            assert bt and first == bt["first"] and count > 0
+            self.n_verifies += 1
+            return batch_classify(ctx, reads, first, count + extra, dp_p, floor_p, out_p)
+
         def batch_undo(ctx, from_read, floor_id):
             assert bt and from_read >= bt["first"]
             later = [e for e in bt["ins"] if int(e[0]) >= from_read]
@@ -320,6 +329,8 @@ class OracleEngine:
         if self.batching:
             impl.update({"classify_reads": classify_reads, "insert_read": insert_read, "batch_insert": batch_insert, "batch_classify": batch_classify,
                          "batch_undo": batch_undo, "batch_end": batch_end})
+            if self.batch_verify:
+                impl["batch_verify"] = batch_verify
         impl.update({"query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync, "last_error": last_error})
         for name, ftype in host.VT_TYPES:
             if name in impl:

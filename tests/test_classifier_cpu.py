@@ -140,8 +140,8 @@ def test_streaming_windows_apply_inserts_themselves(oracle, native, max_window, 
     assert cls.state()["reads_committed"] == len(exp)
 
 
-@pytest.mark.parametrize("max_window,crowded", [(2, 0), (5, 0), (64, 0), (4096, 0), (64, 3)])
-def test_batched_windows_match_serial_loop(oracle, native, max_window, crowded, monkeypatch):
+@pytest.mark.parametrize("max_window,crowded,verify", [(2, 0, True), (5, 0, True), (64, 0, True), (4096, 0, True), (64, 3, True), (5, 0, False), (4096, 0, False)])
+def test_batched_windows_match_serial_loop(oracle, native, max_window, crowded, verify, monkeypatch):
     """Windows committed as batches (batch_insert / _classify / _undo / _end): the window's
     inserts are applied before its reads are decided a second time; a read that decides
     differently behind an earlier read of its own window takes the batch back; a silver-path
@@ -155,7 +155,7 @@ def test_batched_windows_match_serial_loop(oracle, native, max_window, crowded, 
     reads = _workload()
     m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
     exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=90_000, max_paths=2)
-    eng = OracleEngine(oracle, m, seeds, tile, k, reads, batching=True, batch_crowded_above=crowded)
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads, batching=True, batch_crowded_above=crowded, batch_verify=verify)
     cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, target_bases=90_000, max_paths=2, silver_path=True, max_window=max_window)
     lens = np.array([len(r) for r in reads], dtype=np.uint32)
     skipped = np.zeros(len(reads), dtype=np.uint32)
@@ -168,6 +168,7 @@ def test_batched_windows_match_serial_loop(oracle, native, max_window, crowded, 
     st = cls.state()
     assert st["reads_committed"] == len(exp)
     assert eng.n_batches >= 2 and st["batches"] >= 1 and st["batch_reads"] > 0
+    assert (eng.n_verifies > 0) == verify  # an engine with grp_batch_verify is asked through it, one without through grp_batch_classify
     if max_window >= 64 and not crowded:
         assert eng.n_batch_undone >= 1 and st["batches_undone"] == eng.n_batch_undone
     if crowded:

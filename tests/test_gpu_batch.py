@@ -43,11 +43,15 @@ def _same(a, b):
         int(a["kind"]) != 4 or (int(a["trim_start"]), int(a["trim_end"])) == (int(b["trim_start"]), int(b["trim_end"])))
 
 
-def batch_commit(eng, b, reads, tile, block, window, stats):
-    """-> [(read, kind, num_tiles, num_assigned, trim_start, trim_end, first_id)]"""
+def batch_commit(eng, b, reads, tile, block, window, stats, verify=None):
+    """-> [(read, kind, num_tiles, num_assigned, trim_start, trim_end, first_id)]
+    verify: None = the second query (grp_batch_classify); "check" = grp_batch_verify, and the second query behind
+    it: identical bytes; "chain" = grp_batch_verify alone, the first decisions of the next window taken from the
+    reads it decided behind the batch (what the classifier does)"""
     out = []
     pos, ids_inserted, shared = 0, 0, False
     n = len(reads)
+    carried = None  # (position, decisions) of the reads decided behind the previous batch
 
     def record(j, r, first_id):
         k4 = int(r["kind"]) == 4
@@ -57,7 +61,13 @@ def batch_commit(eng, b, reads, tile, block, window, stats):
     while pos < n:
         cnt = max(1, min(window >> shrink, n - pos))
         shrink = 0
-        d0 = eng.classify_reads(b, pos, cnt)
+        if carried is not None and carried[0] == pos and len(carried[1]) > 0:
+            cnt = min(cnt, len(carried[1]))
+            d0 = carried[1][:cnt]
+            stats["carried"] = stats.get("carried", 0) + 1
+        else:
+            d0 = eng.classify_reads(b, pos, cnt)
+        carried = None
         ins, floors, firsts, ids_end, shared_end = _plan(d0, reads, pos, tile, block, ids_inserted, shared)
         if not ins:
             for j in range(cnt):
@@ -75,11 +85,22 @@ def batch_commit(eng, b, reads, tile, block, window, stats):
             while (window >> shrink) >= cnt:
                 shrink += 1
             continue
-        d1 = eng.batch_classify(b, pos, cnt, floors)
+        extra = 0
+        if verify is None:
+            d1 = eng.batch_classify(b, pos, cnt, floors)
+        else:
+            extra = min(max(1, window // 2), n - pos - cnt)
+            dv = eng.batch_verify(b, pos, cnt, extra, floors + [0x7FFFFFFF] * extra)
+            d1 = dv[:cnt]
+            if verify == "check":
+                dq = eng.batch_classify(b, pos, cnt + extra, floors + [0x7FFFFFFF] * extra)
+                assert dv.tobytes() == dq.tobytes(), [(j, dv[j], dq[j]) for j in range(cnt + extra) if dv[j].tobytes() != dq[j].tobytes()][:3]
         bad = next((j for j in range(cnt) if not _same(d0[j], d1[j])), None)
         stats["batches"] += 1
         if bad is None:
             eng.batch_end()
+            if verify == "chain" and extra:
+                carried = (pos + cnt, dv[cnt:])
             for j in range(cnt):
                 record(pos + j, d1[j], firsts[j])
             ids_inserted, shared = ids_end, shared_end
@@ -100,7 +121,7 @@ def batch_commit(eng, b, reads, tile, block, window, stats):
     return out
 
 
-def _run(oracle, native, reads, tile, k, h, m, block, window, key):
+def _run(oracle, native, reads, tile, k, h, m, block, window, key, verify=None):
     from oracle_engine import cached_serial_reference
 
     seeds = default_seeds(h)
@@ -110,17 +131,20 @@ def _run(oracle, native, reads, tile, k, h, m, block, window, key):
     eng.finalize()
     exp, ref_ids, ref_counts, _ = cached_serial_reference(key, oracle, m, seeds, tile, k, reads, block=block)
     stats = {"batches": 0, "undone": 0}
-    got = batch_commit(eng, b, reads, tile, block, window, stats)
+    got = batch_commit(eng, b, reads, tile, block, window, stats, verify)
     assert got == [e[:7] for e in exp]
     ids, counts = eng.export_ids()
     assert np.array_equal(counts, ref_counts)
     assert np.array_equal(ids, ref_ids)
+    if verify is not None:
+        stats["verify"] = eng.verify_stats()
+        assert stats["verify"]["fallbacks"] == 0 and stats["verify"]["patched"] > 0, stats
     eng.close()
     return stats, exp
 
 
-@pytest.mark.parametrize("window", [2, 7, 32, 200])
-def test_batches_equal_the_serial_loop(oracle, native, window):
+@pytest.mark.parametrize("window,verify", [(2, None), (7, None), (32, None), (200, None), (7, "check"), (32, "check"), (200, "check"), (7, "chain"), (32, "chain"), (200, "chain")])
+def test_batches_equal_the_serial_loop(oracle, native, window, verify):
     """A genome covered ~5x: the first reads insert, later ones are assigned or trimmed, so
     windows mix confirmed batches and batches taken back (a read that overlaps an earlier
     read of its own window decides differently once that read is in the filter)."""
@@ -130,14 +154,17 @@ def test_batches_equal_the_serial_loop(oracle, native, window):
     g = synth.random_genome(150_000, 21)
     reads = [r[1] for r in synth.make_reads(g, 140, mean_len=5000, min_len=3500, seed=22, max_len=9000)]
     m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
-    stats, exp = _run(oracle, native, reads, tile, k, h, m, block, window, "loop_basic")
+    stats, exp = _run(oracle, native, reads, tile, k, h, m, block, window, "loop_basic", verify)
     assert stats["batches"] > 0
+    if verify == "chain" and window == 7:
+        assert stats.get("carried", 0) > 0  # first decisions taken from the reads decided behind a batch (larger windows on this genome are nearly always taken back)
     if window >= 7:
         assert stats["undone"] > 0  # the take-back path ran
     assert {e[1] for e in exp} >= {2, 3, 5}
 
 
-def test_batches_on_a_small_crowded_filter(oracle, native):
+@pytest.mark.parametrize("verify", [None, "check", "chain"])
+def test_batches_on_a_small_crowded_filter(oracle, native, verify):
     """A filter far too small for its reads (occupancy ~0.5, most ranks shared by many tiles):
     ranks written by several reads and blocks of one batch, overwrites of non-zero IDs, the
     overflow table — the log has to restore all of it."""
@@ -147,8 +174,10 @@ def test_batches_on_a_small_crowded_filter(oracle, native):
     g = synth.random_genome(400_000, 5)
     reads = [r[1] for r in synth.make_reads(g, 60, mean_len=4000, min_len=1500, seed=6, max_len=8000)]
     m = 1 << 19
-    stats, exp = _run(oracle, native, reads, tile, k, h, m, block, 16, "batch_crowded")
+    stats, exp = _run(oracle, native, reads, tile, k, h, m, block, 16, "batch_crowded", verify)
     assert stats["batches"] > 0
+    if verify is not None:  # on this filter nearly every frame is dirty: tiles that cannot be certified are part of the test
+        assert stats["verify"]["flagged"] > 0
 
 
 @pytest.mark.parametrize("h", [3, 5])
@@ -193,8 +222,14 @@ def test_batch_of_long_reads_equals_inserts_one_by_one(native, h):
     a.close()
 
     b, rb_ = engine()
+    b.classify_reads(rb_, 0, nb)  # the first decisions: their summaries stay with the engine for grp_batch_verify
     b.batch_insert_reads(rb_, ins, block, 0)
+    dv = b.batch_verify(rb_, 0, nb, 4, floors + [0x7FFFFFFF] * 4)
+    vs = b.verify_stats()
+    assert vs["fallbacks"] == 0 and vs["patched"] == sum(int(lens[j]) // tile for j in range(nb)) and vs["queried"] == 0, vs
     d1 = b.batch_classify(rb_, 0, nb, floors)
+    assert dv[:nb].tobytes() == d1.tobytes()
+    assert dv[nb:].tobytes() == b.batch_classify(rb_, nb, 4, [0x7FFFFFFF] * 4).tobytes()
     # a stripe of the window (what one rank of a multi-GPU run asks for), and an empty one
     stripe = b.batch_classify(rb_, 5, 6, floors[5:11])
     assert stripe.tobytes() == d1[5:11].tobytes()

@@ -5,7 +5,18 @@
 //   mode 2: two DEPENDENT random loads per item: 16 B from table A (small),
 //           then 4/8 B from table B (large) at an index derived from the first
 //   mode 3: like 2 but UNR items in flight per lane
-// usage: gather_bench <tableA_MiB> <tableB_MiB> <items_per_lane> <mode>
+//   modes 4-10: bucket-shaped accesses (10 = what k_query does: a quad reads one 64-B line)
+// Round 4 (locality / cache-residency questions, DESIGN 4 "the ceiling of the steady state"):
+//   mode 11: quad 64-B lines drawn PAGE-BINNED in address order: the grid sweeps table A once,
+//            item n (grid order) falls at a random line of region n / L, regions of R bytes
+//            (env GB_REGION bytes, GB_DENSITY lines drawn per line of the region, default 0.6)
+//   mode 17: quad 64-B lines, the 16 lines of one wave step inside ONE random region of R bytes
+//   mode 18: like 17 for the 64 lines of a workgroup step
+//   mode 12: random atomicOr (u32) on table B        mode 13: random atomicCAS (u64) on table B
+//   mode 14: random 1-byte stores on table B         mode 15: 8 lanes read a 128-B bucket
+//   mode 16: quad reads a 64-B line of A, one lane writes 4 B of it back (a dirty random line)
+//   mode 19: random u32 load from table B, one per lane, keyed like a Bloom look-up (same as 1, kept for the tables)
+// usage: gather_bench <tableA_MiB> <tableB_MiB> <items_per_lane> <mode> [unroll] [workgroups]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +27,7 @@
 __device__ inline uint64_t mix64(uint64_t x) { x += 0x9E3779B97F4A7C15ULL; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL; x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL; return x ^ (x >> 31); }
 
 template<int UNR>
-__global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ A, uint64_t nA, const uint2* __restrict__ B, uint64_t nB, int items, int mode, uint64_t* __restrict__ out)
+__global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ A, uint64_t nA, const uint2* __restrict__ B, uint64_t nB, int items, int mode, uint64_t* __restrict__ out, uint64_t region_lines, uint64_t lines_per_region)
 {
   const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t acc = 0;
@@ -73,6 +84,78 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ A, uin
           }
         }
       }
+    } else if (mode == 11 || mode == 17 || mode == 18) {
+      const uint64_t nb = nA / 4; // 64-B lines of table A
+      const int lane = threadIdx.x & 63;
+      const int sub = lane & 3;
+      const uint64_t nquads = (uint64_t)gridDim.x * blockDim.x / 4;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        uint64_t idx;
+        if (mode == 11) {
+          const uint64_t n = (uint64_t)(it + u) * nquads + gid / 4; // grid order: the sweep
+          const uint64_t region = n / lines_per_region;
+          idx = (region * region_lines + mix64(n) % region_lines) % nb;
+        } else {
+          // the lines of one wave (17) / workgroup (18) step share a random region
+          const uint64_t scope = (mode == 17) ? gid / 64 : gid / 256;
+          const uint64_t region = mix64(scope * 0x9E3779B97F4A7C15ULL + (uint64_t)(it + u)) % (nb / region_lines);
+          idx = region * region_lines + mix64((gid / 4) * 77ULL + (uint64_t)(it + u) * 0xD1B54A32D192ED03ULL) % region_lines;
+        }
+        const uint4 t = A[idx * 4 + sub];
+        const uint32_t got = __shfl(t.w, (lane & ~3) + (int)(idx & 3), 64);
+        acc += got + t.x;
+      }
+    } else if (mode == 12) {
+      uint32_t* T = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(B));
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) atomicOr(&T[ia[u] % (nB * 2)], 1u << (ia[u] >> 59));
+    } else if (mode == 13) {
+      unsigned long long* T = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(B));
+      unsigned long long v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = atomicCAS(&T[ia[u] % nB], 0x0202020202020202ULL, ia[u] | 1ull);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += v[u];
+    } else if (mode == 14) {
+      uint8_t* T = const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(B));
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) T[ia[u] % (nB * 8)] = 1;
+    } else if (mode == 15) {
+      const uint64_t nb = nA / 8; // 128-B buckets
+      const int lane = threadIdx.x & 63;
+      const int sub = lane & 7;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        for (int g = 0; g < 8; ++g) {
+          const uint64_t idx = __shfl(ia[u], (lane & ~7) + g, 64) % nb;
+          const uint4 t = A[idx * 8 + sub];
+          const uint32_t got = __shfl(t.w, (lane & ~7) + (int)(idx & 7), 64);
+          if (sub == g) acc += got + t.x;
+        }
+      }
+    } else if (mode == 16) {
+      const uint64_t nb = nA / 4;
+      const int lane = threadIdx.x & 63;
+      const int sub = lane & 3;
+      uint4* W = const_cast<uint4*>(A);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        for (int g = 0; g < 4; ++g) {
+          const uint64_t idx = __shfl(ia[u], (lane & ~3) + g, 64) % nb;
+          const uint4 t = A[idx * 4 + sub];
+          if (sub == g) {
+            acc += t.x;
+            reinterpret_cast<uint32_t*>(W)[idx * 16 + 3 + (ia[u] >> 50) % 13] = (uint32_t)ia[u] | 1u;
+          }
+        }
+      }
+    } else if (mode == 19) {
+      uint32_t v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = reinterpret_cast<const uint32_t*>(B)[(ia[u] >> 5) % (nB * 2)];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) acc += (v[u] >> (ia[u] & 31)) & 1u;
     } else if (mode == 4 || mode == 5 || mode == 6 || mode == 7) {
       // bucket-shaped accesses on table A viewed as 64-byte buckets
       const uint64_t nb = nA / 4;
@@ -121,17 +204,30 @@ int main(int argc, char** argv)
   uint4* A; uint2* B; uint64_t* out;
   CK(hipMalloc(&A, nA * 16)); CK(hipMalloc(&B, nB * 8)); CK(hipMalloc(&out, 8));
   CK(hipMemset(A, 1, nA * 16)); CK(hipMemset(B, 2, nB * 8));
+  const uint64_t region_bytes = getenv("GB_REGION") ? strtoull(getenv("GB_REGION"), nullptr, 10) : 2048;
+  const double density = getenv("GB_DENSITY") ? atof(getenv("GB_DENSITY")) : 0.6;
+  const uint64_t region_lines = region_bytes / 64 ? region_bytes / 64 : 1;
+  uint64_t lines_per_region = (uint64_t)(region_lines * density + 0.5);
+  if (lines_per_region == 0) lines_per_region = 1;
+  if (mode == 11) { // one sweep of the table: items per lane from the table size
+    const uint64_t nquads = (uint64_t)wgs * 256 / 4;
+    const uint64_t total = (nA / 4) / region_lines * lines_per_region;
+    items = (int)(total / nquads / unr * unr);
+    if (items < unr) items = unr;
+  }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(e0));
-    if (unr == 1) k_gather<1><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
-    else if (unr == 2) k_gather<2><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
-    else if (unr == 4) k_gather<4><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
-    else if (unr == 8) k_gather<8><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
-    else k_gather<16><<<wgs, 256>>>(A, nA, B, nB, items, mode, out);
+    if (unr == 1) k_gather<1><<<wgs, 256>>>(A, nA, B, nB, items, mode, out, region_lines, lines_per_region);
+    else if (unr == 2) k_gather<2><<<wgs, 256>>>(A, nA, B, nB, items, mode, out, region_lines, lines_per_region);
+    else if (unr == 4) k_gather<4><<<wgs, 256>>>(A, nA, B, nB, items, mode, out, region_lines, lines_per_region);
+    else if (unr == 8) k_gather<8><<<wgs, 256>>>(A, nA, B, nB, items, mode, out, region_lines, lines_per_region);
+    else k_gather<16><<<wgs, 256>>>(A, nA, B, nB, items, mode, out, region_lines, lines_per_region);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     double n = (double)wgs * 256 * items;
+    if (mode == 11 || mode == 17 || mode == 18) n /= 4; // one line per QUAD and item here
+    if (rep == 2 && (mode == 11 || mode == 17 || mode == 18)) printf("region=%lluB density=%.2f items=%d ", (unsigned long long)region_bytes, density, items);
     if (rep == 2) printf("mode %d A=%lluMiB B=%lluMiB unr=%d wgs=%d: %.2f ms, %.2f G items/s, %.2f G sector-loads/s -> %.2f TB/s at 64 B/sector\n", mode, (unsigned long long)aMiB, (unsigned long long)bMiB, unr, wgs, ms, n / ms / 1e6, n * ((mode == 2 || mode == 3) ? 2 : 1) / ms / 1e6, n * ((mode == 2 || mode == 3) ? 2 : 1) * 64 / ms / 1e9);
   }
   return 0;
