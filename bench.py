@@ -130,7 +130,10 @@ def _newest_profile(pattern: str):
     return files[-1] if files else None
 
 
-def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, seeds, k: int, tile: int, genome: int, budget_s: float = 10.0):
+WITNESS = 1024  # reads at either end of the stream whose GPU decisions are kept for the oracle's check
+
+
+def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, seeds, k: int, tile: int, genome: int, budget_s: float = 10.0, kept=None):
     """Like-for-like CPU baseline: the oracle's serial process_read loop (hash, query, decide,
     insert; OpenMP over tiles like the reference, goldrush_path.cpp:1229-1256) on the SAME
     filter as the measured run and on the same two regimes of the stream:
@@ -145,7 +148,7 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
     from goldrush_amd import host, synth
 
     orc.build()
-    n_s = 1024
+    n_s = WITNESS
     head = dr.download(0, n_s)
     s0 = n_reads - n_s
     steady = dr.download(s0, n_s)
@@ -165,16 +168,57 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
     mh = p.mibf_handle()
     assert lib.orcpy_mibf_pop(mh) == pop, "the oracle's rank build disagrees with the GPU's"
 
+    # The oracle replays exactly the reads whose GPU commits were kept (`kept`, in commit order): the head from read 0 on
+    # the empty arrays — the same state the GPU path started from — and the last reads on the GPU's exported END state,
+    # which is the state in front of a read only behind the last insert the GPU committed (nothing changes the filter
+    # after that), and only as long as the oracle's replay has not inserted anything itself.
+    # kind / tiles / assigned tiles / trim range / first ID (head) / hits / misses.
+    by_read = {c[0]: c for c in (kept or [])}
+    last_steady_insert = max([c[0] for c in (kept or []) if c[0] >= n_reads - n_s and c[1] in (2, 4)], default=-1)
+    steady_oracle_inserts = [0]
+    check = {"head_reads": 0, "steady_reads": 0, "identical": True, "first_difference": None,
+             "what": "oracle process_read on the same filter vs the commits the GPU path kept for these reads: kind, tiles, assigned tiles, trim range, first ID, hits, misses"}
+    ocounts = [None, None]  # the oracle's hits / misses counters before / after a read
+
+    def compare(i, d, li0, li1):
+        g = by_read.get(i if i < n_s else n_reads - 2 * n_s + i)  # sample index -> stream index
+        if g is None or not check["identical"]:
+            return
+        if i >= n_s:
+            steady_oracle_inserts[0] += 1 if d.decision in (2, 4) else 0
+            if g[0] <= last_steady_insert or steady_oracle_inserts[0]:
+                return  # the exported end state is not the state this read was decided against
+        k4 = d.decision == 4
+        mine = (d.decision, d.num_tiles, d.num_assigned, d.trim_start if k4 else 0, d.trim_end if k4 else 0, d.first_id if d.decision in (2, 4) else 0,
+                li1["total_hits_per_path"] - li0["total_hits_per_path"], li1["total_misses_per_path"] - li0["total_misses_per_path"])
+        gk4 = g[1] == 4
+        theirs = (g[1], g[2], g[3], g[4] if gk4 else 0, g[5] if gk4 else 0, g[6] if g[1] in (2, 4) else 0, g[8], g[9])
+        if i >= n_s:  # the oracle allocates IDs from the END state's counter: the first ID of an insert there is not the GPU's
+            mine, theirs = mine[:5] + mine[6:], theirs[:5] + theirs[6:]
+        check["head_reads" if i < n_s else "steady_reads"] += 1
+        if mine != theirs:
+            check["identical"] = False
+            check["first_difference"] = {"read": g[0], "oracle": mine, "gpu": theirs}
+
     def timed(first, count, budget_s=budget_s):
         t0 = time.time()
         done = ins = 0
+        t_check = 0.0
         for i in range(first, first + count):
+            if kept is not None:
+                tc = time.time()
+                li0 = p.log_info()
+                t_check += time.time() - tc
             d = p.process(i)
             done += 1
             ins += 1 if d.decision in (2, 4) else 0
-            if time.time() - t0 > budget_s:
+            if kept is not None:
+                tc = time.time()
+                compare(i, d, li0, p.log_info())
+                t_check += time.time() - tc
+            if time.time() - t0 - t_check > budget_s:
                 break
-        return done, ins, time.time() - t0
+        return done, ins, time.time() - t0 - t_check
 
     h_done, h_ins, h_dt = timed(0, n_s, 2.0 * budget_s)  # the slow regime (~10 reads/s at C2) gets two thirds of the ~30 s
     if silver:  # every silver path is an insert-heavy head: no steady state to compare
@@ -182,7 +226,7 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
         for f in os.listdir(tmp):
             os.remove(os.path.join(tmp, f))
         os.rmdir(tmp)
-        return {"value": h_done / h_dt, "unit": "reads/s", "cores": cores, "kind": "port",
+        return {"value": h_done / h_dt, "unit": "reads/s", "cores": cores, "kind": "port", "oracle_check": check if kept is not None else None,
                 "sample": f"same filter (bit vector of all {n_reads} reads exported from the GPU, m={m}); reads 0..{h_done} of the stream on the empty ID arrays ({h_ins} inserts): "
                           f"the regime of every silver path; oracle process_read loop (hash + query + decide + insert), OpenMP over tiles, {cores} threads"}
     # the GPU's end state -> the oracle's arrays (chunks: the export stages through device memory)
@@ -201,7 +245,7 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
     h_rate, s_rate = h_done / h_dt, s_done / s_dt
     hr, sr = phases["head"]["reads"], phases["steady"]["reads"]
     whole = (hr + sr) / (hr / h_rate + sr / s_rate)
-    return {"value": whole, "unit": "reads/s", "cores": cores, "kind": "port",
+    return {"value": whole, "unit": "reads/s", "cores": cores, "kind": "port", "oracle_check": check if kept is not None else None,
             "sample": f"same filter (bit vector of all {n_reads} reads exported from the GPU, m={m}); head: reads 0..{h_done} on the empty ID arrays "
                       f"({h_ins} inserts); steady: reads {s0}..{s0 + s_done} on the GPU's end state (IDs / counts exported, {s_ins} inserts); oracle process_read loop "
                       f"(hash + query + decide + insert), OpenMP over tiles, {cores} threads; value = the run's {hr} head / {sr} steady reads at the two CPU rates",
@@ -436,6 +480,11 @@ def main():
                           allgather=None if shm else allgather, record=False)
     if shm:
         hl.gr_classifier_set_allgather(cls._h, C.cast(hl.gr_shm_allgather, C.c_void_p), shm)
+    # the oracle's witness (cpu_baseline leg): what the GPU path decided for the first and the last WITNESS reads of
+    # the stream stays inside the classifier (no callback per read) and is compared with the oracle's serial loop
+    witness = world == 1 and rs.n_batches == 1 and not a.no_cpu_baseline and n_reads >= 2 * WITNESS
+    if witness:
+        cls.keep_commits(0, WITNESS, n_reads - WITNESS, WITNESS)
     slices = []  # (reads, seconds, inserts) per timing slice, rank 0's clock
     finished = [False]  # silver mode: the last path is complete (the reference exits there)
     synth_before = rs.synth_s
@@ -609,7 +658,12 @@ def main():
                     "wall_s": dt},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rs, eng, cls, out["phases"], silver, n_reads, m, pop, seeds, k, tile, G)
+            out["cpu_baseline"] = cpu_baseline(rs, eng, cls, out["phases"], silver, n_reads, m, pop, seeds, k, tile, G, kept=cls.kept_commits() if witness else None)
+            check = out["cpu_baseline"].pop("oracle_check", None)
+            out["aux"]["oracle_check"] = check
+            if check and not check["identical"]:
+                print(json.dumps(out), flush=True)
+                raise SystemExit("bench: the GPU path's decisions differ from the oracle's serial loop: %s" % check["first_difference"])
         if world == 1 and not silver and not a.no_pipeline_shaped:
             # What bin/goldrush runs FIRST on the raw reads (bin/goldrush:253-260): --silver_path -M 5
             # -r 0.9 — every silver path starts on empty ID arrays (goldrush_path.cpp:156-187), so the

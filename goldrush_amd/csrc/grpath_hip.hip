@@ -203,7 +203,7 @@ struct grp_ctx
   uint64_t n_ovf = 0;    // IDs living in the overflow table
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
 
-  uint64_t n_flagged_tiles = 0; // statistics
+  uint64_t n_flagged_tiles = 0, n_flagged_distinct = 0, n_flagged_list = 0; // statistics: tiles redone with the worst-case table; why (distinct IDs / list length)
   uint64_t n_verify_tiles = 0, n_verify_queried = 0, n_verify_flagged = 0, n_verify_fallbacks = 0, n_verify_uncertified = 0, n_verify_unpatched = 0; // grp_batch_verify: tiles patched from records / queried again / patched tiles redone / calls that took the second query
   uint64_t n_direct_windows = 0, n_direct_fallbacks = 0, n_general_windows = 0, n_redo_launches = 0; // GRP_DEBUG_STATS
   uint64_t n_chunks = 0; // rank-build chunks
@@ -347,7 +347,9 @@ const uint64_t BASE_SEED[4] = { 0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x
 } // namespace
 
 #include "grp_kernels.inc"
+#ifdef GRP_DEV_HOOKS // the frozen commit loop is a developer build: make DEV=1
 #include "grp_loop.inc"
+#endif
 
 // ---------------------------------------------------------------------------
 // host side
@@ -469,41 +471,44 @@ ensure_lds(grp_ctx* c, K kernel, size_t bytes)
 
 struct QueryGeom
 {
-  uint32_t hist_cap;
-  uint32_t distinct_limit;
-  uint32_t list_cap_lds;
+  uint32_t hist_cap;       // slots of the per-tile count table (even; 6 bytes each: a key and a 16-bit count)
+  uint32_t distinct_limit; // distinct IDs it takes (the rest is room for the claims in flight)
   size_t lds;
 };
 
-// full = worst case (every probe of the tile a different ID); small = the common
-// case at a fraction of the LDS (more workgroups per CU); flagged tiles are redone
+// The per-tile count table (k_query).  full = worst case: every probe of the tile a different ID — tile * h slots
+// plus one claim per lane and seed in flight.  Round 4: at 6 bytes per slot and without power-of-two rounding the
+// worst case of the default geometries fits the LDS share that lets three workgroups (h = 5: 48 KB) or four (h = 3:
+// 27 KB) onto a CU, so it is what every launch uses and no tile is flagged; only geometries beyond that (h = 8 with
+// tiles of 1000: 69 KB; long tiles) keep the two-step scheme: a table of the budget's size first, the tiles whose
+// distinct IDs do not fit flagged and recomputed by the same kernel with the worst-case table.
 QueryGeom
 query_geom(const grp_ctx* c, bool full)
 {
   const uint32_t h = c->params.h, tile = c->params.tile;
   const uint64_t max_ids = (uint64_t)tile * h;
-  QueryGeom g;
-  const uint32_t cap_full = next_pow2(max_ids + (uint64_t)THREADS * h + 2);
-  // 4096 entries hold every possible tile of the default geometry (tile 1000, h = 3: at
-  // most 3000 distinct IDs, limit 4096 - 768 - 1), cost nothing measurable against 2048
-  // (the kernel is not occupancy-bound) and spare repeat-rich tiles the flagged redo; 8192
-  // (h = 5 worst case) halves the kernel's rate, so larger geometries keep the redo.
-  // (Round 3: the list area cut to 256 entries would let a fourth workgroup onto each CU at the
-  // default geometry — measured: C2 -2 %, C1 half the rate, lists of more than 256 IDs are common
-  // at C1's coverage and every such tile is redone.)
-  static const uint32_t small_cap = [] { // developer hook
+  auto lds_of = [&](uint32_t cap) { return tab_bytes(c) + (size_t)cap * 6 + bases_bytes(tile + c->params.k + h); };
+  const uint32_t cap_full = (uint32_t)((max_ids + (uint64_t)THREADS * h + 2 + 1023) / 1024 * 1024);
+  static const uint32_t forced_small = [] { // developer hook / tests: slots of the first-step table (forces the two-step scheme)
     const char* e = getenv("GRP_SMALL_HIST");
-    return e ? (uint32_t)atoi(e) : 4096u;
+    return e ? (uint32_t)atoi(e) / 2u * 2u : 0u;
   }();
-  if (full || cap_full <= small_cap) {
-    g.hist_cap = cap_full;
-    g.list_cap_lds = (uint32_t)(max_ids / 3 + 1);
-  } else {
-    g.hist_cap = small_cap;
-    g.list_cap_lds = 256;
+  QueryGeom g;
+  g.hist_cap = cap_full;
+  if (!full) {
+    if (forced_small && forced_small < cap_full && forced_small > (uint32_t)THREADS * h + 64) {
+      g.hist_cap = forced_small;
+    } else if (lds_of(cap_full) > 52 * 1024) {
+      // the largest table that still lets three workgroups share a CU's 160 KB
+      const size_t fixed = lds_of(0);
+      const uint32_t cap = (uint32_t)((52 * 1024 - std::min<size_t>(fixed, 40 * 1024)) / 6 / 1024 * 1024);
+      if (cap > (uint32_t)THREADS * h + 1024 && cap < cap_full) {
+        g.hist_cap = cap;
+      }
+    }
   }
   g.distinct_limit = g.hist_cap - THREADS * h - 1;
-  g.lds = tab_bytes(c) + (size_t)g.hist_cap * 8 + (size_t)g.list_cap_lds * 8 + bases_bytes(tile + c->params.k + h);
+  g.lds = lds_of(g.hist_cap);
   return g;
 }
 
@@ -523,7 +528,7 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     if (rc != GRP_OK) {
       return rc;
     }
-    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, g.list_cap_lds, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, blk0, stream_ctl ? *stream_ctl : DevStreamCtl{}, (c->view && !plain) ? *c->view : DevBatchView{});
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, blk0, stream_ctl ? *stream_ctl : DevStreamCtl{}, (c->view && !plain) ? *c->view : DevBatchView{});
     return GRP_OK;
   };
   // The synchronous forms (large windows, the two queries of a batch): two frames per lane and pass
@@ -1388,6 +1393,8 @@ enqueue_redo_flagged(grp_ctx* c, const grp_reads* r, uint64_t list_cap, QueryRun
 {
   q.flagged = c->q->h_qctr[4];
   c->n_flagged_tiles += q.flagged;
+  c->n_flagged_distinct += c->q->h_qctr[1];
+  c->n_flagged_list += c->q->h_qctr[2];
   ++c->n_redo_launches;
   // continue the list arena where the first launch stopped
   uint64_t cursor[8] = { 0, 0, 0, c->q->h_qctr[3], 0, 0, 0, 0 };
@@ -2722,7 +2729,45 @@ grp_stream(grp_ctx* c)
 
 } // extern "C"
 
+#ifdef GRP_DEV_HOOKS
 #include "grp_loop_host.inc"
+#else
+// The ordered commit loop on the device (grp_commit_loop_*) is frozen: measured slower than the batches
+// of grp_batch_* on every configuration, it is only compiled into developer builds (make DEV=1 -> -DGRP_DEV_HOOKS).
+// The entry points stay (include/grpath.h) and say so; grp_dev_hooks() tells a host which build it has.
+extern "C" {
+int
+grp_commit_loop_begin(grp_ctx* c, const grp_reads*, uint32_t, uint32_t, const grp_loop_params*, const grp_read_decision**, const volatile uint32_t**)
+{
+  return set_err(c, GRP_ERR_STATE, "grp_commit_loop_begin: this library was built without GRP_DEV_HOOKS (make DEV=1)");
+}
+int
+grp_commit_loop_stop(grp_ctx* c)
+{
+  return set_err(c, GRP_ERR_STATE, "grp_commit_loop_stop: this library was built without GRP_DEV_HOOKS (make DEV=1)");
+}
+int
+grp_commit_loop_poll(grp_ctx* c)
+{
+  return set_err(c, GRP_ERR_STATE, "grp_commit_loop_poll: this library was built without GRP_DEV_HOOKS (make DEV=1)");
+}
+int
+grp_commit_loop_end(grp_ctx* c, grp_loop_result*)
+{
+  return set_err(c, GRP_ERR_STATE, "grp_commit_loop_end: this library was built without GRP_DEV_HOOKS (make DEV=1)");
+}
+}
+#endif
+
+extern "C" int
+grp_dev_hooks(void)
+{
+#ifdef GRP_DEV_HOOKS
+  return 1;
+#else
+  return 0;
+#endif
+}
 #include "grp_batch.inc"
 #include "grp_verify.inc"
 #include "grp_ingest.inc"

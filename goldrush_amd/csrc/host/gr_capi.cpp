@@ -193,6 +193,27 @@ gr_classifier_destroy(gr_classifier* c)
 }
 
 void
+gr_classifier_keep_commits(gr_classifier* c, uint32_t first0, uint32_t count0, uint32_t first1, uint32_t count1)
+{
+  if (c) {
+    c->impl.keep_commits(first0, count0, first1, count1);
+  }
+}
+
+size_t
+gr_classifier_kept_commits(const gr_classifier* c, gr_commit* out, size_t cap)
+{
+  if (!c) {
+    return 0;
+  }
+  const auto& k = c->impl.kept_commits();
+  for (size_t i = 0; i < k.size() && i < cap; ++i) {
+    out[i] = k[i];
+  }
+  return k.size();
+}
+
+void
 gr_classifier_set_debug(gr_classifier* c, gr_debug_fn fn)
 {
   if (c) {

@@ -41,6 +41,31 @@ Classifier::set_callbacks(gr_commit_fn commit, gr_rollover_fn rollover, gr_allga
   ag_user_ = user;
 }
 
+// every committed read goes to the host's callback (the CLI writes its files there) and, inside the ranges
+// asked for with keep_commits, into kept_: a witness of what was decided, cheap enough to leave on in a
+// measured run (bench.py compares it with the oracle's serial loop on the same reads)
+double
+Classifier::emit_commit(const gr_commit& ev)
+{
+  for (int i = 0; i < 2; ++i) {
+    if (ev.read >= keep_first_[i] && ev.read - keep_first_[i] < keep_count_[i]) {
+      kept_.push_back(ev);
+      break;
+    }
+  }
+  return commit_cb_ ? commit_cb_(user_, &ev) : 0.0;
+}
+
+void
+Classifier::keep_commits(uint32_t first0, uint32_t count0, uint32_t first1, uint32_t count1)
+{
+  keep_first_[0] = first0;
+  keep_count_[0] = count0;
+  keep_first_[1] = first1;
+  keep_count_[1] = count1;
+  kept_.clear();
+}
+
 void
 Classifier::set_allgather(gr_allgather_fn allgather, void* allgather_user)
 {
@@ -637,7 +662,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       }
       ids_inserted_ = ids_inserted_ + (uint32_t)(len / ((size_t)tile * block));
       last_insert_shares_id_ = false;
-      const double ph = commit_cb_ ? commit_cb_(user_, &ev) : 0.0;
+      const double ph = emit_commit(ev);
       inserted_bases_ += len;
       ++num_reads_in_path_;
       phred_sum_in_path_ += ph;
@@ -649,9 +674,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
     }
     case DEC_ASSIGNED_ALL: {
       // :1013-1023
-      if (commit_cb_) {
-        commit_cb_(user_, &ev);
-      }
+      (void)emit_commit(ev);
       ++valid_reads_;
       bump_id();
       return false;
@@ -683,7 +706,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
         n_out = std::min<uint64_t>(n_out, (uint64_t)(te - ts + 1) * tile);
       }
       inserted_bases_ += n_out;
-      const double ph = commit_cb_ ? commit_cb_(user_, &ev) : 0.0;
+      const double ph = emit_commit(ev);
       ++num_reads_in_path_;
       phred_sum_in_path_ += ph;
       if (p_.silver_path) {
@@ -693,9 +716,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       break;
     }
     default: // DEC_ASSIGNED (:1083-1088)
-      if (commit_cb_) {
-        commit_cb_(user_, &ev);
-      }
+      (void)emit_commit(ev);
       break;
   }
   if (finished_) {

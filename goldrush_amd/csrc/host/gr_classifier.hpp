@@ -26,6 +26,9 @@ public:
   void set_callbacks(gr_commit_fn commit, gr_rollover_fn rollover, gr_allgather_fn allgather, void* user);
   void set_allgather(gr_allgather_fn allgather, void* allgather_user);
   void set_debug(gr_debug_fn fn) { debug_cb_ = fn; }
+  // commits of the reads [first0, first0 + count0) and [first1, first1 + count1) (numbers in the batch of reads) are kept
+  void keep_commits(uint32_t first0, uint32_t count0, uint32_t first1, uint32_t count1);
+  const std::vector<gr_commit>& kept_commits() const { return kept_; }
   // classifies reads [first, first+n) of the batch; lens / skipped_before are indexed by absolute read number
   int run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, const uint32_t* skipped_before, uint32_t skipped_after, bool& finished);
   void get_state(gr_classifier_state& s) const;
@@ -92,6 +95,9 @@ private:
   grp_engine_vt vt_;
   void* ctx_;
   gr_commit_fn commit_cb_ = nullptr;
+  uint32_t keep_first_[2] = { 0, 0 }, keep_count_[2] = { 0, 0 };
+  std::vector<gr_commit> kept_;
+  double emit_commit(const gr_commit& ev);
   gr_rollover_fn rollover_cb_ = nullptr;
   gr_allgather_fn allgather_cb_ = nullptr;
   void* user_ = nullptr;

@@ -122,6 +122,8 @@ SIGNATURES = {
     "gr_classifier_destroy": (None, [_vp]),
     "gr_classifier_set_allgather": (None, [_vp, _vp, _vp]),
     "gr_classifier_set_debug": (None, [_vp, _vp]),
+    "gr_classifier_keep_commits": (None, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "gr_classifier_kept_commits": (C.c_size_t, [_vp, _vp, C.c_size_t]),
     "gr_shm_allgather_open": (_vp, [C.c_uint32, C.c_uint32, C.c_char_p, C.c_double]),
     "gr_shm_allgather": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "gr_shm_allgather_close": (None, [_vp]),
@@ -249,7 +251,10 @@ def hip_engine_vt() -> grp_engine_vt:
              "stream_abort": "classify_stream_abort", "stream_insert": "classify_stream_insert", "stream_begin_resumable": "classify_stream_begin_resumable", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end",
              "loop_begin": "commit_loop_begin", "loop_stop": "commit_loop_stop", "loop_poll": "commit_loop_poll", "loop_end": "commit_loop_end",
              "batch_insert": "batch_insert_reads"}
+    dev = bool(lib.grp_dev_hooks())
     for name, ftype in VT_TYPES:
+        if name.startswith("loop_") and not dev:
+            continue  # the frozen commit loop is only in developer builds (make DEV=1): a product build's classifier is not offered it
         sym = getattr(lib, "grp_" + alias.get(name, name))
         setattr(vt, name, C.cast(sym, ftype))
     return vt
@@ -301,6 +306,17 @@ class Classifier:
         if rc != 0:
             raise RuntimeError(f"gr_classifier_run_range: {rc}: {self.lib.gr_classifier_error(self._h).decode()}")
         return bool(fin.value)
+
+    def keep_commits(self, first0: int, count0: int, first1: int = 0, count1: int = 0):
+        """keep the commits of these two ranges of reads inside the classifier (no callback per read)"""
+        self.lib.gr_classifier_keep_commits(self._h, first0, count0, first1, count1)
+
+    def kept_commits(self):
+        """-> [(read, kind, num_tiles, num_assigned, trim_start, trim_end, first_id, path, hits, misses)] of the kept ranges, in commit order"""
+        n = self.lib.gr_classifier_kept_commits(self._h, None, 0)
+        arr = (gr_commit * max(n, 1))()
+        self.lib.gr_classifier_kept_commits(self._h, arr, n)
+        return [(c.read, c.dec.kind, c.dec.num_tiles, c.dec.num_assigned, c.dec.trim_start, c.dec.trim_end, c.first_id, c.path, c.dec.hits, c.dec.misses) for c in arr[:n]]
 
     def state(self) -> dict:
         s = gr_classifier_state()

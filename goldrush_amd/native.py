@@ -136,6 +136,7 @@ SIGNATURES = {
     "grp_debug_tile_hashes": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "grp_debug_tile_states": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
     "grp_debug_locate": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, _vp, _vp]),
+    "grp_dev_hooks": (C.c_int, []),
     "grp_set_timing": (C.c_int, [_vp, C.c_int]),
     "grp_get_kernel_stats": (C.c_int, [_vp, C.POINTER(grp_kernel_stat)]),
     "grp_reset_kernel_stats": (C.c_int, [_vp]),
@@ -565,9 +566,9 @@ class Engine:
         return out
 
     def verify_stats(self) -> dict:
-        out = np.zeros(7, dtype=np.uint64)
+        out = np.zeros(9, dtype=np.uint64)
         self._check(self.lib.grp_debug_verify_stats(self._h, _ptr(out)))
-        return dict(zip(("patched", "queried", "flagged", "fallbacks", "uncertified", "unpatched", "window_flagged"), (int(x) for x in out)))
+        return dict(zip(("patched", "queried", "flagged", "fallbacks", "uncertified", "unpatched", "window_flagged", "flagged_distinct", "flagged_list"), (int(x) for x in out)))
 
     def batch_undo(self, from_read: int, id_floor: int):
         """takes back the inserts of reads >= from_read (batch index); id_floor = the first ID read from_read could allocate"""

@@ -610,8 +610,15 @@ int grp_debug_decide(grp_ctx* ctx, uint32_t n_reads, const uint64_t* tile0, cons
  * query kernels or given up by the patch), [3] calls that fell back to grp_batch_classify (the first decisions'
  * summaries were gone), [4] patches given up because the old top ID lost frames and no count > 2 was left,
  * [5] patches given up for another reason (delta table full, shared first ID, flagged first summary),
- * [6] flagged tiles redone by the synchronous windows (grp_classify_reads / grp_batch_classify / grp_query_tiles) */
-int grp_debug_verify_stats(const grp_ctx* ctx, uint64_t out[7]);
+ * [6] flagged tiles redone with the worst-case table by all synchronous forms (grp_classify_reads / grp_batch_* /
+ * grp_query_tiles), of which [7] held more distinct IDs than the small count table takes and [8] had a count > 2
+ * list longer than its LDS area */
+int grp_debug_verify_stats(const grp_ctx* ctx, uint64_t out[9]);
+
+/* 1: the library was built with GRP_DEV_HOOKS (make DEV=1): the frozen commit loop (grp_commit_loop_*) and the
+ * developer kernels / switches (GRP_BATCH_COLLECT3 ...) are compiled in; 0: the product build — grp_commit_loop_*
+ * return GRP_ERR_STATE and a host must not offer them to its classifier */
+int grp_dev_hooks(void);
 
 /* ---- measurement ------------------------------------------------------------ */
 enum

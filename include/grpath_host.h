@@ -182,6 +182,12 @@ void gr_classifier_set_callbacks(gr_classifier* c, gr_commit_fn commit, gr_rollo
  * the host prints what the reference prints there — the skipped records before it, "name:", "num tiles:" */
 typedef void (*gr_debug_fn)(void* user, uint32_t read);
 void gr_classifier_set_debug(gr_classifier* c, gr_debug_fn fn);
+/* A witness of the decisions that costs nothing per read: the commits of the reads [first0, first0 + count0) and
+ * [first1, first1 + count1) — numbers in the batch of reads handed to gr_classifier_run[_range] — are kept inside
+ * the classifier (whether or not a commit callback is set) and handed out by gr_classifier_kept_commits (returns
+ * how many there are, writes at most cap).  bench.py compares them with the oracle's serial loop on the same reads. */
+void gr_classifier_keep_commits(gr_classifier* c, uint32_t first0, uint32_t count0, uint32_t first1, uint32_t count1);
+size_t gr_classifier_kept_commits(const gr_classifier* c, gr_commit* out, size_t cap);
 /* the all-gather with its own user pointer (e.g. gr_shm_allgather + its handle) */
 void gr_classifier_set_allgather(gr_classifier* c, gr_allgather_fn allgather, void* allgather_user);
 /*

@@ -74,6 +74,32 @@ def test_pipelined_windows_match_serial_loop(oracle, native, max_window, monkeyp
     assert cls.state()["reads_committed"] == len(exp)
 
 
+def test_kept_commits_are_the_commits_of_their_ranges(oracle, native):
+    """gr_classifier_keep_commits: the commits of two ranges of reads stay inside the classifier (the witness bench.py
+    hands to the oracle) — with and without a commit callback, in commit order, the rest is not kept."""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine
+
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    reads = _workload()
+    n = len(reads)
+    m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    got = []
+    for record in (True, False):
+        eng = OracleEngine(oracle, m, seeds, tile, k, reads, pipelined=True)
+        cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, max_window=16, record=record)
+        cls.keep_commits(0, 5, n - 7, 7)
+        cls.run(None, lens, skipped_before=np.zeros(n, dtype=np.uint32))
+        kept = cls.kept_commits()
+        assert [c[0] for c in kept] == list(range(5)) + list(range(n - 7, n))
+        if record:
+            assert kept == [c for c in cls.commits if c[0] < 5 or c[0] >= n - 7]
+        got.append(kept)
+    assert got[0] == got[1]
+
+
 @pytest.mark.parametrize("max_window,redo_every", [(32, 0), (4096, 0), (40, 7)])
 def test_streaming_windows_match_serial_loop(oracle, native, max_window, redo_every, monkeypatch):
     """Streaming windows (stream_begin / _abort / _end): records behind an insert are

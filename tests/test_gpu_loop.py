@@ -10,6 +10,13 @@ from helpers import default_seeds
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _needs_dev_hooks(native):
+    """The commit loop is frozen and only compiled into developer builds (make -C goldrush_amd/csrc DEV=1)."""
+    if not native.load().grp_dev_hooks():
+        pytest.skip("libgrpath_hip.so was built without GRP_DEV_HOOKS (make DEV=1): the commit loop is not in the product build")
+
+
 def _setup(oracle, native, reads, tile, k, h, m):
     seeds = default_seeds(h)
     eng = native.Engine(k, h, tile, m, seeds)

@@ -15,6 +15,7 @@
 //   mode 12: random atomicOr (u32) on table B        mode 13: random atomicCAS (u64) on table B
 //   mode 14: random 1-byte stores on table B         mode 15: 8 lanes read a 128-B bucket
 //   mode 16: quad reads a 64-B line of A, one lane writes 4 B of it back (a dirty random line)
+//   mode 20: mode 10's random lines in the loop shape of modes 11 / 17 / 18 (their reference)
 //   mode 19: random u32 load from table B, one per lane, keyed like a Bloom look-up (same as 1, kept for the tables)
 // usage: gather_bench <tableA_MiB> <tableB_MiB> <items_per_lane> <mode> [unroll] [workgroups]
 #include <hip/hip_runtime.h>
@@ -59,6 +60,17 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ A, uin
       for (int u = 0; u < UNR; ++u) v[u] = reinterpret_cast<const uint32_t*>(A)[(ia[u] % nb) * 16 + 2 + ((h2[u].y ^ ia[u]) % 14)];
 #pragma unroll
       for (int u = 0; u < UNR; ++u) acc += h2[u].x + v[u];
+    } else if (mode == 20) { // mode 10's access (a quad reads one random 64-B line) in the loop shape of modes 11 / 17 / 18
+      const uint64_t nbmask = nA / 4 - 1;
+      const int lane = threadIdx.x & 63;
+      const int sub = lane & 3;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint64_t idx = mix64((gid / 4) * 77ULL + (uint64_t)(it + u) * 0xD1B54A32D192ED03ULL) & nbmask;
+        const uint4 t = A[idx * 4 + sub];
+        const uint32_t got = __shfl(t.w, (lane & ~3) + (int)(idx & 3), 64);
+        acc += got + t.x;
+      }
     } else if (mode == 9 || mode == 10) {
       // cooperative: G lanes read one whole 64-B bucket with one coalesced access;
       // every lane still owns `items` probes, processed G at a time via shuffles
@@ -85,22 +97,26 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ A, uin
         }
       }
     } else if (mode == 11 || mode == 17 || mode == 18) {
+      // (table and region sizes are powers of two: masks and one reciprocal multiply, no 64-bit division —
+      // a first form spent its time in three `%` per item and measured the ALU, not the memory system)
       const uint64_t nb = nA / 4; // 64-B lines of table A
       const int lane = threadIdx.x & 63;
       const int sub = lane & 3;
-      const uint64_t nquads = (uint64_t)gridDim.x * blockDim.x / 4;
+      const uint32_t nquads = gridDim.x * blockDim.x / 4;
+      const uint32_t inv = (uint32_t)(0x100000000ull / lines_per_region); // region of item n ~ (n * inv) >> 32
+      const uint64_t rmask = region_lines - 1, nbmask = nb - 1, nregmask = nb / region_lines - 1;
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         uint64_t idx;
         if (mode == 11) {
-          const uint64_t n = (uint64_t)(it + u) * nquads + gid / 4; // grid order: the sweep
-          const uint64_t region = n / lines_per_region;
-          idx = (region * region_lines + mix64(n) % region_lines) % nb;
+          const uint32_t n = (uint32_t)(it + u) * nquads + (uint32_t)(gid / 4); // grid order: the sweep
+          const uint64_t region = ((uint64_t)n * inv) >> 32;
+          idx = (region * region_lines + (mix64(n) & rmask)) & nbmask;
         } else {
           // the lines of one wave (17) / workgroup (18) step share a random region
           const uint64_t scope = (mode == 17) ? gid / 64 : gid / 256;
-          const uint64_t region = mix64(scope * 0x9E3779B97F4A7C15ULL + (uint64_t)(it + u)) % (nb / region_lines);
-          idx = region * region_lines + mix64((gid / 4) * 77ULL + (uint64_t)(it + u) * 0xD1B54A32D192ED03ULL) % region_lines;
+          const uint64_t region = mix64(scope * 0x9E3779B97F4A7C15ULL + (uint64_t)(it + u)) & nregmask;
+          idx = region * region_lines + (mix64((gid / 4) * 77ULL + (uint64_t)(it + u) * 0xD1B54A32D192ED03ULL) & rmask);
         }
         const uint4 t = A[idx * 4 + sub];
         const uint32_t got = __shfl(t.w, (lane & ~3) + (int)(idx & 3), 64);
@@ -226,7 +242,7 @@ int main(int argc, char** argv)
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     double n = (double)wgs * 256 * items;
-    if (mode == 11 || mode == 17 || mode == 18) n /= 4; // one line per QUAD and item here
+    if (mode == 11 || mode == 17 || mode == 18 || mode == 20) n /= 4; // one line per QUAD and item here
     if (rep == 2 && (mode == 11 || mode == 17 || mode == 18)) printf("region=%lluB density=%.2f items=%d ", (unsigned long long)region_bytes, density, items);
     if (rep == 2) printf("mode %d A=%lluMiB B=%lluMiB unr=%d wgs=%d: %.2f ms, %.2f G items/s, %.2f G sector-loads/s -> %.2f TB/s at 64 B/sector\n", mode, (unsigned long long)aMiB, (unsigned long long)bMiB, unr, wgs, ms, n / ms / 1e6, n * ((mode == 2 || mode == 3) ? 2 : 1) / ms / 1e6, n * ((mode == 2 || mode == 3) ? 2 : 1) * 64 / ms / 1e9);
   }
