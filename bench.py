@@ -72,9 +72,9 @@ class ReadStream:
     region); otherwise batches of `batch` reads generated on demand, one resident at a time
     (C4: 50 M reads = 312 GB of 2-bit bases do not fit 288 GB of HBM)."""
 
-    def __init__(self, native, n_reads: int, genome: int, batch: int):
+    def __init__(self, native, n_reads: int, genome: int, batch: int, sigma: float = 0.25):
         self.native, self.n, self.G = native, n_reads, genome
-        self.plan = native.synth_read_plan(n_reads, genome)
+        self.plan = native.synth_read_plan(n_reads, genome, sigma=sigma)
         self.batch = batch if batch else n_reads
         self.n_batches = (n_reads + self.batch - 1) // self.batch
         self.cur = None  # (index, DeviceReads, ReadBatch, lens)
@@ -158,6 +158,10 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
     synth.write_fastq(fq, [(b"r%d" % i, s, b"5" * len(s)) for i, s in enumerate(head + steady)])
     del head, steady
     cores = int(host.load().gr_effective_cpus())  # affinity mask and cgroup quota
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        cpu_model = "unknown CPU"
     bits = eng.export_bits()  # the filter of the whole data set
     args = ["-k", str(k), "-w16", "-t", str(tile), "-h", str(len(seeds)), "-s", PRESET, "-g", str(genome), "-P10", "-d50", "-m0",
             "-j", str(cores), "-i", fq, "-p", os.path.join(tmp, "o")]
@@ -220,7 +224,12 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
                 break
         return done, ins, time.time() - t0 - t_check
 
-    h_done, h_ins, h_dt = timed(0, n_s, 2.0 * budget_s)  # the slow regime (~10 reads/s at C2) gets two thirds of the ~30 s
+    # the reference's structure: 6 hashing threads ahead of the serial loop through an ordered queue
+    # (read_hashing.cpp:77-117, goldrush_path.cpp:1219), OpenMP over the tiles of a read with -j threads
+    producers = 6
+    p.start_producers(producers, 0, n_s)
+    h_done, h_ins, h_dt = timed(0, n_s, 4.0 * budget_s)  # the slow regime (~10-25 reads/s at C2) gets most of the ~50 s
+    p.stop_producers()
     if silver:  # every silver path is an insert-heavy head: no steady state to compare
         p.close()
         for f in os.listdir(tmp):
@@ -228,7 +237,8 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
         os.rmdir(tmp)
         return {"value": h_done / h_dt, "unit": "reads/s", "cores": cores, "kind": "port", "oracle_check": check if kept is not None else None,
                 "sample": f"same filter (bit vector of all {n_reads} reads exported from the GPU, m={m}); reads 0..{h_done} of the stream on the empty ID arrays ({h_ins} inserts): "
-                          f"the regime of every silver path; oracle process_read loop (hash + query + decide + insert), OpenMP over tiles, {cores} threads"}
+                          f"the regime of every silver path; oracle process_read loop (query + decide + insert) with {producers} hashing producers ahead of it, OpenMP over tiles, -j {cores}; {cpu_model}",
+                "threads": f"{cores} OpenMP + {producers} hashing", "cpu_model": cpu_model}
     # the GPU's end state -> the oracle's arrays (chunks: the export stages through device memory)
     ids_p, cnt_p = lib.orcpy_mibf_data(mh), lib.orcpy_mibf_counts(mh)
     chunk = 1 << 28
@@ -237,6 +247,7 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
         eng._check(eng.lib.grp_export_ids(eng._h, a0, n, C.c_void_p(ids_p + 4 * a0), C.c_void_p(cnt_p + 4 * a0)))
     st = cls.state()
     p.set_state(st["ids_inserted"], st["inserted_bases"], st["id"])
+    p.start_producers(producers, n_s, n_s)
     s_done, s_ins, s_dt = timed(n_s, n_s)
     p.close()
     for f in os.listdir(tmp):
@@ -248,7 +259,9 @@ def cpu_baseline(dr, eng, cls, phases, silver, n_reads: int, m: int, pop: int, s
     return {"value": whole, "unit": "reads/s", "cores": cores, "kind": "port", "oracle_check": check if kept is not None else None,
             "sample": f"same filter (bit vector of all {n_reads} reads exported from the GPU, m={m}); head: reads 0..{h_done} on the empty ID arrays "
                       f"({h_ins} inserts); steady: reads {s0}..{s0 + s_done} on the GPU's end state (IDs / counts exported, {s_ins} inserts); oracle process_read loop "
-                      f"(hash + query + decide + insert), OpenMP over tiles, {cores} threads; value = the run's {hr} head / {sr} steady reads at the two CPU rates",
+                      f"(query + decide + insert) with {producers} hashing producers ahead of it through an ordered queue (the reference's structure), OpenMP over tiles, -j {cores}; {cpu_model}; "
+                      f"value = the run's {hr} head / {sr} steady reads at the two CPU rates",
+            "threads": f"{cores} OpenMP + {producers} hashing", "cpu_model": cpu_model,
             "head_reads_per_s": h_rate, "steady_reads_per_s": s_rate, "head_sample_reads": h_done, "steady_sample_reads": s_done}
 
 
@@ -293,6 +306,8 @@ def main():
     ap.add_argument("--silver", type=int, default=-1, help="silver-path mode with this many paths (-M); default: the config's")
     ap.add_argument("--stream-batch", type=int, default=-1, help="reads per resident batch (0: all resident; default: 2 M when the packed reads exceed 100 GB)")
     ap.add_argument("--max-window", type=int, default=0)
+    ap.add_argument("--len-sigma", type=float, default=0.25, help="sigma of the log-normal read lengths (mean 25 kb, floor 20 kb); 0.25 = the headline workload (no read above ~64 kb), "
+                    "0.6 = a realistic ONT tail (reads of 100 kb and more: the decision path for reads of more than 64 tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline-shaped", action="store_true", help="skip aux.pipeline_shaped (the silver-mode pass over the same reads after the timed region)")
     ap.add_argument("--trace", action="store_true", help="per-slice timing / speculation statistics on stderr")
@@ -364,7 +379,7 @@ def main():
     # ---- untimed setup: inputs resident in HBM, phase 1 -------------------------
     t0 = time.time()
     stream_batch = a.stream_batch if a.stream_batch >= 0 else (2_000_000 if n_reads * 6400 > 100e9 else 0)
-    rs = ReadStream(native, n_reads, G, stream_batch)
+    rs = ReadStream(native, n_reads, G, stream_batch, sigma=a.len_sigma)
     eng = native.Engine(k, h, tile, m, seeds, device=local_rank)
     rs.eng = eng
     rs.get(0)
@@ -622,6 +637,7 @@ def main():
                            cfg["name"], " [C3: stream shared by %d GPUs]" % world if (world > 1 and a.config == "C2") else "", h,
                            "silver-path mode, %d paths (the run ends behind the last path: reads_timed = reads consumed)" % max_paths if silver else "golden-path mode"),
                        "reads": n_reads, "reads_timed": reads_done, "reads_per_step": per_step, "genome": G, "filter_bits": m, "pop": pop,
+                       "read_lengths": {"sigma": a.len_sigma, "mean": float(rs.plan[1].mean()), "max": int(rs.plan[1].max()), "reads_over_64_tiles": int((rs.plan[1] >= 65 * tile).sum())},
                        "parallelism": ("one GPU: windows committed as batches where >= ~1 % of the reads insert, streaming windows elsewhere" if world == 1 else "replicated miBF on %d GPUs: batches on every rank where >= ~1 %% of the reads insert, streaming windows striped over the ranks elsewhere (32-B decisions all-gathered per stripe group)" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_unit": "HBM bytes per launch: " + pmc_note,

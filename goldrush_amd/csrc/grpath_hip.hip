@@ -139,11 +139,11 @@ struct BatchRun
   uint32_t* d_floor = nullptr;    // grp_batch_classify: per read of the window
   uint64_t floor_cap = 0;
   // grp_batch_verify: the window's tiles with records, then the tiles queried again; per read its insert entry
-  std::vector<uint32_t> h_vf_tiles, h_vf_read_ins;
-  uint32_t* d_vf_tiles = nullptr;
-  uint64_t vf_tiles_cap = 0;
-  uint32_t* d_vf_read_ins = nullptr;
-  uint64_t vf_read_ins_cap = 0;
+  uint32_t* h_vf_stage = nullptr; // page-locked: per read of the batch its insert entry, then the floors
+  uint64_t vf_stage_cap = 0;
+  uint32_t* d_vf_stage = nullptr;
+  uint64_t vf_stage_dev_cap = 0;
+  uint32_t* d_df = nullptr; // bitmap of the buckets the batch touched (grp_verify.inc)
   uint32_t first_read = 0;        // reads are numbered from here in the log
 };
 
@@ -203,6 +203,7 @@ struct grp_ctx
   uint64_t n_ovf = 0;    // IDs living in the overflow table
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
 
+  uint64_t n_stream_idle_exits = 0, n_stream_coop_refused = 0; // parked windows that left by themselves (idle limit); resumable windows whose cooperative launch was refused
   uint64_t n_flagged_tiles = 0, n_flagged_distinct = 0, n_flagged_list = 0; // statistics: tiles redone with the worst-case table; why (distinct IDs / list length)
   uint64_t n_verify_tiles = 0, n_verify_queried = 0, n_verify_flagged = 0, n_verify_fallbacks = 0, n_verify_uncertified = 0, n_verify_unpatched = 0; // grp_batch_verify: tiles patched from records / queried again / patched tiles redone / calls that took the second query
   uint64_t n_direct_windows = 0, n_direct_fallbacks = 0, n_general_windows = 0, n_redo_launches = 0; // GRP_DEBUG_STATS
@@ -260,7 +261,7 @@ struct grp_ctx
   double* d_delog = nullptr; // 10^(-Q/10) table for the FASTQ ingest
   const char* reg_text = nullptr; // the caller's text buffer, page-locked by grp_fastq_pin
   size_t reg_bytes = 0;
-  uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT) | (1u << GRP_K_VERIFY);
+  uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT) | (1u << GRP_K_VERIFY) | (1u << GRP_K_BATCH);
   // timing
   bool timing = true;
   std::vector<EventPair> pending;
@@ -527,6 +528,40 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     int rc = ensure_lds(c, kern, g.lds);
     if (rc != GRP_OK) {
       return rc;
+    }
+    if (stream_ctl && stream_ctl->ctl) {
+      // A window that applies inserts itself: its workgroups wait for each other inside the launch, so ALL of them
+      // must be resident at once.  The grid is sized from the occupancy query below; a cooperative launch makes the
+      // runtime guarantee it (or refuse: another process on the device) instead of inferring it.
+      // GRP_ERR_BUSY: refused — the caller begins the window in its classic form (it ends where it parks).
+      static const bool coop_off = [] { // developer switch
+        const char* e = getenv("GRP_STREAM_COOP");
+        return e && !strcmp(e, "off");
+      }();
+      if (!coop_off) {
+        DevFilter a_f = c->f;
+        DevReads a_rd = r->dev;
+        const DevSeeds* a_sd = c->d_seeds;
+        uint32_t a_tile = c->params.tile;
+        uint64_t a_t0 = t0;
+        const uint32_t* a_idx = d_tile_idx;
+        uint32_t a_cap = g.hist_cap, a_lim = g.distinct_limit;
+        grp_tile_summary* a_tiles = out_tiles;
+        grp_id_count* a_lists = out_lists;
+        uint64_t a_lcap = list_cap;
+        unsigned long long* a_ctr = reinterpret_cast<unsigned long long*>(c->q->d_qctr);
+        uint32_t* a_flag = (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx;
+        uint32_t a_fcap = (uint32_t)c->q->d_flag_cap, a_ds = direct_stride, a_blk0 = blk0;
+        DevStreamCtl a_sc = *stream_ctl;
+        DevBatchView a_bv{};
+        void* args[] = { &a_f, &a_rd, &a_sd, &a_tile, &a_t0, &a_idx, &a_cap, &a_lim, &a_tiles, &a_lists, &a_lcap, &a_ctr, &a_flag, &a_fcap, &a_ds, &a_blk0, &a_sc, &a_bv };
+        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3((uint32_t)n_launch), dim3(THREADS), args, (unsigned int)g.lds, c->stream);
+        if (e == hipSuccess) {
+          return GRP_OK;
+        }
+        (void)hipGetLastError();
+        return set_err(c, GRP_ERR_BUSY, "cooperative launch of a resumable window refused: %s", hipGetErrorString(e));
+      }
     }
     kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, blk0, stream_ctl ? *stream_ctl : DevStreamCtl{}, (c->view && !plain) ? *c->view : DevBatchView{});
     return GRP_OK;
@@ -875,8 +910,11 @@ grp_destroy(grp_ctx* c)
     (void)hipFree(b.d_log_next);
     (void)hipFree(b.d_log_slot);
     (void)hipFree(b.d_floor);
-    (void)hipFree(b.d_vf_tiles);
-    (void)hipFree(b.d_vf_read_ins);
+    (void)hipFree(b.d_vf_stage);
+    if (b.h_vf_stage) {
+      (void)hipHostFree(b.h_vf_stage);
+    }
+    (void)hipFree(b.d_df);
   }
   (void)hipFree(c->d_ntc);
   (void)hipFree(c->d_ntc_chunks);
@@ -2110,6 +2148,14 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
       Timer t(c, GRP_K_QUERY, 0); // the probes actually executed are added at _end
       int lrc = GRP_OK;
       DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, n_mine, t0, striped ? sl.d_stripe_tiles : nullptr, g, sl.list_cap, nullptr, nullptr, 0, &sc));
+      if (lrc == GRP_ERR_BUSY && sl.resumable) {
+        // the runtime cannot keep every workgroup of the window resident (the device is shared): the window is
+        // begun in its classic form — it ends where it parks, grp_classify_stream_insert says GRP_ERR_STATE
+        sl.resumable = false;
+        sc.ctl = nullptr;
+        ++c->n_stream_coop_refused;
+        DISPATCH_H(c->params.h, lrc = launch_query<HH>(c, r, n_mine, t0, striped ? sl.d_stripe_tiles : nullptr, g, sl.list_cap, nullptr, nullptr, 0, &sc));
+      }
       if (lrc != GRP_OK) {
         sl.busy = false;
         sl.streaming = false;
@@ -2182,6 +2228,10 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
       return set_err(c, GRP_ERR_STATE, "grp_classify_stream_end: a grid-wide wait timed out in the middle of an insert (the ID array may be inconsistent)");
     }
     if (code == 3) {
+      // The parked window was told nothing for its idle limit (16 x GRP_STREAM_WAIT_S: a host stopped by a
+      // debugger or SIGSTOP, a stalled file system) and left by itself.  It had modified nothing: not an error
+      //  — the records it did not produce stay open and the caller begins the window again behind
+      // the last one it has; what the launch was waiting on is kept as the context's last message.
       uint32_t first_open = sl.count;
       for (uint32_t j = 0; j < sl.count; ++j) {
         if (sl.h_sdec[j].pad != sl.gen) {
@@ -2189,11 +2239,11 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
           break;
         }
       }
-      return set_err(c, GRP_ERR_STATE,
-                     "grp_classify_stream_end: the parked window was never told how to go on (idle time limit); launch: park %u decided %u / %u next tile %u / %llu event %u command seen %u "
-                     "generation %u; host: %u reads, generation %u, commands posted %u applied %u, first record of another generation %u (pad %u kind %u)",
-                     sl.h_ack[8], sl.h_ack[9], 0u, sl.h_ack[10], (unsigned long long)sl.nt, sl.h_ack[11], sl.h_ack[12], sl.h_ack[13], sl.count, sl.gen, sl.cmd_seq, applied, first_open,
-                     first_open < sl.count ? sl.h_sdec[first_open].pad : 0u, first_open < sl.count ? sl.h_sdec[first_open].kind : 0u);
+      ++c->n_stream_idle_exits;
+      (void)set_err(c, GRP_OK,
+                    "grp_classify_stream_end: the parked window was never told how to go on (idle time limit) and left; launch: park %u decided %u next tile %u / %llu event %u command seen %u "
+                    "generation %u; host: %u reads, generation %u, commands posted %u applied %u, first open record %u",
+                    sl.h_ack[8], sl.h_ack[9], sl.h_ack[10], (unsigned long long)sl.nt, sl.h_ack[11], sl.h_ack[12], sl.h_ack[13], sl.count, sl.gen, sl.cmd_seq, applied, first_open);
     }
     if (applied != sl.cmd_seq) {
       // The launch ended without the insert posted last (an abort overtook it, or the first

@@ -102,6 +102,8 @@ Classifier::get_state(gr_classifier_state& s) const
   s.batches_refused = n_batch_refused_;
   s.batches_fused = n_batch_fused_;
   s.stream_inserts = n_stream_inserts_;
+  s.stream_insert_fallbacks = n_stream_insert_fallbacks_;
+  s.stream_relaunches = n_stream_relaunches_;
 }
 
 void
@@ -339,6 +341,8 @@ Classifier::end_stream(StreamFlight& f)
     // resident — a shared device — or an abort overtook it): nothing was inserted; the classic
     // call applies it, stream-ordered behind whatever is queued, and windows end at inserts again
     resume_disabled_ = true;
+    resume_clean_windows_ = 0;
+    ++n_stream_insert_fallbacks_;
     rc = GRP_OK;
     if (f.ins_posted) {
       rc = vt_.insert_read(ctx_, rg_.reads, f.ins_read, f.ins_ts, f.ins_te, p_.block_size, f.ins_first_id, f.ins_off);
@@ -352,6 +356,9 @@ Classifier::end_stream(StreamFlight& f)
   }
   f.ins_posted = false;
   n_queried_ += decided;
+  if (resume_disabled_ && rc == GRP_OK && ++resume_clean_windows_ >= 64) {
+    resume_disabled_ = false; // 64 windows ended cleanly since the last refused insert: parked windows are tried again
+  }
   return rc;
 }
 
@@ -370,11 +377,19 @@ Classifier::wait_record(const StreamFlight& f, uint32_t j)
     __builtin_ia32_pause();
     if ((++spins & 0x3FFFu) == 0) {
       if (finished_seen) {
-        if (f.ins_posted) {
-          return STREAM_LOST; // the launch gave up on the insert it was handed: end_stream applies it
+        // The launch is over and this record never came.  With an insert posted: the launch gave up on it
+        // (end_stream applies it).  Without: a parked window that was told nothing for its idle limit (a host
+        // stopped by a debugger, SIGSTOP, a stalled file system) has left by itself — nothing was modified, the
+        // window is ended and begun again at this read.  Twice in a row at the same read is an error.
+        if (!f.ins_posted && lost_at_ == (uint64_t)base_ + f.pos + j) {
+          err_ = "streaming window finished without deciding one of its reads";
+          return GRP_ERR_STATE;
         }
-        err_ = "streaming window finished without deciding one of its reads";
-        return GRP_ERR_STATE;
+        lost_at_ = f.ins_posted ? UINT64_MAX : (uint64_t)base_ + f.pos + j;
+        if (!f.ins_posted) {
+          ++n_stream_relaunches_;
+        }
+        return STREAM_LOST;
       }
       const int st = vt_.stream_poll(ctx_, f.slot);
       if (st < 0) {
@@ -793,6 +808,7 @@ Classifier::stream_decision(uint32_t j, gr_read_decision& d)
     const int e = wait_record(scur_, j);
     if (e == GRP_OK) {
       d = scur_.dec[j];
+      scur_.ins_posted = false; // a record of the generation behind the posted insert: the launch has applied it
     }
     return e;
   }

@@ -21,8 +21,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libgrpath_hip.so")
 
 GRP_OK = 0
 GRP_ERR_INVALID, GRP_ERR_NO_DEVICE, GRP_ERR_HIP, GRP_ERR_STATE, GRP_ERR_NOMEM, GRP_ERR_BUSY = -1, -2, -3, -4, -5, -6
-GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_LOOP, GRP_K_QUERY_LAT, GRP_K_VERIFY, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard", "loop", "query_latency", "verify")
+GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_LOOP, GRP_K_QUERY_LAT, GRP_K_VERIFY, GRP_K_BATCH, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard", "loop", "query_latency", "verify", "batch_insert")
 GRP_LOOP_RUNNING, GRP_LOOP_DONE, GRP_LOOP_ROLLOVER, GRP_LOOP_HANDBACK, GRP_LOOP_STOPPED, GRP_LOOP_TIMEOUT = 0, 1, 2, 3, 4, 5
 
 

@@ -633,7 +633,9 @@ enum
   GRP_K_QUERY_LAT = 7, /* the query kernel in its latency form: windows of a few reads written straight to
                           host memory (insert-heavy stretches); GRP_K_QUERY holds the throughput forms */
   GRP_K_VERIFY = 8,   /* grp_batch_verify: inserted tiles patched from the batch's records (units = their probes) */
-  GRP_K_COUNT = 9
+  GRP_K_BATCH = 9,    /* grp_batch_insert_reads: collect + apply of a whole batch (units = (frame, seed) records); large launches,
+                         timed by default — GRP_K_INSERT holds the latency-critical single-read inserts */
+  GRP_K_COUNT = 10
 };
 
 typedef struct

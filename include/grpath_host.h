@@ -223,6 +223,9 @@ typedef struct
   /* round 3: batches whose first decisions came out of the previous batch's second-query launch; inserts a
    * streaming window applied inside its own launch (grp_classify_stream_insert) */
   uint64_t batches_fused, stream_inserts;
+  /* round 4: inserts a parked window did not apply (applied the classic way; parked windows are tried again after 64
+   * clean windows), windows begun again because their launch had left without deciding a read (idle limit) */
+  uint64_t stream_insert_fallbacks, stream_relaunches;
 } gr_classifier_state;
 void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
 

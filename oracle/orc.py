@@ -402,6 +402,16 @@ class Path:
                 break
         return out
 
+    def start_producers(self, n: int, first: int, count: int):
+        """n hashing threads ahead of process() for reads [first, first + count) (read_hashing.cpp:77-117: the reference runs 6)"""
+        self.lib.orc_path_start_producers.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t]
+        if self.lib.orc_path_start_producers(self._h, n, first, count) != 0:
+            raise ValueError("bad producer range")
+
+    def stop_producers(self):
+        self.lib.orc_path_stop_producers.argtypes = [C.c_void_p]
+        self.lib.orc_path_stop_producers(self._h)
+
     def set_state(self, ids_inserted: int, inserted_bases: int, id_: int):
         self.lib.orc_path_set_state(self._h, ids_inserted, inserted_bases, id_)
 

@@ -18,6 +18,7 @@
 #include <time.h>
 #if defined(_OPENMP)
 #include <omp.h>
+#include <pthread.h>
 #endif
 
 static double
@@ -1282,6 +1283,34 @@ struct orc_path
   int finished;
   double t_fill;
   double t_assign_start;
+  struct orc_producers* prod; /* hashing threads running ahead of process_read (orc_path_start_producers), NULL: hashes are computed inline */
+};
+
+/* ---- the hashing producers of read_hashing.cpp:77-117 ------------------------------------------------------
+ * The reference hashes with `worker_num` threads (6, goldrush_path.cpp:1219) that take reads from the reader's
+ * queue and push {record, tile hashes} into an ORDER queue the main thread consumes (btllib::OrderQueueMPMC):
+ * hashing runs ahead of, and beside, the serial process_read loop.  Here: n threads draw read indices from a
+ * counter, hash, and put the result into a ring of Q slots in index order (slot = index % Q; a producer waits
+ * until the consumer has passed index - Q).  Reads that process_read skips without hashing (too short, filtered)
+ * get an empty entry. */
+typedef struct
+{
+  orc_tile_hashes th;
+  size_t idx;
+  int ready, hashed;
+} orc_prod_slot;
+
+struct orc_producers
+{
+  orc_path* p;
+  pthread_t* threads;
+  int n;
+  size_t first, end, next, consumed; /* next: next index to hash; consumed: every index below it has been taken */
+  orc_prod_slot* ring;
+  size_t Q;
+  int stop;
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
 };
 
 #define LOGF(p, ...)                                                                                                   \
@@ -1668,6 +1697,126 @@ progress(orc_path* p)
   }
 }
 
+
+static int strset_has(const strset* ss, const char* s);
+
+static void*
+producer_main(void* arg)
+{
+  struct orc_producers* pr = (struct orc_producers*)arg;
+  orc_path* p = pr->p;
+  for (;;) {
+    pthread_mutex_lock(&pr->mu);
+    if (pr->stop || pr->next >= pr->end) {
+      pthread_mutex_unlock(&pr->mu);
+      return NULL;
+    }
+    const size_t idx = pr->next++;
+    pthread_mutex_unlock(&pr->mu);
+    const orc_record* record = &p->reads->rec[idx];
+    orc_tile_hashes th;
+    memset(&th, 0, sizeof(th));
+    int hashed = 0;
+    /* the reads process_read hashes: long enough and not filtered out (read_hashing.cpp:31-43 / goldrush_path.cpp:907-932) */
+    if (record->len >= p->opt.min_length && !(p->filter_out_reads.n != 0 && strset_has(&p->filter_out_reads, record->id))) {
+      orc_hash_read_tiles(&th, record->seq, record->len, p->opt.tile_length, p->opt.kmer_size, p->seeds, p->h, 1);
+      hashed = 1;
+    }
+    pthread_mutex_lock(&pr->mu);
+    while (!pr->stop && idx >= pr->consumed + pr->Q) { /* the ring is full: the consumer has not passed idx - Q yet */
+      pthread_cond_wait(&pr->cv, &pr->mu);
+    }
+    if (pr->stop) {
+      pthread_mutex_unlock(&pr->mu);
+      if (hashed) {
+        orc_tile_hashes_free(&th);
+      }
+      return NULL;
+    }
+    orc_prod_slot* sl = &pr->ring[idx % pr->Q];
+    sl->th = th;
+    sl->idx = idx;
+    sl->hashed = hashed;
+    sl->ready = 1;
+    pthread_cond_broadcast(&pr->cv);
+    pthread_mutex_unlock(&pr->mu);
+  }
+}
+
+void
+orc_path_stop_producers(orc_path* p)
+{
+  struct orc_producers* pr = p ? p->prod : NULL;
+  if (!pr) {
+    return;
+  }
+  pthread_mutex_lock(&pr->mu);
+  pr->stop = 1;
+  pthread_cond_broadcast(&pr->cv);
+  pthread_mutex_unlock(&pr->mu);
+  for (int i = 0; i < pr->n; ++i) {
+    pthread_join(pr->threads[i], NULL);
+  }
+  for (size_t i = 0; i < pr->Q; ++i) {
+    if (pr->ring[i].ready && pr->ring[i].hashed) {
+      orc_tile_hashes_free(&pr->ring[i].th);
+    }
+  }
+  pthread_mutex_destroy(&pr->mu);
+  pthread_cond_destroy(&pr->cv);
+  free(pr->ring);
+  free(pr->threads);
+  free(pr);
+  p->prod = NULL;
+}
+
+/* n hashing threads for the reads [first, first + count), which must then be processed in order, each once */
+int
+orc_path_start_producers(orc_path* p, int n, size_t first, size_t count)
+{
+  if (!p || n <= 0 || first + count > p->reads->n) {
+    return -1;
+  }
+  orc_path_stop_producers(p);
+  struct orc_producers* pr = (struct orc_producers*)calloc(1, sizeof(*pr));
+  pr->p = p;
+  pr->n = n;
+  pr->first = pr->next = pr->consumed = first;
+  pr->end = first + count;
+  pr->Q = 64; /* reads in flight between the producers and the consumer */
+  pr->ring = (orc_prod_slot*)calloc(pr->Q, sizeof(orc_prod_slot));
+  pr->threads = (pthread_t*)calloc((size_t)n, sizeof(pthread_t));
+  pthread_mutex_init(&pr->mu, NULL);
+  pthread_cond_init(&pr->cv, NULL);
+  p->prod = pr;
+  for (int i = 0; i < n; ++i) {
+    pthread_create(&pr->threads[i], NULL, producer_main, pr);
+  }
+  return 0;
+}
+
+/* the consumer's side: the hashes of read idx (1), or 0 when idx is not the next read of the producers' range */
+static int
+producer_take(orc_path* p, size_t idx, orc_tile_hashes* th)
+{
+  struct orc_producers* pr = p->prod;
+  if (!pr || idx != pr->consumed || idx >= pr->end) {
+    return 0;
+  }
+  pthread_mutex_lock(&pr->mu);
+  orc_prod_slot* sl = &pr->ring[idx % pr->Q];
+  while (!(sl->ready && sl->idx == idx)) {
+    pthread_cond_wait(&pr->cv, &pr->mu);
+  }
+  *th = sl->th;
+  const int hashed = sl->hashed;
+  sl->ready = 0;
+  pr->consumed = idx + 1;
+  pthread_cond_broadcast(&pr->cv);
+  pthread_mutex_unlock(&pr->mu);
+  return hashed ? 1 : 2;
+}
+
 void
 orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
 {
@@ -1684,6 +1833,8 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
     dec->finished = 1;
     return;
   }
+  orc_tile_hashes th;
+  const int taken = producer_take(p, idx, &th); /* 1: hashed ahead by a producer thread, 2: a read that is not hashed, 0: no producers */
   if (record->len < opt->min_length) { /* :907-918 */
     if (opt->debug) {
       LOGF(p, "too short\nskipping: %s\n", record->id);
@@ -1712,9 +1863,11 @@ orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec)
     LOGF(p, "name: %s\nnum tiles: %zu\n", record->id, num_tiles);
   }
 
-  /* the producer side (read_hashing.cpp:29-54): hashes of this read's tiles */
-  orc_tile_hashes th;
-  orc_hash_read_tiles(&th, record->seq, len, opt->tile_length, opt->kmer_size, p->seeds, p->h, 1);
+  /* the producer side (read_hashing.cpp:29-54): hashes of this read's tiles — computed ahead by the hashing
+   * threads when there are any (orc_path_start_producers), inline otherwise */
+  if (taken != 1) {
+    orc_hash_read_tiles(&th, record->seq, len, opt->tile_length, opt->kmer_size, p->seeds, p->h, 1);
+  }
 
   int assigned = 1;
   uint32_t* ids = (uint32_t*)calloc(num_tiles ? num_tiles : 1, sizeof(uint32_t));
@@ -1873,6 +2026,9 @@ cleanup:
 void
 orc_path_close(orc_path* p)
 {
+  if (p) {
+    orc_path_stop_producers(p);
+  }
   if (!p) {
     return;
   }

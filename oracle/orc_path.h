@@ -217,6 +217,11 @@ void orc_path_set_state(orc_path* p, uint32_t ids_inserted, uint64_t inserted_ba
 void orc_path_process_read(orc_path* p, size_t idx, orc_decision* dec);
 /* tail of main() (:1257-1273) and cleanup */
 void orc_path_close(orc_path* p);
+/* The reference's hashing producers (read_hashing.cpp:77-117; 6 threads, goldrush_path.cpp:1219): n threads hash the
+ * reads [first, first + count) ahead of orc_path_process_read through an ordered ring of 64 reads; the reads of
+ * the range must then be processed in order, each once.  Without them process_read hashes inline. */
+int orc_path_start_producers(orc_path* p, int n, size_t first, size_t count);
+void orc_path_stop_producers(orc_path* p);
 
 /* accessors for tests */
 orc_mibf* orc_path_mibf(orc_path* p);

@@ -290,7 +290,7 @@ def test_long_reads_small_tiles_all_decision_paths(oracle, native, mode, monkeyp
     register state (<= 64 tiles), LDS arrays (<= 256), and, in a streaming window, the
     hand-back to the synchronous path (kind 0) for longer reads."""
     from goldrush_amd import host, synth
-    from oracle_engine import serial_reference
+    from oracle_engine import cached_serial_reference
 
     for key, val in ({"GRP_BATCH": "off", "GRP_STREAM": "force"} if mode == "stream" else {"GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "force"}).items():
         monkeypatch.setenv(key, val)
@@ -301,17 +301,17 @@ def test_long_reads_small_tiles_all_decision_paths(oracle, native, mode, monkeyp
     reads += [g[5000:5000 + 30500].tobytes(), g[40000:40000 + 26000].tobytes(), g[70000:70000 + 6400].tobytes()]
     assert max(len(r) for r in reads) // tile > 256 and any(64 < len(r) // tile <= 256 for r in reads)
     m = oracle.load().orc_calc_optimal_size(3_000_000, 1, 0.1)
-    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=100_000, max_paths=4)
+    exp, ref_ids, ref_counts, ref_pop = cached_serial_reference("long_reads_small_tiles", oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=100_000, max_paths=4)
     eng = native.Engine(k, h, tile, m, seeds)
     b = eng.upload(reads)
     eng.bv_insert(b)
-    assert eng.finalize() == mf_ref.pop
+    assert eng.finalize() == ref_pop
     cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, k=k, h=h, target_bases=100_000, max_paths=4, silver_path=True, max_window=64)
     cls.run(b._h, b.lens)
     eng.sync()
     assert [c[:8] for c in cls.commits] == exp
     ids, counts = eng.export_ids()
-    assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
+    assert np.array_equal(ids, ref_ids) and np.array_equal(counts, ref_counts)
     kinds = [e[1] for e in exp]
     assert kinds.count(2) >= 3 and (kinds.count(3) + kinds.count(5)) >= 10, kinds
 

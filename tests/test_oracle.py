@@ -53,6 +53,26 @@ def test_fixture_end_to_end(oracle, fx, tmp_path):
         assert hashlib.sha256(open(tmp_path / name.replace("out", "cli"), "rb").read()).hexdigest() == sha
 
 
+@pytest.mark.parametrize("n", [1, 6])
+def test_hashing_producers_change_nothing(oracle, fx, tmp_path, n):
+    """The reference hashes with 6 threads ahead of its serial loop (read_hashing.cpp:77-117, goldrush_path.cpp:1219);
+    the oracle's producers (orc_path_start_producers: an ordered ring in front of process_read, what bench.py's CPU
+    baseline runs with) deliver the hashes the loop would have computed itself — same decisions, same files; a range
+    that starts in the middle, reads skipped without hashing, producers stopped early."""
+    p = oracle.Path(fx["tiny_args"] + ["-i", os.path.join(GOLD, "tiny.fq"), "-p", str(tmp_path / "out")])
+    half = p.n_reads // 2
+    p.start_producers(n, 0, half)
+    out = [p.process(i) for i in range(half)]
+    p.start_producers(n, half, p.n_reads - half)  # (a second range; the first one's threads are joined)
+    out += [p.process(i) for i in range(half, p.n_reads)]
+    got = [[d.decision, d.num_tiles, d.num_assigned, d.trim_start, d.trim_end, d.first_id, d.path_at_write] for d in out if not (d.finished and d.decision == 0 and d.num_tiles == 0)]
+    assert got == fx["tiny_decisions"]
+    p.start_producers(n, 0, 5)  # never consumed: close stops and joins them
+    p.close()
+    for name, sha in fx["tiny_outputs"].items():
+        assert hashlib.sha256(open(tmp_path / name, "rb").read()).hexdigest() == sha
+
+
 def test_split_rotate(oracle):
     lib = oracle.load()
     rng = np.random.default_rng(1)
