@@ -143,7 +143,6 @@ struct BatchRun
   uint64_t vf_stage_cap = 0;
   uint32_t* d_vf_stage = nullptr;
   uint64_t vf_stage_dev_cap = 0;
-  uint32_t* d_df = nullptr; // bitmap of the buckets the batch touched (grp_verify.inc)
   uint32_t first_read = 0;        // reads are numbered from here in the log
 };
 
@@ -203,6 +202,8 @@ struct grp_ctx
   uint64_t n_ovf = 0;    // IDs living in the overflow table
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
 
+  // developer switches, read once at grp_create (not on every call of a latency path)
+  bool env_no_direct = false, env_stream_resume_off = false, env_no_early_park = false, env_trace_abort = false;
   uint64_t n_stream_idle_exits = 0, n_stream_coop_refused = 0; // parked windows that left by themselves (idle limit); resumable windows whose cooperative launch was refused
   uint64_t n_flagged_tiles = 0, n_flagged_distinct = 0, n_flagged_list = 0; // statistics: tiles redone with the worst-case table; why (distinct IDs / list length)
   uint64_t n_verify_tiles = 0, n_verify_queried = 0, n_verify_flagged = 0, n_verify_fallbacks = 0, n_verify_uncertified = 0, n_verify_unpatched = 0; // grp_batch_verify: tiles patched from records / queried again / patched tiles redone / calls that took the second query
@@ -725,6 +726,13 @@ grp_create(const grp_params* p, grp_ctx** out)
     set_err(c, GRP_ERR_NO_DEVICE, "hipGetDevice failed");
     return fail(GRP_ERR_NO_DEVICE);
   }
+  {
+    const char* e = getenv("GRP_STREAM_RESUME");
+    c->env_stream_resume_off = e && !strcmp(e, "off");
+    c->env_no_direct = getenv("GRP_NO_DIRECT") != nullptr;
+    c->env_no_early_park = getenv("GRP_NO_EARLY_PARK") != nullptr;
+    c->env_trace_abort = getenv("GRP_TRACE_ABORT") != nullptr;
+  }
   int rc = build_seed_tables(c);
   if (rc != GRP_OK) {
     return fail(rc);
@@ -914,7 +922,6 @@ grp_destroy(grp_ctx* c)
     if (b.h_vf_stage) {
       (void)hipHostFree(b.h_vf_stage);
     }
-    (void)hipFree(b.d_df);
   }
   (void)hipFree(c->d_ntc);
   (void)hipFree(c->d_ntc_chunks);
@@ -1497,7 +1504,7 @@ grp_query_tiles(grp_ctx* c,
   if (!tiles_out) {
     return set_err(c, GRP_ERR_INVALID, "grp_query_tiles: tiles_out is NULL");
   }
-  if (nt <= SMALL_TILES && !getenv("GRP_NO_DIRECT")) { // (developer hook: force the general path)
+  if (nt <= SMALL_TILES && !c->env_no_direct) { // (GRP_NO_DIRECT, developer hook: force the general path)
     // latency path (insert-heavy phases query one read at a time): the kernel
     // writes summaries and lists straight into mapped host memory, no copies,
     // no counters; one stream synchronisation
@@ -2070,8 +2077,7 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
   // waits for the host's word — _abort, or _insert: the insert the host has committed, applied
   // inside the launch.  Not when the scratch table would have to grow while the other slot's
   // window holds its address (the window is then an ordinary one; _insert says so).
-  const char* resume_env = getenv("GRP_STREAM_RESUME"); // developer switch / tests: "off" = every window ends where it parks
-  const bool resume_off = resume_env && !strcmp(resume_env, "off");
+  const bool resume_off = c->env_stream_resume_off; // GRP_STREAM_RESUME=off (developer switch / tests, read at grp_create): every window ends where it parks
   sl.resumable = false;
   if (want_resumable && !striped && !resume_off && n_mine != 0) {
     const uint64_t need_ranks = max_tiles_read * c->params.tile * c->params.h;
@@ -2122,7 +2128,7 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
     sc.abort_host = sl.dmap_abort;
     sc.next_tile = sl.d_abort + 32;
     sc.park = sl.d_abort + 48;
-    sc.early_park = getenv("GRP_NO_EARLY_PARK") ? 0u : 1u; // developer hook (the engine-level API contract assumes 1)
+    sc.early_park = c->env_no_early_park ? 0u : 1u; // GRP_NO_EARLY_PARK, developer hook (the engine-level API contract assumes 1)
     sc.n_tiles = (uint32_t)n_mine;
     sc.dec = sl.dmap_sdec;
     sc.executed = sl.d_executed;
@@ -2281,7 +2287,7 @@ grp_classify_stream_insert(grp_ctx* c, uint32_t slot, uint32_t read_idx, uint32_
   if ((tile_end - tile_start + block_tiles - 1) / block_tiles > 64) {
     return set_err(c, GRP_ERR_STATE, "grp_classify_stream_insert: more than 64 ID blocks (the caller ends the window and uses grp_insert_read)");
   }
-  if (sl.cmd_seq != 0 && getenv("GRP_TRACE_ABORT")) { // developer trace: phase times of the previous in-launch insert (100 MHz ticks)
+  if (sl.cmd_seq != 0 && c->env_trace_abort) { // GRP_TRACE_ABORT, developer trace: phase times of the previous in-launch insert (100 MHz ticks)
     static double t_ph[4] = { 0, 0, 0, 0 };
     static uint64_t n_tr = 0;
     for (int i = 0; i < 4; ++i) {

@@ -20,6 +20,16 @@ Classifier::Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, v
   , vt_(vt)
   , ctx_(ctx)
 {
+  // the behaviour switches are read ONCE per classifier, not per window
+  auto env = [](const char* name) { const char* e = getenv(name); return std::string(e ? e : ""); };
+  env_.pipeline = env("GRP_PIPELINE");
+  env_.stream = env("GRP_STREAM");
+  env_.loop = env("GRP_LOOP");
+  env_.batch = env("GRP_BATCH");
+  {
+    const std::string t = env("GRP_MAX_WINDOW_TILES");
+    env_.max_window_tiles = t.empty() ? 0 : (uint64_t)std::max(1l, atol(t.c_str()));
+  }
   if (p_.world == 0) {
     p_.world = 1;
   }
@@ -166,11 +176,9 @@ Classifier::window_plan() const
   }();
   // GRP_PIPELINE=off: synchronous rounds only; =force: pipelined whenever the window
   // cap allows (tests)
-  const char* pipe_env = getenv("GRP_PIPELINE");
-  const bool no_pipeline = pipe_env && !strcmp(pipe_env, "off");
-  const bool force_pipeline = pipe_env && !strcmp(pipe_env, "force");
-  const char* stream_env = getenv("GRP_STREAM");
-  const bool force_stream = stream_env && !strcmp(stream_env, "force");
+  const bool no_pipeline = env_.pipeline == "off";
+  const bool force_pipeline = env_.pipeline == "force";
+  const bool force_stream = env_.stream == "force";
   // With the batches of batch_round taking every stretch where more than ~1 % of the reads insert,
   // the windows only see isolated inserts: the 32-read average (one insert = 3 %) would answer
   // each of them with a handful of small synchronous windows (~0.8 ms per insert, measured on
@@ -259,8 +267,7 @@ Classifier::window_plan() const
 bool
 Classifier::can_stream() const
 {
-  const char* e = getenv("GRP_STREAM");
-  return vt_.stream_begin && vt_.stream_abort && vt_.stream_poll && vt_.stream_end && (p_.world == 1 || allgather_cb_) && !(e && !strcmp(e, "off"));
+  return vt_.stream_begin && vt_.stream_abort && vt_.stream_poll && vt_.stream_end && (p_.world == 1 || allgather_cb_) && env_.stream != "off";
 }
 
 uint32_t
@@ -289,8 +296,8 @@ Classifier::stripe_reads() const
 uint32_t
 Classifier::clamp_tiles(uint32_t pos, uint32_t S, uint64_t max_tiles) const
 {
-  if (const char* e = getenv("GRP_MAX_WINDOW_TILES")) { // tests: a tiny cap
-    max_tiles = std::min<uint64_t>(max_tiles, std::max(1l, atol(e)));
+  if (env_.max_window_tiles) { // tests: a tiny cap (GRP_MAX_WINDOW_TILES)
+    max_tiles = std::min<uint64_t>(max_tiles, env_.max_window_tiles);
   }
   if (S <= 1 || tile0_[(size_t)pos + S] - tile0_[pos] <= max_tiles) {
     return S;
@@ -843,9 +850,8 @@ Classifier::can_loop() const
 {
   // opt-in (GRP_LOOP=on / force): over a whole C2 stream the loop did not beat the host-driven
   // windows (head 27.2 s against 25.0 s, profiles/README.md), see want_loop
-  const char* e = getenv("GRP_LOOP");
   const bool built = p_.hash_num == 1 || p_.hash_num == 3 || p_.hash_num == 5; // the frozen path is compiled for these seed counts (round 3)
-  return vt_.loop_begin && vt_.loop_stop && vt_.loop_poll && vt_.loop_end && !loop_disabled_ && built && e && (!strcmp(e, "on") || !strcmp(e, "force"));
+  return vt_.loop_begin && vt_.loop_stop && vt_.loop_poll && vt_.loop_end && !loop_disabled_ && built && (env_.loop == "on" || env_.loop == "force");
 }
 
 // Measured on MI355X (tools/loop_matrix.sh, profiles/r02_loop_matrix.txt): the device-side
@@ -860,8 +866,7 @@ Classifier::want_loop() const
   if (!can_loop() || p_.debug) {
     return false;
   }
-  const char* e = getenv("GRP_LOOP");
-  if (e && !strcmp(e, "force")) {
+  if (env_.loop == "force") {
     return true;
   }
   static const double p_in = [] {
@@ -885,9 +890,7 @@ Classifier::want_loop() const
 bool
 Classifier::can_batch() const
 {
-  const char* e = getenv("GRP_BATCH");
-  return vt_.batch_insert && vt_.batch_classify && vt_.batch_undo && vt_.batch_end && vt_.classify_reads && vt_.insert_read && !p_.debug && p_.max_window >= 2 &&
-         !(e && !strcmp(e, "off"));
+  return vt_.batch_insert && vt_.batch_classify && vt_.batch_undo && vt_.batch_end && vt_.classify_reads && vt_.insert_read && !p_.debug && p_.max_window >= 2 && env_.batch != "off";
 }
 
 bool
@@ -896,8 +899,7 @@ Classifier::want_batch() const
   if (!can_batch() || batch_bypass_) {
     return false;
   }
-  const char* e = getenv("GRP_BATCH");
-  if (e && !strcmp(e, "force")) {
+  if (env_.batch == "force") {
     return true;
   }
   // a batch costs two queries per read whatever the insert rate (~4.5 us on C2); the classic
@@ -1291,8 +1293,7 @@ Classifier::loop_round(uint32_t& pos)
   ++n_windows_;
   ++n_loops_;
   in_loop_ = true;
-  const char* force_env = getenv("GRP_LOOP");
-  const bool forced = force_env && !strcmp(force_env, "force");
+  const bool forced = env_.loop == "force";
   uint32_t consumed = 0, spins = 0;
   bool stop_sent = false, ended = false, rolled = false;
   while (rc == GRP_OK) {

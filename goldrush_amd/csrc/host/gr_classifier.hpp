@@ -94,6 +94,11 @@ private:
   gr_classifier_params p_;
   grp_engine_vt vt_;
   void* ctx_;
+  struct
+  {
+    std::string pipeline, stream, loop, batch; // GRP_PIPELINE / GRP_STREAM / GRP_LOOP / GRP_BATCH as found when the classifier was created
+    uint64_t max_window_tiles = 0;             // GRP_MAX_WINDOW_TILES (0: unset)
+  } env_;
   gr_commit_fn commit_cb_ = nullptr;
   uint32_t keep_first_[2] = { 0, 0 }, keep_count_[2] = { 0, 0 };
   std::vector<gr_commit> kept_;

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 #include <zlib.h>
@@ -18,6 +19,7 @@ namespace gr {
 // behind it parses > 20 GB/s).  Everything else — gzip data, pipes — goes through zlib.
 InputFile::InputFile(const std::string& path)
 {
+  path_ = path;
   const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
   if (fd >= 0) {
     struct stat st;
@@ -49,8 +51,43 @@ InputFile::~InputFile()
   }
 }
 
+namespace {
+std::mutex g_fail_mu;
+std::string g_fail_what;
+bool g_failed = false;
+} // namespace
+
+void
+note_input_failure(const std::string& what)
+{
+  std::lock_guard<std::mutex> g(g_fail_mu);
+  if (!g_failed) {
+    g_failed = true;
+    g_fail_what = what;
+  }
+}
+
+bool
+input_failed(std::string* what)
+{
+  std::lock_guard<std::mutex> g(g_fail_mu);
+  if (g_failed && what) {
+    *what = g_fail_what;
+  }
+  return g_failed;
+}
+
+void
+clear_input_failure()
+{
+  std::lock_guard<std::mutex> g(g_fail_mu);
+  g_failed = false;
+  g_fail_what.clear();
+}
+
+// *err: errno of a read that failed (0: none; a short count is then the end of the file)
 static size_t
-pread_all(int fd, char* dst, size_t n, uint64_t off)
+pread_all(int fd, char* dst, size_t n, uint64_t off, int* err)
 {
   size_t got = 0;
   while (got < n) {
@@ -58,7 +95,11 @@ pread_all(int fd, char* dst, size_t n, uint64_t off)
     if (r < 0 && errno == EINTR) {
       continue;
     }
-    if (r <= 0) {
+    if (r < 0) {
+      *err = errno;
+      break;
+    }
+    if (r == 0) {
       break;
     }
     got += (size_t)r;
@@ -73,26 +114,34 @@ InputFile::read(char* dst, size_t n)
     constexpr size_t kSlice = size_t(16) << 20;
     size_t threads = std::min<size_t>(n / kSlice, std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())));
     size_t got = 0;
+    int err = 0;
     if (threads < 2) {
-      got = pread_all(fd_, dst, n, off_);
+      got = pread_all(fd_, dst, n, off_, &err);
     } else {
       // slice i covers [i * per, (i + 1) * per); the data ends in the first short slice
       const size_t per = (n + threads - 1) / threads;
       std::vector<size_t> part(threads, 0);
+      std::vector<int> errs(threads, 0);
       std::vector<std::thread> pool;
       for (size_t i = 1; i < threads; ++i) {
-        pool.emplace_back([&, i] { part[i] = pread_all(fd_, dst + i * per, std::min(per, n - i * per), off_ + i * per); });
+        pool.emplace_back([&, i] { part[i] = pread_all(fd_, dst + i * per, std::min(per, n - i * per), off_ + i * per, &errs[i]); });
       }
-      part[0] = pread_all(fd_, dst, per, off_);
+      part[0] = pread_all(fd_, dst, per, off_, &errs[0]);
       for (auto& t : pool) {
         t.join();
       }
       for (size_t i = 0; i < threads; ++i) {
         got += part[i];
         if (part[i] < std::min(per, n - i * per)) {
+          err = errs[i];
           break;
         }
       }
+    }
+    // the size is known: a read that failed, or data that ends in front of it, is an error and not the end of the input
+    const uint64_t want = std::min<uint64_t>(n, size_ > off_ ? size_ - off_ : 0);
+    if (err != 0 || got < want) {
+      note_input_failure("reading " + path_ + " failed at byte " + std::to_string(off_ + got) + " of " + std::to_string(size_) + ": " + (err ? strerror(err) : "the file ends early"));
     }
     off_ += got;
     return got;
@@ -101,7 +150,13 @@ InputFile::read(char* dst, size_t n)
   while (f_ && got < n) { // gzread takes an unsigned length
     const unsigned want = (unsigned)std::min<size_t>(n - got, 1u << 30);
     const int r = gzread(static_cast<gzFile>(f_), dst + got, want);
-    if (r <= 0) {
+    if (r < 0) {
+      int zerr = 0;
+      const char* msg = gzerror(static_cast<gzFile>(f_), &zerr);
+      note_input_failure("reading " + path_ + " failed: " + (msg ? msg : "zlib error"));
+      break;
+    }
+    if (r == 0) {
       break;
     }
     got += (size_t)r;

@@ -14,6 +14,13 @@ namespace gr {
 
 // the input file: a plain regular file (pread, large requests by several threads) or anything
 // zlib reads — gzip data, pipes (GRP_ZLIB_READER=1 sends plain files through zlib too)
+// An input that could not be read to its end (EIO, a file that shrank under the run, a damaged gzip stream) must not
+// pass for a shorter input: the readers below note it here (first message wins) and the program ends with an
+// error behind the pass that met it instead of classifying a prefix of the reads silently.
+void note_input_failure(const std::string& what);
+bool input_failed(std::string* what = nullptr);
+void clear_input_failure();
+
 class InputFile
 {
 public:
@@ -31,6 +38,7 @@ private:
   int fd_ = -1;       // plain regular file
   uint64_t off_ = 0;  // ... and the read position in it
   uint64_t size_ = 0;
+  std::string path_;
 };
 
 struct RecordRef

@@ -856,6 +856,9 @@ commit_sink(void* user, const gr_commit* c)
   if (c->dec.kind != DEC_INSERT_WHOLE && c->dec.kind != DEC_INSERT_TRIMMED) {
     return 0.0;
   }
+  if (input_failed()) {
+    return 0.0;
+  }
   Batch fetched; // resident mode: one record read back from the file
   Rec fetched_rec{};
   if (st.resident) {
@@ -866,8 +869,11 @@ commit_sink(void* user, const gr_commit* c)
     while (got < n) {
       const ssize_t k = pread(st.fd, st.text.data() + got, n - got, (off_t)(l.off + got));
       if (k <= 0) {
-        std::cerr << "goldrush-path: cannot read the record back from " << run.opt.input << std::endl;
-        exit(1);
+        // not exit(1) from inside the commit callback (a streaming window may be parked on this thread's word,
+        // ADVICE r03): the failure is noted, this and the later records are not written, and the program ends with
+        // an error behind the pass
+        note_input_failure("cannot read the record back from " + run.opt.input);
+        return 0.0;
       }
       got += (size_t)k;
     }
@@ -971,6 +977,16 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     quiet.cerr_buf = std::cerr.rdbuf(quiet.null.rdbuf());
     quiet.cout_buf = std::cout.rdbuf(quiet.null.rdbuf());
   }
+  clear_input_failure();
+  // an input that could not be read to its end is an error, not a shorter input (gr_fastq.hpp): checked behind every pass
+  auto input_error = [] {
+    std::string what;
+    if (!input_failed(&what)) {
+      return false;
+    }
+    std::cerr << "ERROR: " << what << std::endl;
+    return true;
+  };
   int ec = process_options(opt, argc, argv);
   if (ec >= 0) {
     return ec;
@@ -1043,6 +1059,9 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     if (ec >= 0) {
       return ec;
     }
+    if (input_error()) {
+      return 1;
+    }
     opt.hash_universe = genome_size;
     filter_size = calc_optimal_size(opt.hash_universe, 1, opt.occupancy);
     if (run.vt.set_filter_size(run.ctx, filter_size) != GRP_OK) {
@@ -1091,6 +1110,9 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   ec = calc_min_phred_threshold(run);
   if (ec >= 0) {
     return ec;
+  }
+  if (input_error()) {
+    return 1;
   }
   std::cerr << "Calculating " << what << "\n"
             << "Using:\n"
@@ -1149,9 +1171,25 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   if (ec >= 0) {
     return ec;
   }
+  if (input_error()) {
+    return 1;
+  }
   uint64_t pop = 0;
   if (run.vt.finalize(run.ctx, &pop) != GRP_OK) {
     return run.fail_engine("building the rank structure");
+  }
+  if (run.world > 1 && run.shm) {
+    // every rank classifies on its own replica: they must hold the same filter (a merge that failed on one rank
+    // would otherwise only show as diverging decisions much later)
+    std::vector<uint64_t> one(8, pop), all((size_t)8 * run.world);
+    bool same = gr_shm_allgather(run.shm, one.data(), 64, all.data()) == 0;
+    for (uint32_t p = 0; p < run.world && same; ++p) {
+      same = all[(size_t)p * 8] == pop;
+    }
+    if (!same) {
+      std::cerr << "ERROR: the ranks' filters differ after the merge (rank " << run.rank << ": " << pop << " set bits)" << std::endl;
+      return 1;
+    }
   }
 
   std::cerr << "assigning tiles" << std::endl;
@@ -1311,8 +1349,11 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     }
     if (finished) {
       run.out.flush();
-      return 0; // exit(0) inside silver_path_check (:173-176)
+      return input_error() ? 1 : 0; // exit(0) inside silver_path_check (:173-176)
     }
+  }
+  if (input_error()) {
+    return 1;
   }
   if (opt.silver_path && opt.max_paths > cls.curr_path()) {
     std::cerr << "WARNING: Expected " << std::to_string(opt.max_paths) << " silver paths, but only " << std::to_string(cls.curr_path()) << " generated.\n"

@@ -143,12 +143,8 @@ def _run(oracle, native, reads, tile, k, h, m, block, window, key, verify=None):
     return stats, exp
 
 
-@pytest.mark.parametrize("window,verify", [(2, None), (7, None), (32, None), (200, None), (7, "check"), (32, "check"), (200, "check"), (7, "chain"), (32, "chain"), (200, "chain"),
-                                           (32, "check-nobitmap"), (200, "chain-nobitmap")])
-def test_batches_equal_the_serial_loop(oracle, native, window, verify, monkeypatch):
-    if verify and verify.endswith("-nobitmap"):  # tiles without records go through the log (k_query<.., VER> skipping the recorded tiles) instead of the bitmap of touched buckets
-        monkeypatch.setenv("GRP_BATCH_VERIFY_DF", "off")
-        verify = verify.split("-")[0]
+@pytest.mark.parametrize("window,verify", [(2, None), (7, None), (32, None), (200, None), (7, "check"), (32, "check"), (200, "check"), (7, "chain"), (32, "chain"), (200, "chain")])
+def test_batches_equal_the_serial_loop(oracle, native, window, verify):
     """A genome covered ~5x: the first reads insert, later ones are assigned or trimmed, so
     windows mix confirmed batches and batches taken back (a read that overlaps an earlier
     read of its own window decides differently once that read is in the filter)."""
