@@ -43,6 +43,7 @@ struct DevSeeds
   // number of care positions of the left part): the H hashes of a frame then share their halves
   // (grp_kernels.inc, seed_halves), 16 table look-ups per frame instead of 16 per seed.
   uint32_t n_left;
+  uint32_t wide; // 1: the longest span exceeds 32 bases (k + h - 1 <= 64): hashes read a 128-bit window (grp_kernels.inc, seed_hash)
   uint32_t weight[GRP_DEV_MAX_H];
   uint32_t span[GRP_DEV_MAX_H];
   uint32_t shift[GRP_DEV_MAX_H][GRP_DEV_MAX_W]; // 2*q for care position q

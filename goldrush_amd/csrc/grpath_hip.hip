@@ -203,7 +203,7 @@ struct grp_ctx
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
 
   // developer switches, read once at grp_create (not on every call of a latency path)
-  bool env_no_direct = false, env_stream_resume_off = false, env_no_early_park = false, env_trace_abort = false;
+  bool env_no_direct = false, env_stream_resume_off = false, env_no_early_park = false, env_trace_abort = false, env_sync_fr1 = false;
   uint64_t n_stream_idle_exits = 0, n_stream_coop_refused = 0; // parked windows that left by themselves (idle limit); resumable windows whose cooperative launch was refused
   uint64_t n_flagged_tiles = 0, n_flagged_distinct = 0, n_flagged_list = 0; // statistics: tiles redone with the worst-case table; why (distinct IDs / list length)
   uint64_t n_verify_tiles = 0, n_verify_queried = 0, n_verify_flagged = 0, n_verify_fallbacks = 0, n_verify_uncertified = 0, n_verify_unpatched = 0; // grp_batch_verify: tiles patched from records / queried again / patched tiles redone / calls that took the second query
@@ -445,7 +445,7 @@ size_t
 bases_bytes(uint32_t nbases)
 {
   // words covering nbases at any 16-base phase + 2 pad words, rounded to 16 B
-  size_t words = (nbases + 15u) / 16u + 1u + 2u;
+  size_t words = (nbases + 15u) / 16u + 1u + 4u;
   return ((words * 4u + 15u) / 16u) * 16u;
 }
 
@@ -457,6 +457,23 @@ ensure_lds(grp_ctx* c, K kernel, size_t bytes)
     HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   }
   return GRP_OK;
+}
+
+// k_decide's LDS work space: reads of more than 256 tiles (register forms above) up to DECIDE_LDS_MAX_TILES
+inline uint32_t
+decide_lds_tiles(const uint64_t* tile0, uint32_t count)
+{
+  uint64_t most = 0;
+  for (uint32_t i = 0; i < count; ++i) {
+    most = std::max(most, tile0[i + 1] - tile0[i]);
+  }
+  return most <= 4 * LANE_TILES ? 0u : (uint32_t)std::min<uint64_t>((most + 63) / 64 * 64, DECIDE_LDS_MAX_TILES);
+}
+
+inline size_t
+decide_lds_bytes(uint32_t lds_tiles)
+{
+  return (size_t)lds_tiles * DECIDE_LDS_BYTES_PER_TILE;
 }
 
 #define DISPATCH_H(hval, CALL)                                                                                         \
@@ -571,6 +588,13 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
   // up to h = 3; from h = 4 on one frame per lane with the software-pipelined pass (222 -> 171 VGPRs
   // at h = 5; C4 geometry +4 %, h = 3 -3 %: measured, tools/dev/r3_fr1.sh)
   constexpr int SFR = (HH <= 3) ? 2 : 1;
+  if constexpr (HH == 3) {
+    // measurement switch (GRP_SYNC_FR1, read at grp_create): the synchronous forms at h = 3 with one frame per lane and
+    // the software-pipelined pass, as at h >= 4 (round 3 measured -3 % with the 43 KB count table; 24 KB now)
+    if (c->env_sync_fr1 && !stream_ctl) {
+      return (c->view && !plain) ? go(k_query<3, 1, 0, false, true>) : go(k_query<3, 1, 0, false, false>);
+    }
+  }
   if (c->view && !stream_ctl && !plain) { // grp_batch_classify: every read sees the state in front of its own insert
     return go(k_query<HH, SFR, 0, false, true>);
   }
@@ -593,7 +617,14 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     // access rate, not by occupancy); 4 keeps the amount of work in flight — what an abort
     // throws away — small and leaves room on every CU for other kernels (copies, a
     // collective) beside the persistent launch
-    per_cu = std::min(per_cu, cap_per_cu > 0 ? cap_per_cu : 4);
+    // Round 4: THREE, not four.  With the 24 KB count table a fourth workgroup fits a CU by LDS and VGPRs (128: four
+    // waves per SIMD, every wave slot of the device), and the occupancy query — and hipLaunchCooperativeKernel — say
+    // so; but the launch then is NOT fully resident in practice (the kernel keeps 4 VGPRs in scratch, and the
+    // dispatcher admits fewer scratch waves than wave slots): on the C1 stream the grid-wide waits of the in-launch
+    // insert timed out (inserts handed back to the host: 243 k reads/s instead of 489 k, or code 2 with the
+    // cooperative launch), profiles/r04_c1_workgroups_per_cu.txt.  Rounds 1 - 3 ran three (the 43.6 KB table allowed
+    // no more); three leave a wave slot per SIMD free, and are as fast (C1 559 k reads/s in the steady state, two: 500 k).
+    per_cu = std::min(per_cu, cap_per_cu > 0 ? cap_per_cu : 3);
     const uint64_t resident = (uint64_t)std::max(per_cu, 1) * (uint64_t)std::max(c->n_cus, 1);
     n_launch = std::min<uint64_t>(n_launch, resident);
     return go(kern);
@@ -647,6 +678,12 @@ build_seed_tables(grp_ctx* c)
       c->uniform_weight = 0;
     }
   }
+  // spans beyond 32 bases (round 4): the generic hash reads a second 64-bit window; the unrolled weight-16 form and
+  // the shared halves are 32-base forms and stay off
+  sd.wide = (c->params.k + sd.h - 1 > 32) ? 1u : 0u;
+  if (sd.wide) {
+    c->uniform_weight = 0;
+  }
   // make_seed_pattern's family (spaced_seeds.cpp:58-66): seed i = left || "0" x i || right with
   // left = the first k/2 positions of seed 0.  The query kernel then evaluates the halves once per
   // frame (GRP_SHARED_HALVES=off: developer switch, every seed on its own as before).
@@ -663,7 +700,7 @@ build_seed_tables(grp_ctx* c)
     for (size_t q = 0; q < cut; ++q) {
       nl += s0[q] == '1';
     }
-    if (family && nl > 0 && nl < sd.weight[0]) {
+    if (family && nl > 0 && nl < sd.weight[0] && !sd.wide) {
       sd.n_left = nl;
     }
   }
@@ -732,6 +769,7 @@ grp_create(const grp_params* p, grp_ctx** out)
     c->env_no_direct = getenv("GRP_NO_DIRECT") != nullptr;
     c->env_no_early_park = getenv("GRP_NO_EARLY_PARK") != nullptr;
     c->env_trace_abort = getenv("GRP_TRACE_ABORT") != nullptr;
+    c->env_sync_fr1 = getenv("GRP_SYNC_FR1") != nullptr;
   }
   int rc = build_seed_tables(c);
   if (rc != GRP_OK) {
@@ -1677,7 +1715,12 @@ int
 classify_enqueue_decide(grp_ctx* c, QuerySlot& sl, hipStream_t st)
 {
   Timer t(c, GRP_K_DECIDE, sl.count, st);
-  k_decide<<<dim3(sl.count), dim3(DECIDE_THREADS), 0, st>>>(sl.reads->dev, sl.first, sl.count, sl.dp, sl.d_tiles, sl.d_lists, sl.list_cap, sl.d_dec_ids, sl.d_dec_asg, sl.d_dec_scratch, sl.d_dec);
+  const uint32_t lds_tiles = decide_lds_tiles(sl.reads->tile0.data() + sl.first, sl.count);
+  const size_t lds = decide_lds_bytes(lds_tiles);
+  if (const int rc = ensure_lds(c, k_decide, lds); rc != GRP_OK) {
+    return rc;
+  }
+  k_decide<<<dim3(sl.count), dim3(DECIDE_THREADS), lds, st>>>(sl.reads->dev, sl.first, sl.count, sl.dp, sl.d_tiles, sl.d_lists, sl.list_cap, sl.d_dec_ids, sl.d_dec_asg, sl.d_dec_scratch, sl.d_dec, lds_tiles);
   HIP_TRY(c, hipGetLastError());
   return GRP_OK;
 }
@@ -2723,7 +2766,9 @@ grp_debug_decide(grp_ctx* c, uint32_t n_reads, const uint64_t* tile0, const grp_
   DBG_TRY(hipMemset(d_asg, 0, std::max<uint64_t>(nt, 1)));
   DevReads rd{};
   rd.tile0 = d_tile0;
-  k_decide<<<dim3(n_reads), dim3(DECIDE_THREADS), 0, c->stream>>>(rd, 0, n_reads, *dp, d_tiles, d_lists, std::max<uint64_t>(n_lists, 1), d_ids, d_asg, d_scr, d_out);
+  const uint32_t lds_tiles = decide_lds_tiles(tile0, n_reads);
+  DBG_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_decide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)decide_lds_bytes(DECIDE_LDS_MAX_TILES)));
+  k_decide<<<dim3(n_reads), dim3(DECIDE_THREADS), decide_lds_bytes(lds_tiles), c->stream>>>(rd, 0, n_reads, *dp, d_tiles, d_lists, std::max<uint64_t>(n_lists, 1), d_ids, d_asg, d_scr, d_out, lds_tiles);
   DBG_TRY(hipGetLastError());
   DBG_TRY(hipStreamSynchronize(c->stream));
   DBG_TRY(hipMemcpy(out, d_out, n_reads * sizeof(grp_read_decision), hipMemcpyDeviceToHost));

@@ -114,6 +114,7 @@ Classifier::get_state(gr_classifier_state& s) const
   s.stream_inserts = n_stream_inserts_;
   s.stream_insert_fallbacks = n_stream_insert_fallbacks_;
   s.stream_relaunches = n_stream_relaunches_;
+  s.stream_handbacks = n_stream_handbacks_;
 }
 
 void
@@ -1465,7 +1466,12 @@ Classifier::stream_round(uint32_t& pos)
       }
     }
     d.pad = 0;
-    p_redo_ += (1.0 / 64.0) * ((d.kind == 0 ? 1.0 : 0.0) - p_redo_);
+    // (1 / 1024: a record handed back is priced as what it is over the last ~1000 reads.  With 1 / 64 a SINGLE read of
+    // more than 256 tiles — one in 70 000 with a realistic ONT length tail — made the streaming windows look 2.6 x as
+    // expensive as they are and the plan left them for ~45 synchronous windows: 146 such reads cost the C2 stream 5 s,
+    // bench.py --len-sigma 0.6, profiles/r04_long_tail.txt)
+    p_redo_ += (1.0 / 1024.0) * ((d.kind == 0 ? 1.0 : 0.0) - p_redo_);
+    n_stream_handbacks_ += d.kind == 0 ? 1 : 0;
     if (d.kind == 0) {
       redo = true; // needs the worst-case table / a larger arena: synchronous path below
       break;

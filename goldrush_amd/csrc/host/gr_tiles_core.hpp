@@ -21,7 +21,11 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define GR_HD __host__ __device__
+// always_inline: the device keeps the state of a read in REGISTERS (LaneState / LaneStateN, grp_kernels.inc), which only
+// works while every function below is inlined into the kernel — a call takes the state by reference, i.e. through
+// scratch memory (round 4: k_decide's four-tiles-per-lane form first compiled to 304 bytes of scratch and 1.7 ms per
+// decision launch)
+#define GR_HD __host__ __device__ __attribute__((always_inline))
 #else
 #define GR_HD
 #endif

@@ -60,7 +60,7 @@ typedef struct grp_reads grp_reads; /* a batch of packed reads resident in HBM *
 
 /* limits of this implementation (checked by grp_create) */
 #define GRP_MAX_SEEDS 8  /* -h */
-#define GRP_MAX_SPAN 32  /* k + h - 1 <= 32 bases (one 64-bit window) */
+#define GRP_MAX_SPAN 64  /* k + h - 1 <= 64 bases (round 4; up to 32: one 64-bit window of 2-bit bases, beyond: two) */
 
 typedef struct
 {

@@ -226,6 +226,8 @@ typedef struct
   /* round 4: inserts a parked window did not apply (applied the classic way; parked windows are tried again after 64
    * clean windows), windows begun again because their launch had left without deciding a read (idle limit) */
   uint64_t stream_insert_fallbacks, stream_relaunches;
+  uint64_t stream_handbacks; /* records a streaming window handed back to the synchronous path (kind 0: a read of more tiles than the
+                                in-launch decision holds, a tile that needed the worst-case table) */
 } gr_classifier_state;
 void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
 

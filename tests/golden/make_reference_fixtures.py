@@ -96,6 +96,25 @@ def make_funcs():
             for step in (0, 1):
                 ids, lists = ref_funcs.tiles_from_pattern(pat, step=step)
                 cases.append((ids, lists, 10))
+    # round 4: reads of 65 .. 300 tiles (the device decides them with two / four tiles per lane, beyond 256 in LDS; a realistic ONT length tail has 3 % of its reads there)
+    long_cases = []
+    rng_l = np.random.default_rng(20261005)
+    for n in (65, 100, 127, 128, 129, 200, 255, 256, 257, 300):
+        for rep in range(4):
+            ids, lists = ref_funcs.random_tiles(rng_l, n, wrap=(rep == 3))
+            long_cases.append((ids, lists, int(rng_l.choice([10, 10, 3, 11]))))
+    # the tail of the tail: k_decide's LDS state (257 .. 4096 tiles) and the global arrays behind it
+    for n, reps in ((700, 2), (4096, 1), (4100, 1)):
+        for rep in range(reps):
+            ids, lists = ref_funcs.random_tiles(rng_l, n, wrap=(rep == 1))
+            long_cases.append((ids, lists, 10))
+    out["tiles_long"] = []
+    for ids, lists, x in long_cases:
+        o_ids, o_b, na = rf.smooth_tiles(ids, lists, x)
+        ls, le = rf.find_longest_stretch(o_b)
+        good, ts, te = rf.eval_flanks(ls, le, o_ids)
+        out["tiles_long"].append({"x": x, "ids": ids, "lists": [[list(e) for e in l] for l in lists], "out_ids": [int(v) for v in o_ids], "out_bools": [int(v) for v in o_b],
+                                  "assigned": na, "stretch": [ls, le], "flanks": [int(good), ts, te]})
     for ids, lists, x in cases:
         o_ids, o_b, na = rf.smooth_tiles(ids, lists, x)
         ls, le = rf.find_longest_stretch(o_b)

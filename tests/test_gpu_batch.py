@@ -357,6 +357,64 @@ def test_batches_with_one_tile_id_blocks(oracle, native, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("entry", ["batch", "read", "stream"])
+def test_claim_loops_keep_every_touch(oracle, native, entry):
+    """The claim-loop rule of the insert kernels: every kernel that claims ranks
+    per seed — k_batch_collect [batch], k_insert_collect [read], the collect unit inside the streaming launch
+    [stream] — walks ONE seed per claim loop; a form that kept three seeds live across the loops lost ~10 % of the
+    third seed's touches once more than 256 workgroups were in flight.  Small enough for every run, large enough
+    for that: ~1000 tiles x 3 seeds x 4 workgroups of overlapping reads, every ID and count against the oracle."""
+    from goldrush_amd import synth
+
+    k, h, tile, block = 22, 3, 1000, 10
+    seeds = default_seeds(h)
+    g = synth.random_genome(400_000, 77)
+    reads = [r[1] for r in synth.make_reads(g, 44, mean_len=24000, min_len=18000, seed=78, max_len=40000)]
+    m = oracle.load().orc_calc_optimal_size(4_000_000, 1, 0.1)
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    omf = oracle.MiBF(m, oracle.Seeds(seeds), tile, k)
+    omf.bv_insert_reads(reads)
+    assert eng.finalize() == omf.finalize()
+    ins, next_id = [], 0
+    for ri, seq in enumerate(reads):
+        nt = len(seq) // tile
+        ins.append((ri, 0, nt, next_id + 1, 0))
+        for bs in range(0, nt, block):
+            omf.insert_read_tiles(seq, bs, min(bs + block, nt), next_id + 1 + bs // block)
+        next_id += 1 + len(seq) // (tile * block)
+    assert sum(i[2] for i in ins) * h * 4 > 10_000  # workgroups of the collect grids, all reads together
+    if entry == "batch":
+        eng.batch_insert_reads(b, ins, block, 0)
+        eng.batch_end()
+    elif entry == "read":
+        for (ri, a, e, fid, off) in ins:
+            eng.insert_read(b, ri, a, e, block, fid, off)
+    else:
+        # a resumable window whose every read is a whole-read insert record (no tile ever counts as assigned): the
+        # launch parks behind each, stream_insert is applied by its persistent workgroups (768 of them)
+        v = eng.stream_begin(b, 0, len(reads), 0, resumable=True, threshold=1 << 30, unassigned_min=1, assigned_max=1 << 30)
+        import time
+        gen = 1
+        for j, (ri, a, e, fid, off) in enumerate(ins):
+            t0 = time.time()
+            while int(v["pad"][j]) != gen:
+                assert time.time() - t0 < 60 and not eng.stream_poll(0)
+            assert int(v["kind"][j]) == 2 and int(v["num_tiles"][j]) == e
+            gen = eng.stream_insert(0, ri, a, e, block, fid, off)
+        t0 = time.time()
+        while not eng.stream_poll(0):
+            assert time.time() - t0 < 60
+        eng.stream_end(0)
+    ids, counts = eng.export_ids()
+    oi, oc = omf.ids(), omf.counts()
+    bad = np.flatnonzero((ids != oi) | (counts != oc))
+    assert bad.size == 0, (entry, bad.size, bad[:10], ids[bad[:10]], oi[bad[:10]], counts[bad[:10]], oc[bad[:10]])
+    assert int((counts > 1).sum()) > 1_000
+    eng.close()
+
+
 @pytest.mark.parametrize("collect3", [None])
 def test_large_batch_at_c2_filter_size_against_the_oracle(oracle, native, collect3, monkeypatch):
     """ONE batch of 200 whole-read inserts on C2's own filter (m = 61 146 729 472:

@@ -222,11 +222,66 @@ def test_other_geometries(oracle, native, h, tile):
             ti += 1
 
 
+def _symmetric_seed(k, weight, seed):
+    """A palindromic care pattern of span k (ends are care positions), like the reference's designed seeds."""
+    rng = np.random.default_rng(seed)
+    half = k // 2
+    left = np.zeros(half, dtype=bool)
+    left[0] = True
+    left[rng.choice(np.arange(1, half), size=max(weight // 2 - 1, 0), replace=False)] = True
+    s = "".join("1" if b else "0" for b in left)
+    return s + ("1" if k % 2 else "") + s[::-1]
+
+
+@pytest.mark.parametrize("k,h,tile", [(31, 3, 400), (32, 1, 300), (33, 2, 400), (40, 3, 500), (48, 5, 700), (62, 3, 400), (64, 1, 1000)])
+def test_spans_beyond_one_window(oracle, native, k, h, tile):
+    """k + h - 1 up to 64 bases: the frames of seeds wider than 32 bases are hashed from two
+    64-bit windows of 2-bit bases.  Hashes, fill, inserts and queries against the oracle, bit for bit."""
+    base = _symmetric_seed(k, min(k // 2 * 2 - 2, 24), 7 + k)
+    seeds = default_seeds(h, base)
+    assert all(len(sd) == k + i for i, sd in enumerate(seeds)) and len(seeds[-1]) <= 64
+    m = oracle.load().orc_calc_optimal_size(300_000, 1, 0.1)
+    eng = native.Engine(k, h, tile, m, seeds)
+    oseeds = oracle.Seeds(seeds)
+    omf = oracle.MiBF(m, oseeds, tile, k)
+    reads = random_reads(5, 2 * tile, 6 * tile + 70, seed=151 + k)
+    reads += [reads[0][: 3 * tile // 2 + k - 2], reads[1][: 2 * tile + k + h - 2], b"ACGT" * (tile // 2), reads[2][: tile + 3]]
+    b = eng.upload(reads)
+    for ri, seq in enumerate(reads):
+        for t in range(len(seq) // tile):
+            assert np.array_equal(eng.tile_hashes(b, ri, t), oseeds.tile_hashes(seq, tile, k, t)), (ri, t)
+    eng.bv_insert(b)
+    for sq in reads:
+        omf.bv_insert_read(sq)
+    assert eng.finalize() == omf.finalize()
+    assert np.array_equal(eng.export_bits(), omf.bits())
+    for ri in (0, 2, 5):
+        nt = len(reads[ri]) // tile
+        eng.insert_tiles(b, ri, 0, nt, ri + 1)
+        omf.insert_read_tiles(reads[ri], 0, nt, ri + 1)
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts())
+    _compare_queries(eng, omf, b, reads)
+    # the classification window (hash + query + decisions in one call) against the host decision on the queried tiles
+    from goldrush_amd import host
+    dp = dict(threshold=2, unassigned_min=2, assigned_max=1 << 30)
+    dec = eng.classify_reads(b, 0, len(reads), **dp)
+    tiles, lists, _ = eng.query_tiles(b)
+    lists_arr = np.ascontiguousarray(lists) if len(lists) else np.zeros(1, dtype=native.id_count_dtype)
+    for ri in range(len(reads)):
+        a0, e0 = int(b.tile0[ri]), int(b.tile0[ri + 1])
+        t = np.ascontiguousarray(tiles[a0:e0]) if e0 > a0 else np.zeros(1, dtype=native.tile_summary_dtype)
+        d = host.decide_read(t, lists_arr, e0 - a0, **dp)
+        got = dec[ri]
+        assert (int(got["kind"]), int(got["num_tiles"]), int(got["num_assigned"]), int(got["hits"]), int(got["misses"])) == (d.kind, d.num_tiles, d.num_assigned, d.hits, d.misses), ri
+    eng.close()
+
+
 def test_errors_are_loud(native):
     with pytest.raises(native.GrpError):
         native.Engine(22, 3, 10, 1 << 20, default_seeds(3))  # tile shorter than the seeds
     with pytest.raises(native.GrpError):
-        native.Engine(40, 3, 1000, 1 << 20, ["1" * 40, "1" * 41, "1" * 42])  # span > 32
+        native.Engine(63, 3, 1000, 1 << 20, ["1" * 63, "1" * 64, "1" * 65])  # span k + h - 1 > 64
     eng = native.Engine(22, 3, 1000, 1 << 20, default_seeds(3))
     b = eng.upload([b"ACGT" * 600])
     with pytest.raises(native.GrpError):

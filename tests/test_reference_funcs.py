@@ -73,9 +73,9 @@ def _check_case(oracle, host, ids, lists, x, out_ids, out_bools, na, stretch, fl
 
 
 def test_smoothing_stretch_flanks_match_the_reference(gold, oracle, host):
-    assert len(gold["tiles"]) >= 600
+    assert len(gold["tiles"]) >= 600 and len(gold["tiles_long"]) >= 44
     kinds = set()
-    for c in gold["tiles"]:
+    for c in gold["tiles"] + gold["tiles_long"]:
         _check_case(oracle, host, c["ids"], _lists(c), c["x"], c["out_ids"], c["out_bools"], c["assigned"], c["stretch"], c["flanks"])
         kinds.add(_decision(len(c["ids"]), c["assigned"], lambda: (bool(c["flanks"][0]), c["flanks"][1], c["flanks"][2]))[0])
     assert kinds == {2, 3, 4, 5}
@@ -148,7 +148,7 @@ def test_fixture_is_what_the_reference_computes_now(gold, oracle, host):
         _check_case(oracle, host, ids, lists, x, [int(v) for v in o_ids], [int(v) for v in o_b], na, list(st), [int(fl[0]), fl[1], fl[2]])
 
     for i in range(4000):
-        n = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 14, 15, 16, 20, 25, 31, 60, 90]))
+        n = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 12, 14, 15, 16, 20, 25, 31, 60, 90, 128, 129, 260] + ([700] if i % 40 == 0 else [])))
         ids, lists = ref_funcs.random_tiles(rng, n, wrap=(i % 11 == 0))
         live(ids, lists, int(rng.choice([10, 10, 10, 3, 11, 0, 400])))
     for n in (3, 4, 5, 7, 14, 15, 16, 17, 30):
@@ -167,8 +167,9 @@ def test_device_decision_kernel_matches_the_reference(gold, native):
     from helpers import default_seeds
 
     eng = native.Engine(22, 3, 1000, 64 * 1024, default_seeds(3))
-    for x in sorted({c["x"] for c in gold["tiles"]}):
-        cases = [c for c in gold["tiles"] if c["x"] == x]
+    all_cases = gold["tiles"] + gold["tiles_long"]  # the long ones: 65 .. 256 tiles — two / four tiles per lane; .. 4096 — LDS state; 4100 — global arrays
+    for x in sorted({c["x"] for c in all_cases}):
+        cases = [c for c in all_cases if c["x"] == x]
         # a 70-tile and a 300-tile read made of fixture states glued together would change the result; the long
         # forms are exercised by tests/test_gpu_classifier.py — here every fixture state is one read
         tile0 = np.zeros(len(cases) + 1, dtype=np.uint64)
