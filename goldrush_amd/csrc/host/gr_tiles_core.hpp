@@ -108,6 +108,24 @@ struct PtrState
     }
     return c;
   }
+  // P7's work list: scratch[0 .. ne) = id << 32 | index of the assigned tiles, ascending; returns ne.
+  // Insertion sort (indices arrive ascending).
+  GR_HD size_t sort_assigned(size_t n)
+  {
+    size_t ne = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (flags[i]) {
+        const uint64_t key = ((uint64_t)ids[i] << 32) | (uint64_t)i;
+        size_t j = ne++;
+        while (j > 0 && scratch[j - 1] > key) {
+          scratch[j] = scratch[j - 1];
+          --j;
+        }
+        scratch[j] = key;
+      }
+    }
+    return ne;
+  }
   GR_HD void sum_hits_misses(size_t n, uint32_t& h, uint32_t& m) const
   {
     h = 0;
@@ -272,19 +290,10 @@ smooth(size_t n, size_t x, S& s)
     // P7 (:799-822): per ID in ascending order (std::map), between two
     // non-adjacent assigned occurrences every tile gets the ID found at the
     // earlier occurrence *at that moment* (earlier groups may have rewritten it).
-    // scratch[e] = id<<32 | idx, insertion-sorted (indices arrive ascending).
-    size_t ne = 0;
-    for (size_t i = 0; assigned_1_7 && i < n; ++i) {
-      if (s.asg(i)) {
-        const uint64_t key = ((uint64_t)s.id(i) << 32) | (uint64_t)i;
-        size_t j = ne++;
-        while (j > 0 && s.scr(j - 1) > key) {
-          s.set_scr(j, s.scr(j - 1));
-          --j;
-        }
-        s.set_scr(j, key);
-      }
-    }
+    // scratch[e] = id<<32 | idx, sorted ascending (State::sort_assigned; the keys are distinct).
+    // (the device states sort with the whole wave: the insertion sort is quadratic for a read on the other
+    // strand — IDs falling along the read — and was most of a long read's decision time, round 4)
+    const size_t ne = assigned_1_7 ? s.sort_assigned(n) : 0;
     for (size_t g = 1; g < ne; ++g) {
       const uint64_t e0 = s.scr(g - 1), e1 = s.scr(g);
       if ((e1 >> 32) != (e0 >> 32)) {

@@ -394,15 +394,31 @@ def test_claim_loops_keep_every_touch(oracle, native, entry):
     else:
         # a resumable window whose every read is a whole-read insert record (no tile ever counts as assigned): the
         # launch parks behind each, stream_insert is applied by its persistent workgroups (768 of them)
-        v = eng.stream_begin(b, 0, len(reads), 0, resumable=True, threshold=1 << 30, unassigned_min=1, assigned_max=1 << 30)
         import time
-        gen = 1
-        for j, (ri, a, e, fid, off) in enumerate(ins):
+        dp = dict(threshold=1 << 30, unassigned_min=1, assigned_max=1 << 30)
+        first, gen, restarts, applied = 0, 1, 0, 0
+        v = eng.stream_begin(b, 0, len(reads), 0, resumable=True, **dp)
+        j = 0
+        while j < len(ins):
+            ri, a, e, fid, off = ins[j]
             t0 = time.time()
-            while int(v["pad"][j]) != gen:
+            while int(v["pad"][j - first]) != gen:
                 assert time.time() - t0 < 60 and not eng.stream_poll(0)
-            assert int(v["kind"][j]) == 2 and int(v["num_tiles"][j]) == e
+            if int(v["kind"][j - first]) == 0:
+                # handed back (the window's list arena is used up by the tiles queried again behind every insert):
+                # the product takes such a read through the synchronous path; here a new window starts at it
+                eng.stream_abort(0)
+                eng.stream_end(0)
+                restarts += 1
+                assert restarts < 20
+                first, gen = j, 1
+                v = eng.stream_begin(b, j, len(reads) - j, 0, resumable=True, **dp)
+                continue
+            assert int(v["kind"][j - first]) == 2 and int(v["num_tiles"][j - first]) == e
             gen = eng.stream_insert(0, ri, a, e, block, fid, off)
+            applied += 1
+            j += 1
+        assert applied == len(ins)
         t0 = time.time()
         while not eng.stream_poll(0):
             assert time.time() - t0 < 60

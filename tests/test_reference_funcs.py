@@ -241,3 +241,97 @@ def test_device_vote_matches_the_reference_statements(native, oracle):
                 ti += 1
         assert ti == len(tiles)
         eng.close()
+
+
+def _strand_states(rng, sizes):
+    """Tile states of reads that overlap earlier reads: long runs of assigned tiles whose IDs rise (same strand) or
+    FALL (other strand) along the read, in steps of 0 / 1 (ID blocks of `block` tiles), broken by unassigned
+    tiles, foreign IDs and repeats of an earlier ID (P7's work) — the worst case of P7's sort is the falling run."""
+    out = []
+    for n in sizes:
+        for direction in (1, -1):
+            ids, lists = [], []
+            cur = int(rng.integers(5000, 9000))
+            for i in range(n):
+                r = rng.random()
+                if r < 0.08:       # an unassigned tile with a weak vote
+                    tid = int(rng.integers(1, 20000))
+                    ids.append(tid)
+                    lists.append([] if rng.random() < 0.5 else [(tid, int(rng.integers(3, 9)))])
+                    continue
+                if r < 0.12:       # a foreign ID with a strong vote
+                    tid = int(rng.integers(1, 20000))
+                    ids.append(tid)
+                    lists.append([(tid, int(rng.integers(11, 60)))])
+                    continue
+                if r < 0.16 and i > 10:  # an earlier ID again (two non-adjacent occurrences)
+                    tid = ids[int(rng.integers(0, i - 5))]
+                    ids.append(tid)
+                    lists.append([(tid, int(rng.integers(11, 60)))])
+                    continue
+                if rng.random() < 0.45:
+                    cur += direction
+                ids.append(cur)
+                l = [(cur, int(rng.integers(9, 200)))]
+                if rng.random() < 0.3:
+                    l.append((cur - direction, int(rng.integers(3, l[0][1] + 1))))
+                l.sort(key=lambda t: (-t[1], t[0]))
+                lists.append(l)
+            out.append((ids, lists, 10))
+    return out
+
+
+def test_strand_states_host_core_against_the_reference_live(oracle):
+    """Rising / falling ID runs (reads on either strand over earlier reads), 20 .. 700 tiles: the shared decision core
+    (host build; the device builds the same template around its own states) against the reference's lines."""
+    from goldrush_amd import host
+
+    if not os.path.exists(ref_funcs.LIB):
+        pytest.skip("oracle/_ref not built here")
+    rf = ref_funcs.RefFuncs()
+    rng = np.random.default_rng(414)
+    for ids, lists, x in _strand_states(rng, [20, 40, 64, 65, 100, 128, 200, 256, 300, 700]):
+        o_ids, o_b, na = rf.smooth_tiles(ids, lists, x)
+        st = rf.find_longest_stretch(o_b)
+        fl = rf.eval_flanks(st[0], st[1], o_ids)
+        _check_case(oracle, host, ids, lists, x, [int(v) for v in o_ids], [int(v) for v in o_b], na, list(st), [int(fl[0]), fl[1], fl[2]])
+
+
+@pytest.mark.gpu
+def test_device_decisions_of_strand_states(native):
+    """k_decide in all its forms — tile per lane (<= 64 tiles), two / four tiles per lane (.. 256), LDS state walked
+    by the wave (.. 4096), global arrays — on rising / falling ID runs: per-tile IDs and flags, assigned count and
+    decision against the host build of the same core, which the CPU suite pins to the reference's own lines
+    (test_strand_states_host_core_against_the_reference_live, the fixtures).  P7's wave-parallel sort is the point."""
+    from goldrush_amd import host
+    from helpers import default_seeds
+
+    eng = native.Engine(22, 3, 1000, 64 * 1024, default_seeds(3))
+    rng = np.random.default_rng(414)
+    cases = _strand_states(rng, [20, 40, 64, 65, 100, 128, 200, 256, 300, 700])
+    cases += _strand_states(np.random.default_rng(415), [3, 5, 17, 63, 129, 255, 257, 1100, 4096, 4200])
+    tile0 = np.zeros(len(cases) + 1, dtype=np.uint64)
+    all_tiles, all_lists, per = [], [], []
+    for i, (ids, lists, x) in enumerate(cases):
+        tiles, flat = host.tiles_from(ids, lists)
+        per.append((tiles[: len(ids)].copy(), flat))
+        tiles = tiles[: len(ids)].copy()
+        tiles["list_off"] += len(all_lists)
+        all_tiles.extend(tiles.tolist())
+        all_lists.extend(flat[: sum(len(l) for l in lists)].tolist())
+        tile0[i + 1] = tile0[i] + len(ids)
+    tiles = np.array(all_tiles, dtype=native.tile_summary_dtype)
+    lists = np.array(all_lists, dtype=native.id_count_dtype)
+    dec, ids_out, asg_out = eng.debug_decide(tile0, tiles, lists, threshold=10)
+    kinds = set()
+    for i, (ids, lsts, x) in enumerate(cases):
+        a, b = int(tile0[i]), int(tile0[i + 1])
+        t, fl = per[i]
+        h_ids, h_b, na = host.smooth_tiles(t, fl, b - a, 10)
+        assert np.array_equal(ids_out[a:b], h_ids) and np.array_equal(asg_out[a:b], h_b), (i, b - a)
+        d = host.decide_read(t, fl, b - a, threshold=10)
+        got = dec[i]
+        assert (int(got["kind"]), int(got["num_tiles"]), int(got["num_assigned"]), int(got["trim_start"]), int(got["trim_end"])) == (d.kind, d.num_tiles, d.num_assigned, d.trim_start, d.trim_end), (i, b - a)
+        kinds.add(int(got["kind"]))
+    assert len(kinds) >= 2, kinds
+    eng.close()
