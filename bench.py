@@ -687,6 +687,7 @@ def main():
             # reset; not the headline (BASELINE's metric is the golden-path stream above).
             eng.reset_ids()
             eng.sync()
+            eng.reset_kernel_stats()
             scls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h,
                                    target_bases=int(0.9 * G), max_paths=5, silver_path=True, max_window=a.max_window, record=False)
             t_s0 = time.perf_counter()
@@ -705,7 +706,9 @@ def main():
                 "what": "the pipeline's first goldrush-path process on these reads: --silver_path -M 5 -r 0.9 (bin/goldrush:253-260), same filter, ID arrays reset; the run ends behind the fifth path",
                 "reads_consumed": int(sst["reads_committed"]), "seconds": t_s, "reads_per_s": sst["reads_committed"] / t_s if t_s > 0 else None,
                 "inserts": int(sst["inserts"]), "paths_completed": int(sst["curr_path"]) - 1 if s_fin else int(sst["curr_path"]) - 1, "finished": bool(s_fin),
-                "batches": int(sst["batches"]), "batches_undone": int(sst["batches_undone"]), "reads_queried": int(sst["reads_queried"])}
+                "batches": int(sst["batches"]), "batches_undone": int(sst["batches_undone"]), "reads_queried": int(sst["reads_queried"]),
+                "stream_inserts": int(sst["stream_inserts"]), "stream_rollovers": int(sst["stream_rollovers"]),
+                "kernel_stats": {k_: v_ for k_, v_ in eng.kernel_stats().items() if v_["launches"]}}  # of this pass alone (HIP events, summed ms)
             del scls
         print(json.dumps(out), flush=True)
     if world > 1:

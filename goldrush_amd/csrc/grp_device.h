@@ -21,8 +21,11 @@
 //   ~6 set bits on average; the rare bucket with more than 13 set bits keeps the
 //   IDs of its 14th.. set bits in a small open-addressing table keyed by rank.
 //   super[n_super]   uint64  absolute ones before each superbucket (2^22 buckets)
-//   counts[pop]      uint32  insert counts (MIBFConstructSupport m_counts, :338),
-//                            indexed by global rank; touched by inserts only
+//   counts[pop]      uint64  bits 0..27: insert count (MIBFConstructSupport m_counts, :338), indexed by
+//                            global rank; touched by inserts only.  Round 4: bits 28..37 the epoch of the
+//                            batch that claimed the rank last, bits 38..63 the claiming record of that batch
+//                            (grp_batch.inc: the claim of the collect pass and the count share one word — one
+//                            random line per record instead of two; a count that would not fit 28 bits traps)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,7 +59,7 @@ struct DevFilter
   uint32_t* bv;                 // phase 1
   uint4* buckets;               // phase 2: 4 x uint4 per bucket
   const uint64_t* super;
-  uint32_t* counts;
+  unsigned long long* counts;   // per rank: insert count | batch epoch | claiming record (grp_cnt, grp_claim_* below)
   unsigned long long* ovf_keys; // rank + 1, 0 = empty
   uint32_t* ovf_ids;
   uint64_t ovf_mask;
@@ -68,6 +71,45 @@ struct DevFilter
   uint32_t W;       // filter bits per bucket (13..64)
   uint32_t pad;
 };
+
+constexpr unsigned long long GRP_CNT_MASK = (1ull << 28) - 1ull;
+constexpr uint32_t GRP_EPOCH_MAX = (1u << 10) - 1u; // epochs 1 .. 1023, 0: never claimed
+
+__host__ __device__ inline uint32_t
+grp_cnt(unsigned long long w)
+{
+  return (uint32_t)(w & GRP_CNT_MASK);
+}
+
+// the word with its count replaced (epoch and claim kept)
+__host__ __device__ inline unsigned long long
+grp_cnt_with(unsigned long long w, uint32_t count)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (count > (uint32_t)GRP_CNT_MASK) {
+    __builtin_trap(); // 2^28 inserts on one rank: fail loudly rather than wrap
+  }
+#endif
+  return (w & ~GRP_CNT_MASK) | (unsigned long long)count;
+}
+
+__host__ __device__ inline uint32_t
+grp_claim_epoch(unsigned long long w)
+{
+  return (uint32_t)(w >> 28) & GRP_EPOCH_MAX;
+}
+
+__host__ __device__ inline uint32_t
+grp_claim_record(unsigned long long w)
+{
+  return (uint32_t)(w >> 38);
+}
+
+__host__ __device__ inline unsigned long long
+grp_claim_word(uint32_t record, uint32_t epoch, uint32_t count)
+{
+  return ((unsigned long long)record << 38) | ((unsigned long long)epoch << 28) | (unsigned long long)count;
+}
 
 struct DevReads
 {

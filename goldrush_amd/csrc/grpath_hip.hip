@@ -117,7 +117,7 @@ struct BatchRun
   uint32_t* d_counters = nullptr;
   uint32_t* d_ins = nullptr;
   uint64_t ins_cap = 0;
-  unsigned long long* d_keys = nullptr; // collect: rank -> owner's record (zeroed behind every collect pass)
+  uint32_t epoch = 0; // of the current / last batch: the claim field of the count words (grp_device.h), 1 .. GRP_EPOCH_MAX
   uint64_t tab_cap = 0, cur_cap = 0;    // allocated slots / slots the current batch uses (both tables)
   unsigned long long* d_rec_key = nullptr; // records, one per (frame, seed) of the inserted tiles
   unsigned long long* d_rec_loc = nullptr;
@@ -204,6 +204,7 @@ struct grp_ctx
 
   // developer switches, read once at grp_create (not on every call of a latency path)
   bool env_no_direct = false, env_stream_resume_off = false, env_no_early_park = false, env_trace_abort = false, env_sync_fr1 = false;
+  uint64_t n_batch_sweeps = 0; // times the batch epochs wrapped and the claims were swept out of the count words
   uint64_t n_stream_idle_exits = 0, n_stream_coop_refused = 0; // parked windows that left by themselves (idle limit); resumable windows whose cooperative launch was refused
   uint64_t n_flagged_tiles = 0, n_flagged_distinct = 0, n_flagged_list = 0; // statistics: tiles redone with the worst-case table; why (distinct IDs / list length)
   uint64_t n_verify_tiles = 0, n_verify_queried = 0, n_verify_flagged = 0, n_verify_fallbacks = 0, n_verify_uncertified = 0, n_verify_unpatched = 0; // grp_batch_verify: tiles patched from records / queried again / patched tiles redone / calls that took the second query
@@ -941,7 +942,6 @@ grp_destroy(grp_ctx* c)
     BatchRun& b = c->batch;
     (void)hipFree(b.d_counters);
     (void)hipFree(b.d_ins);
-    (void)hipFree(b.d_keys);
     (void)hipFree(b.d_rec_key);
     (void)hipFree(b.d_rec_loc);
     (void)hipFree(b.d_rec_old);
@@ -1368,11 +1368,11 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
   (void)hipFree(c->f.bv); // the bits now live in the buckets
   c->f.bv = nullptr;
   c->f.pop = h_pop;
-  e = hipMalloc(&c->f.counts, std::max<uint64_t>(h_pop, 1) * sizeof(uint32_t));
+  e = hipMalloc(&c->f.counts, std::max<uint64_t>(h_pop, 1) * sizeof(unsigned long long));
   if (e != hipSuccess) {
     return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu insert counts failed: %s", (unsigned long long)h_pop, hipGetErrorString(e));
   }
-  HIP_TRY(c, hipMemsetAsync(c->f.counts, 0, std::max<uint64_t>(h_pop, 1) * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->f.counts, 0, std::max<uint64_t>(h_pop, 1) * sizeof(unsigned long long), c->stream));
   const uint64_t ovf_cap = next_pow2_64(std::max<uint64_t>(2 * h_scalars[2], 1024));
   HIP_TRY(c, hipMalloc(&c->f.ovf_keys, ovf_cap * sizeof(unsigned long long)));
   HIP_TRY(c, hipMalloc(&c->f.ovf_ids, ovf_cap * sizeof(uint32_t)));
@@ -2495,7 +2495,8 @@ grp_reset_ids(grp_ctx* c)
   HIP_TRY(c, hipSetDevice(c->device));
   k_reset_bucket_ids<<<dim3(65536), dim3(THREADS), 0, c->stream>>>(c->f.buckets, c->f.n_buckets);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemsetAsync(c->f.counts, 0, std::max<uint64_t>(c->f.pop, 1) * sizeof(uint32_t), c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->f.counts, 0, std::max<uint64_t>(c->f.pop, 1) * sizeof(unsigned long long), c->stream));
+  c->batch.epoch = 0; // (the claims are gone with the counts)
   HIP_TRY(c, hipMemsetAsync(c->f.ovf_keys, 0, (c->f.ovf_mask + 1) * sizeof(unsigned long long), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->f.ovf_ids, 0, (c->f.ovf_mask + 1) * sizeof(uint32_t), c->stream));
   return GRP_OK;

@@ -115,6 +115,7 @@ Classifier::get_state(gr_classifier_state& s) const
   s.stream_insert_fallbacks = n_stream_insert_fallbacks_;
   s.stream_relaunches = n_stream_relaunches_;
   s.stream_handbacks = n_stream_handbacks_;
+  s.stream_rollovers = n_stream_rollovers_;
 }
 
 void
@@ -314,9 +315,9 @@ Classifier::launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, 
   S = clamp_tiles(pos, S, 1ull << 30);
   const grp_decide_params dp{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
   const gr_read_decision* dec = nullptr;
-  // One rank, golden-path mode: a window that waits where it parks and applies the insert the
-  // host commits inside its own launch (stream_round); a silver-path run resets the ID array
-  // at a rollover, several ranks share a window in stripes: those windows end where they park.
+  // One rank: a window that waits where it parks and applies the insert the host commits inside its own
+  // launch (stream_round; a silver-path run resets the ID array at a rollover: commit() ends the launches in
+  // front of that insert); several ranks share a window in stripes: those windows end where they park.
   const bool resumable = can_resume();
   int rc = resumable ? vt_.stream_begin_resumable(ctx_, reads, base_ + pos, S, &dp, slot, &dec) : vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, stripe_reads(), p_.world, p_.rank, &dec);
   if (rc != GRP_OK) {
@@ -629,7 +630,9 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
   };
 
   // all ID blocks of the read in one engine call (same result as the block loop)
-  auto insert_read = [&](uint32_t ts, uint32_t te_excl, uint32_t id_offset) {
+  // `bases`: what the insert adds to the path (silver mode: the host knows in front of the insert whether the path
+  // rolls over behind it, :156-187 — the ID array is reset there, a parked window has nothing to carry on with)
+  auto insert_read = [&](uint32_t ts, uint32_t te_excl, uint32_t id_offset, uint64_t bases) {
     if (engine_inserted) {
       // the commit loop on the device allocated the same ID from the same counter
       if (engine_first_id != ids_inserted_) {
@@ -643,7 +646,11 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       // insert itself and carries on behind the read (no launch boundary)
       StreamFlight& f = *stream_ins_;
       uint32_t gen = 0;
-      if (vt_.stream_insert(ctx_, f.slot, base_ + r, ts, te_excl, block, ids_inserted_, id_offset, &gen) == GRP_OK) {
+      const bool rolls_over = p_.silver_path && p_.target_bases < inserted_bases_ + bases;
+      if (rolls_over) {
+        ++n_stream_rollovers_;
+      }
+      if (!rolls_over && vt_.stream_insert(ctx_, f.slot, base_ + r, ts, te_excl, block, ids_inserted_, id_offset, &gen) == GRP_OK) {
         f.gen = gen;
         f.ins_posted = true;
         f.ins_read = base_ + r;
@@ -677,7 +684,7 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       ++ids_inserted_;
       ev.first_id = ids_inserted_;
       if (vt_.insert_read || engine_inserted) {
-        insert_read(0, nt, 0);
+        insert_read(0, nt, 0, len);
       } else {
         for (uint32_t bs = 0; bs < nt; bs += block) {
           insert_block(bs, std::min(bs + block, nt), ids_inserted_ + (uint32_t)(bs / block));
@@ -707,8 +714,14 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       const uint32_t ts = d.trim_start, te = d.trim_end;
       ++ids_inserted_;
       ev.first_id = ids_inserted_;
+      // new_seq = seq.substr(ts*tile, te == nt-1 ? npos : (te-ts+1)*tile)
+      const uint64_t off = (uint64_t)ts * tile;
+      uint64_t n_out = len - off;
+      if (te != nt - 1) {
+        n_out = std::min<uint64_t>(n_out, (uint64_t)(te - ts + 1) * tile);
+      }
       if (vt_.insert_read || engine_inserted) {
-        insert_read(ts, te + 1, 1);
+        insert_read(ts, te + 1, 1, n_out);
       } else {
         for (uint64_t bs = ts; bs <= te; bs += block) {
           const uint64_t be = std::min<uint64_t>(bs + block - 1, te);
@@ -722,12 +735,6 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
       // last of them, nothing is shared (the rule used to be (te - ts + 1) % block == 0,
       // exact but needlessly wide — every probe with ID == floor then took the slow look-up)
       last_insert_shares_id_ = block == 1;
-      // new_seq = seq.substr(ts*tile, te == nt-1 ? npos : (te-ts+1)*tile)
-      const uint64_t off = (uint64_t)ts * tile;
-      uint64_t n_out = len - off;
-      if (te != nt - 1) {
-        n_out = std::min<uint64_t>(n_out, (uint64_t)(te - ts + 1) * tile);
-      }
       inserted_bases_ += n_out;
       const double ph = emit_commit(ev);
       ++num_reads_in_path_;
@@ -920,11 +927,12 @@ Classifier::want_batch() const
   return p_insert_mid_ >= (in_batch_ ? p_out : p_in);
 }
 
-// one rank, golden-path mode, an engine with the entry points: streaming windows apply inserts inside their launch
+// one rank, an engine with the entry points: streaming windows apply inserts inside their launch (round 4: in silver
+// mode too — the insert behind which the path rolls over is known to the host in front of it and ends the launches)
 bool
 Classifier::can_resume() const
 {
-  return vt_.stream_begin_resumable && vt_.stream_insert && vt_.insert_read && p_.world == 1 && !p_.silver_path && !resume_disabled_;
+  return vt_.stream_begin_resumable && vt_.stream_insert && vt_.insert_read && p_.world == 1 && !resume_disabled_;
 }
 
 // The size of the next batch.  A read decides differently in a batch when it overlaps a read
@@ -1478,8 +1486,8 @@ Classifier::stream_round(uint32_t& pos)
     }
     bool resume = false;
     if (d.kind == DEC_INSERT_WHOLE || d.kind == DEC_INSERT_TRIMMED) {
-      // One rank, golden-path mode: the parked launch applies the insert itself and carries on
-      // behind the read (commit() hands it over).  Otherwise everything behind this read is
+      // One rank: the parked launch applies the insert itself and carries on behind the read
+      // (commit() hands it over).  Otherwise everything behind this read is
       // stale: stop the launches before the insert is queued.
       resume = scur_.resumable;
       if (resume) {

@@ -155,6 +155,7 @@ private:
   uint64_t n_stream_inserts_ = 0;
   uint32_t resume_clean_windows_ = 0;  // windows ended without a refused insert since resume_disabled_ was set (64: tried again)
   uint64_t n_stream_insert_fallbacks_ = 0, n_stream_relaunches_ = 0, n_stream_handbacks_ = 0;
+  uint64_t n_stream_rollovers_ = 0; // silver mode: inserts kept out of a parked launch because the path rolls over behind them
   uint64_t lost_at_ = UINT64_MAX;      // read at which a window was last begun again because its launch had left without deciding it
   uint32_t group_base_ = UINT32_MAX; // first read of the stripe group held in stripe_recv_
 

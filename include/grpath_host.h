@@ -228,6 +228,7 @@ typedef struct
   uint64_t stream_insert_fallbacks, stream_relaunches;
   uint64_t stream_handbacks; /* records a streaming window handed back to the synchronous path (kind 0: a read of more tiles than the
                                 in-launch decision holds, a tile that needed the worst-case table) */
+  uint64_t stream_rollovers; /* silver mode (round 4): inserts a parked window did not apply itself because the silver path rolls over behind them (the ID array is reset: the launches end there) */
 } gr_classifier_state;
 void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
 

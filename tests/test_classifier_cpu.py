@@ -166,6 +166,34 @@ def test_streaming_windows_apply_inserts_themselves(oracle, native, max_window, 
     assert cls.state()["reads_committed"] == len(exp)
 
 
+@pytest.mark.parametrize("max_window", [4096, 32])
+def test_streaming_windows_apply_inserts_in_silver_mode(oracle, native, max_window, monkeypatch):
+    """Round 4: in silver mode too the parked window applies the host's inserts itself; the insert
+    behind which the path rolls over (silver_path_check, goldrush_path.cpp:156-187: the ID array is reset) is known
+    to the host in front of it — it ends the launches and goes the classic way."""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine, serial_reference
+
+    monkeypatch.setenv("GRP_STREAM", "force")
+    monkeypatch.setenv("GRP_BATCH", "off")
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    reads = _workload()
+    m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
+    target = sum(len(r) for r in reads) // 9
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=target, max_paths=3)
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads, streaming=True, resume=True)
+    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, max_window=max_window, silver_path=True, target_bases=target, max_paths=3)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    cls.run(None, lens)
+    assert _strip(cls.commits) == exp
+    assert np.array_equal(eng.mf.ids(), mf_ref.ids()) and np.array_equal(eng.mf.counts(), mf_ref.counts())
+    st = cls.state()
+    assert len({e[7] for e in exp}) >= 2                       # the run crossed a rollover
+    assert st["stream_rollovers"] >= 1 and eng.n_stream_inserts >= 3
+    assert st["stream_inserts"] + st["stream_rollovers"] <= st["inserts"]
+
+
 @pytest.mark.parametrize("max_window,crowded,verify", [(2, 0, True), (5, 0, True), (64, 0, True), (4096, 0, True), (64, 3, True), (5, 0, False), (4096, 0, False)])
 def test_batched_windows_match_serial_loop(oracle, native, max_window, crowded, verify, monkeypatch):
     """Windows committed as batches (batch_insert / _classify / _undo / _end): the window's

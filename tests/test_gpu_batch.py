@@ -431,8 +431,7 @@ def test_claim_loops_keep_every_touch(oracle, native, entry):
     eng.close()
 
 
-@pytest.mark.parametrize("collect3", [None])
-def test_large_batch_at_c2_filter_size_against_the_oracle(oracle, native, collect3, monkeypatch):
+def test_large_batch_at_c2_filter_size_against_the_oracle(oracle, native):
     """ONE batch of 200 whole-read inserts on C2's own filter (m = 61 146 729 472:
     65 GB of buckets) — 15 M (frame, seed) records, a collect grid of ~60 000 workgroups, thousands
     of them in flight — against the ORACLE's serial inserts: every ID and count, the chained ranks
@@ -440,8 +439,6 @@ def test_large_batch_at_c2_filter_size_against_the_oracle(oracle, native, collec
     from goldrush_amd import host
     from test_gpu_wide import _oracle_bits_view  # noqa: F401  (same helpers, same sizes)
 
-    if collect3:
-        monkeypatch.setenv("GRP_BATCH_COLLECT3", collect3)
     hl = host.load()
     k, h, tile, block = 22, 3, 1000, 10
     m = hl.gr_calc_optimal_size(hl.gr_hash_universe(16, 3_000_000_000, h), 1, 0.1)

@@ -164,3 +164,36 @@ def test_classifier_golden_mode_streams_through_inserts(oracle, native, max_wind
     assert cls2.state()["windows"] > n_ins // 2
     eng.close()
     eng2.close()
+
+
+def test_classifier_silver_mode_streams_through_inserts(oracle, native, monkeypatch):
+    """Round 4: silver mode with streaming windows forced — the parked launch applies the inserts, the insert behind
+    which a silver path is complete ends the launches (the ID array is reset, goldrush_path.cpp:156-187).  Commits
+    (paths included) and the final arrays equal the oracle's serial loop."""
+    from goldrush_amd import host, synth
+    from oracle_engine import serial_reference
+
+    monkeypatch.setenv("GRP_STREAM", "force")
+    monkeypatch.setenv("GRP_BATCH", "off")
+    monkeypatch.setenv("GRP_LOOP", "off")
+    k, h, tile, block = 22, 3, 500, 4
+    seeds = default_seeds(h)
+    g = synth.random_genome(150_000, 23)
+    reads = [r[1] for r in synth.make_reads(g, 160, mean_len=5000, min_len=3500, seed=24, max_len=9000)]
+    m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
+    target = 120_000
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=target, max_paths=4)
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    assert eng.finalize() == mf_ref.pop
+    cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, k=k, h=h, silver_path=True, target_bases=target, max_paths=4)
+    cls.run(b._h, b.lens)
+    eng.sync()
+    assert [c[:8] for c in cls.commits] == exp
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, mf_ref.ids()) and np.array_equal(counts, mf_ref.counts())
+    st = cls.state()
+    assert len({e[7] for e in exp}) >= 3
+    assert st["stream_rollovers"] >= 2 and st["stream_inserts"] >= 20
+    eng.close()
