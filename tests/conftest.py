@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# The oracle's OpenMP loops are small in these tests (a read, a tile): on the GPU box's host (128+ hardware threads)
+# the default team made every parallel region cost more than its work — the oracle-bound GPU tests took 44 s each
+# there against 2 s on the 8-core build container (round 4, profiles/r04_suite_durations.txt).  Set before any
+# OpenMP runtime is loaded; the bench's CPU baseline sets its own thread count.
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:

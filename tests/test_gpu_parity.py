@@ -183,7 +183,11 @@ def test_tiles_where_every_probe_returns_another_id(oracle, native, h):
         first = int(np.flatnonzero(done & (v["kind"] == 0))[0])
         assert np.all(done[: first + 1])
     else:
-        assert np.all(done) and np.all(v["kind"] != 0)
+        # nothing is handed back; the window parks itself at its first insert record (kinds 2 / 4), whatever of the
+        # reads behind it had not been handed out by then stays undecided (the host would begin again behind it)
+        ins = np.flatnonzero(done & ((v["kind"] == 2) | (v["kind"] == 4)))
+        upto = int(ins[0]) + 1 if ins.size else len(reads)
+        assert np.all(done[:upto]) and np.all(v["kind"][done] != 0)
     ok = done & (v["kind"] != 0)
     for f in ("kind", "num_tiles", "num_assigned", "trim_start", "trim_end", "hits", "misses"):
         assert np.array_equal(v[f][ok], dec[f][ok]), f
