@@ -203,7 +203,7 @@ struct grp_ctx
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
 
   // developer switches, read once at grp_create (not on every call of a latency path)
-  bool env_no_direct = false, env_stream_resume_off = false, env_no_early_park = false, env_trace_abort = false, env_sync_fr1 = false;
+  bool env_no_direct = false, env_stream_resume_off = false, env_no_early_park = false, env_trace_abort = false;
   uint64_t n_batch_sweeps = 0; // times the batch epochs wrapped and the claims were swept out of the count words
   uint64_t n_stream_idle_exits = 0, n_stream_coop_refused = 0; // parked windows that left by themselves (idle limit); resumable windows whose cooperative launch was refused
   uint64_t n_flagged_tiles = 0, n_flagged_distinct = 0, n_flagged_list = 0; // statistics: tiles redone with the worst-case table; why (distinct IDs / list length)
@@ -587,15 +587,9 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
   };
   // The synchronous forms (large windows, the two queries of a batch): two frames per lane and pass
   // up to h = 3; from h = 4 on one frame per lane with the software-pipelined pass (222 -> 171 VGPRs
-  // at h = 5; C4 geometry +4 %, h = 3 -3 %: measured, tools/dev/r3_fr1.sh)
+  // at h = 5; C4 geometry +4 %, h = 3 -3 %: measured, tools/dev/r3_fr1.sh; round 4 again with the 24 KB count table:
+  // the head of C2 2.94 - 3.04 s against 2.94 - 2.96 s, no gain, the switch is gone)
   constexpr int SFR = (HH <= 3) ? 2 : 1;
-  if constexpr (HH == 3) {
-    // measurement switch (GRP_SYNC_FR1, read at grp_create): the synchronous forms at h = 3 with one frame per lane and
-    // the software-pipelined pass, as at h >= 4 (round 3 measured -3 % with the 43 KB count table; 24 KB now)
-    if (c->env_sync_fr1 && !stream_ctl) {
-      return (c->view && !plain) ? go(k_query<3, 1, 0, false, true>) : go(k_query<3, 1, 0, false, false>);
-    }
-  }
   if (c->view && !stream_ctl && !plain) { // grp_batch_classify: every read sees the state in front of its own insert
     return go(k_query<HH, SFR, 0, false, true>);
   }
@@ -770,7 +764,6 @@ grp_create(const grp_params* p, grp_ctx** out)
     c->env_no_direct = getenv("GRP_NO_DIRECT") != nullptr;
     c->env_no_early_park = getenv("GRP_NO_EARLY_PARK") != nullptr;
     c->env_trace_abort = getenv("GRP_TRACE_ABORT") != nullptr;
-    c->env_sync_fr1 = getenv("GRP_SYNC_FR1") != nullptr;
   }
   int rc = build_seed_tables(c);
   if (rc != GRP_OK) {

@@ -112,7 +112,12 @@ InputFile::read(char* dst, size_t n)
 {
   if (fd_ >= 0) {
     constexpr size_t kSlice = size_t(16) << 20;
-    size_t threads = std::min<size_t>(n / kSlice, std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())));
+    static const size_t max_threads = [] { // GRP_READ_THREADS: threads copying one request out of the page cache (default 8)
+      const char* e = getenv("GRP_READ_THREADS");
+      const long v = e ? atol(e) : 0;
+      return (size_t)(v > 0 ? std::min(v, 64l) : 8l);
+    }();
+    size_t threads = std::min<size_t>(n / kSlice, std::min<size_t>(max_threads, std::max(1u, std::thread::hardware_concurrency())));
     size_t got = 0;
     int err = 0;
     if (threads < 2) {
