@@ -204,6 +204,7 @@ struct grp_ctx
 
   // developer switches, read once at grp_create (not on every call of a latency path)
   bool env_no_direct = false, env_stream_resume_off = false, env_no_early_park = false, env_trace_abort = false;
+  uint32_t batch_epochs = GRP_EPOCH_MAX; // batches between two sweeps of the claims (GRP_BATCH_EPOCHS: tests)
   uint64_t n_batch_sweeps = 0; // times the batch epochs wrapped and the claims were swept out of the count words
   uint64_t n_stream_idle_exits = 0, n_stream_coop_refused = 0; // parked windows that left by themselves (idle limit); resumable windows whose cooperative launch was refused
   uint64_t n_flagged_tiles = 0, n_flagged_distinct = 0, n_flagged_list = 0; // statistics: tiles redone with the worst-case table; why (distinct IDs / list length)
@@ -762,6 +763,9 @@ grp_create(const grp_params* p, grp_ctx** out)
     const char* e = getenv("GRP_STREAM_RESUME");
     c->env_stream_resume_off = e && !strcmp(e, "off");
     c->env_no_direct = getenv("GRP_NO_DIRECT") != nullptr;
+    if (const char* e = getenv("GRP_BATCH_EPOCHS")) { // tests: the claims are swept every n batches instead of every 1023
+      c->batch_epochs = (uint32_t)std::min<long>(std::max<long>(atol(e), 1), (long)GRP_EPOCH_MAX);
+    }
     c->env_no_early_park = getenv("GRP_NO_EARLY_PARK") != nullptr;
     c->env_trace_abort = getenv("GRP_TRACE_ABORT") != nullptr;
   }

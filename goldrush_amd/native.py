@@ -566,9 +566,9 @@ class Engine:
         return out
 
     def verify_stats(self) -> dict:
-        out = np.zeros(9, dtype=np.uint64)
+        out = np.zeros(10, dtype=np.uint64)
         self._check(self.lib.grp_debug_verify_stats(self._h, _ptr(out)))
-        return dict(zip(("patched", "queried", "flagged", "fallbacks", "uncertified", "unpatched", "window_flagged", "flagged_distinct", "flagged_list"), (int(x) for x in out)))
+        return dict(zip(("patched", "queried", "flagged", "fallbacks", "uncertified", "unpatched", "window_flagged", "flagged_distinct", "flagged_list", "claim_sweeps"), (int(x) for x in out)))
 
     def batch_undo(self, from_read: int, id_floor: int):
         """takes back the inserts of reads >= from_read (batch index); id_floor = the first ID read from_read could allocate"""

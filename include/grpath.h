@@ -612,8 +612,9 @@ int grp_debug_decide(grp_ctx* ctx, uint32_t n_reads, const uint64_t* tile0, cons
  * [5] patches given up for another reason (delta table full, shared first ID, flagged first summary),
  * [6] flagged tiles redone with the worst-case table by all synchronous forms (grp_classify_reads / grp_batch_* /
  * grp_query_tiles), of which [7] held more distinct IDs than the small count table takes and [8] had a count > 2
- * list longer than its LDS area */
-int grp_debug_verify_stats(const grp_ctx* ctx, uint64_t out[9]);
+ * list longer than its LDS area; [9] times the batch epochs wrapped and the claims were swept out of the count
+ * words (every 1023 batches; GRP_BATCH_EPOCHS=<n> for tests) */
+int grp_debug_verify_stats(const grp_ctx* ctx, uint64_t out[10]);
 
 /* 1: the library was built with GRP_DEV_HOOKS (make DEV=1): the frozen commit loop (grp_commit_loop_*) and the
  * developer kernels / switches (GRP_BATCH_COLLECT3 ...) are compiled in; 0: the product build — grp_commit_loop_*

@@ -163,6 +163,36 @@ def test_batches_equal_the_serial_loop(oracle, native, window, verify):
     assert {e[1] for e in exp} >= {2, 3, 5}
 
 
+def test_claim_epochs_wrap(oracle, native, monkeypatch):
+    """The claim of the collect pass lives in the rank's count word under the batch's epoch (round 4); after 1023
+    batches the epochs wrap and the claims are swept out of the words.  Here after every third batch: the same
+    commits, IDs and counts as the serial loop, with chained ranks, undone batches and the verify pass looking
+    records up through claims of the current epoch only."""
+    from goldrush_amd import synth
+
+    monkeypatch.setenv("GRP_BATCH_EPOCHS", "3")
+    tile, k, h, block = 500, 22, 3, 4
+    g = synth.random_genome(150_000, 21)
+    reads = [r[1] for r in synth.make_reads(g, 140, mean_len=5000, min_len=3500, seed=22, max_len=9000)]
+    m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
+    from oracle_engine import cached_serial_reference
+
+    seeds = default_seeds(h)
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    eng.finalize()
+    exp, ref_ids, ref_counts, _ = cached_serial_reference("loop_basic", oracle, m, seeds, tile, k, reads, block=block)
+    stats = {"batches": 0, "undone": 0}
+    got = batch_commit(eng, b, reads, tile, block, 7, stats, "check")
+    assert got == [e[:7] for e in exp]
+    ids, counts = eng.export_ids()
+    assert np.array_equal(counts, ref_counts) and np.array_equal(ids, ref_ids)
+    vs = eng.verify_stats()
+    assert stats["batches"] >= 9 and vs["claim_sweeps"] >= stats["batches"] // 3 - 1 and vs["claim_sweeps"] >= 2, (stats, vs)
+    eng.close()
+
+
 @pytest.mark.parametrize("verify", [None, "check", "chain"])
 def test_batches_on_a_small_crowded_filter(oracle, native, verify):
     """A filter far too small for its reads (occupancy ~0.5, most ranks shared by many tiles):
