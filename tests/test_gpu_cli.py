@@ -102,6 +102,18 @@ def test_designed_seed_h5_noisy_quals(oracle, host, tmp_path):
     assert ("WARNING: Expected" in rp.stderr) == ("WARNING: Expected" in ro.stderr)
 
 
+@pytest.mark.parametrize("k,w,h", [(40, 20, 3), (60, 24, 5)])
+def test_spans_beyond_32_bases_through_the_binary(oracle, host, tmp_path, k, w, h):
+    """-k 40 / -k 60 (round 4: k + h - 1 up to 64): designed seeds wider than one 64-bit window of 2-bit bases through the
+    whole program — ingest, fill, silver paths — byte-identical to the oracle's."""
+    fq = str(tmp_path / "reads.fq")
+    _mk_fastq(fq, 150_000, 140, 8000, 6000, seed=12 + k)
+    args = ["-k%d" % k, "-w%d" % w, "-t500", "-u5", "-a1", "-o0.1", "-h%d" % h, "-j2", "-P10", "-d5", "-x8", "-g150000", "-b4", "-r0.9", "--silver_path", "-M3", "-m5000",
+            "-i", fq, "--verbose"]
+    ro, rp, d_o, d_p, files = _run_both(oracle, host, tmp_path, args, "wide%d" % k)
+    assert files and _verbose_counters(rp.stderr) == _verbose_counters(ro.stderr)
+
+
 def _ntcard_lines(stderr):
     keep = ("Calculating expected entries", "Expected entries for seed pattern", "Total expected entries", "m_filterSize", "\texpected hash space",
             "\toccupancy")
