@@ -262,6 +262,24 @@ struct grp_ctx
   void* comm = nullptr;
   uint32_t comm_world = 1, comm_rank = 0;
   double* d_delog = nullptr; // 10^(-Q/10) table for the FASTQ ingest
+  // buffers of the FASTQ ingest, kept between chunks (round 4: a chunk used to pay seven hipMalloc / hipFree pairs,
+  // 256 MiB of text among them — every hipFree waits for the device)
+  struct IngestPool
+  {
+    uint8_t* text[2] = { nullptr, nullptr }; // two chunks can be alive at once (parsed / being packed)
+    uint64_t text_cap[2] = { 0, 0 };
+    bool text_used[2] = { false, false };
+    uint32_t* d_counts = nullptr;
+    uint64_t counts_cap = 0;
+    uint64_t *d_base = nullptr, *d_super = nullptr, *d_total = nullptr, *d_nl = nullptr;
+    uint64_t base_cap = 0, super_cap = 0, total_cap = 0, nl_cap = 0;
+    void* d_rec = nullptr; // grp_fastq_record[]
+    uint64_t rec_bytes = 0;
+    uint64_t *d_so = nullptr, *d_wo = nullptr; // grp_fastq_pack: sequence offsets, word offsets, lengths of the selection
+    uint32_t* d_len = nullptr;
+    uint64_t so_cap = 0, wo_cap = 0, len_cap = 0;
+    hipEvent_t uploaded = nullptr; // the chunk's text has arrived (copied on the side stream, beside the fill of the chunk before)
+  } ingest;
   const char* reg_text = nullptr; // the caller's text buffer, page-locked by grp_fastq_pin
   size_t reg_bytes = 0;
   uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT) | (1u << GRP_K_VERIFY) | (1u << GRP_K_BATCH);
@@ -981,6 +999,21 @@ grp_destroy(grp_ctx* c)
     (void)hipHostFree(c->h_small_lists);
   }
   (void)hipFree(c->d_delog);
+  for (int i = 0; i < 2; ++i) {
+    (void)hipFree(c->ingest.text[i]);
+  }
+  (void)hipFree(c->ingest.d_counts);
+  (void)hipFree(c->ingest.d_base);
+  (void)hipFree(c->ingest.d_super);
+  (void)hipFree(c->ingest.d_total);
+  (void)hipFree(c->ingest.d_nl);
+  (void)hipFree(c->ingest.d_rec);
+  (void)hipFree(c->ingest.d_so);
+  (void)hipFree(c->ingest.d_wo);
+  (void)hipFree(c->ingest.d_len);
+  if (c->ingest.uploaded) {
+    (void)hipEventDestroy(c->ingest.uploaded);
+  }
   (void)hipFree(c->d_dedup);
   (void)hipFree(c->d_ir_keys);
   (void)hipFree(c->d_ir_masks);

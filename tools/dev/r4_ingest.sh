@@ -23,12 +23,11 @@ run() {
   s=$(date +%s.%N)
   env $1 $2 $CLI $base -p /tmp/ing_out > /tmp/ing.log 2>&1
   e=$(date +%s.%N)
-  echo "$1 $2: wall $(echo "$e - $s" | bc) s; phases: $(grep -E '^in [0-9.]+$' /tmp/ing.log | tr '\n' ' ')"
+  echo "$1 $2: wall $(python3 -c "print(round($e - $s, 2))") s; phases: $(grep -E '^in [0-9.]+$' /tmp/ing.log | tr '\n' ' ')"
 }
+timeout 900 python3 -m pytest tests/test_gpu_ingest.py tests/test_gpu_cli.py -m gpu -x -q 2>&1 | tail -3
 run A=1 B=1
-for th in 8 16 32; do
-  for ch in 268435456 1073741824; do
-    run GRP_READ_THREADS=$th GRP_INGEST_CHUNK=$ch
-  done
-done
+run A=1 B=2
+run GRP_READ_THREADS=16 GRP_INGEST_CHUNK=134217728
+run GRP_READ_THREADS=16 GRP_INGEST_CHUNK=536870912
 run GRP_READ_THREADS=16 GRP_RESIDENT=off
