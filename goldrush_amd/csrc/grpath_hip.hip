@@ -606,7 +606,7 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
   };
   // The synchronous forms (large windows, the two queries of a batch): two frames per lane and pass
   // up to h = 3; from h = 4 on one frame per lane with the software-pipelined pass (222 -> 171 VGPRs
-  // at h = 5; C4 geometry +4 %, h = 3 -3 %: measured, tools/dev/r3_fr1.sh; round 4 again with the 24 KB count table:
+  // at h = 5; C4 geometry +4 %, h = 3 -3 %: measured, tools/dev/r3_fr1.sh of round 3; round 4 again with the 24 KB count table:
   // the head of C2 2.94 - 3.04 s against 2.94 - 2.96 s, no gain, the switch is gone)
   constexpr int SFR = (HH <= 3) ? 2 : 1;
   if (c->view && !stream_ctl && !plain) { // grp_batch_classify: every read sees the state in front of its own insert
