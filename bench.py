@@ -662,7 +662,7 @@ def main():
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors OR-merged as reduce-scatter (all-to-all + OR) + all-gather" % world, "synth_s": t_synth,
                     "read_batches": rs.n_batches, "synth_in_timed_region_s": rs.synth_s - synth_before,
                     "warmup_s": t_warm, "warmup_mode": "%d steps of 512 reads on a throw-away engine (G=2e6)" % a.warmup,
-                    "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit", "batches", "batches_undone", "batch_reads", "batches_fused", "stream_inserts", "stream_insert_fallbacks", "stream_relaunches", "stream_handbacks")},
+                    "timed": {key: st1[key] - st0[key] for key in ("windows", "reads_queried", "reads_committed", "inserts", "seconds_windows", "seconds_commit", "batches", "batches_undone", "batch_reads", "batches_fused", "stream_inserts", "stream_insert_fallbacks", "stream_relaunches", "stream_handbacks", "batch_overlap_cuts")},
                     "query_Gprobes_per_s": gprobes,
                     "query_kernel_s": kq_s, "decide_kernel_s": ks["decide"]["ms"] * 1e-3, "decide_launches": ks["decide"]["launches"],
                     "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
@@ -707,7 +707,7 @@ def main():
                 "reads_consumed": int(sst["reads_committed"]), "seconds": t_s, "reads_per_s": sst["reads_committed"] / t_s if t_s > 0 else None,
                 "inserts": int(sst["inserts"]), "paths_completed": int(sst["curr_path"]) - 1 if s_fin else int(sst["curr_path"]) - 1, "finished": bool(s_fin),
                 "batches": int(sst["batches"]), "batches_undone": int(sst["batches_undone"]), "reads_queried": int(sst["reads_queried"]),
-                "stream_inserts": int(sst["stream_inserts"]), "stream_rollovers": int(sst["stream_rollovers"]),
+                "stream_inserts": int(sst["stream_inserts"]), "stream_rollovers": int(sst["stream_rollovers"]), "batch_overlap_cuts": int(sst["batch_overlap_cuts"]),
                 "kernel_stats": {k_: v_ for k_, v_ in eng.kernel_stats().items() if v_["launches"]}}  # of this pass alone (HIP events, summed ms)
             del scls
         print(json.dumps(out), flush=True)

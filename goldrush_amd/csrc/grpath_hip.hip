@@ -204,6 +204,19 @@ struct grp_ctx
 
   // developer switches, read once at grp_create (not on every call of a latency path)
   bool env_no_direct = false, env_stream_resume_off = false, env_no_early_park = false, env_trace_abort = false;
+  // grp_window_overlap (grp_batch.inc): samples per tile, their table, the result per read
+  struct OverlapBuf
+  {
+    unsigned long long* d_samples = nullptr;
+    uint64_t samples_cap = 0; // in tiles
+    uint32_t* d_n = nullptr;
+    uint64_t n_cap = 0;
+    unsigned long long* d_tab = nullptr;
+    uint64_t tab_cap = 0;
+    uint32_t* d_prev = nullptr;
+    uint64_t prev_cap = 0;
+  } ovl;
+  uint64_t n_overlap_calls = 0;
   uint32_t batch_epochs = GRP_EPOCH_MAX; // batches between two sweeps of the claims (GRP_BATCH_EPOCHS: tests)
   uint64_t n_batch_sweeps = 0; // times the batch epochs wrapped and the claims were swept out of the count words
   uint64_t n_stream_idle_exits = 0, n_stream_coop_refused = 0; // parked windows that left by themselves (idle limit); resumable windows whose cooperative launch was refused
@@ -999,6 +1012,10 @@ grp_destroy(grp_ctx* c)
     (void)hipHostFree(c->h_small_lists);
   }
   (void)hipFree(c->d_delog);
+  (void)hipFree(c->ovl.d_samples);
+  (void)hipFree(c->ovl.d_n);
+  (void)hipFree(c->ovl.d_tab);
+  (void)hipFree(c->ovl.d_prev);
   for (int i = 0; i < 2; ++i) {
     (void)hipFree(c->ingest.text[i]);
   }

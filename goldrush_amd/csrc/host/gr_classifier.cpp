@@ -30,6 +30,18 @@ Classifier::Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, v
     const std::string t = env("GRP_MAX_WINDOW_TILES");
     env_.max_window_tiles = t.empty() ? 0 : (uint64_t)std::max(1l, atol(t.c_str()));
   }
+  {
+    const std::string t = env("GRP_BATCH_OVERLAP");
+    if (t == "off") {
+      env_.overlap_samples = 0;
+    } else if (!t.empty()) {
+      env_.overlap_samples = (uint32_t)std::max(1l, atol(t.c_str()));
+    }
+    const std::string pmin = env("GRP_BATCH_OVERLAP_P");
+    if (!pmin.empty()) {
+      env_.overlap_min_insert = atof(pmin.c_str());
+    }
+  }
   if (p_.world == 0) {
     p_.world = 1;
   }
@@ -116,6 +128,8 @@ Classifier::get_state(gr_classifier_state& s) const
   s.stream_relaunches = n_stream_relaunches_;
   s.stream_handbacks = n_stream_handbacks_;
   s.stream_rollovers = n_stream_rollovers_;
+  s.batch_overlap_cuts = n_batch_overlap_cuts_;
+  s.overlap_calls = n_overlap_calls_;
 }
 
 void
@@ -1002,6 +1016,42 @@ Classifier::batch_round(uint32_t& pos)
     err_ = std::string(what) + ": " + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
     return rc;
   };
+  // Where most reads insert, a read that overlaps ANY read in front of it in its window will decide differently
+  // behind that read's insert and take the rest of the batch back.  The engine tells for blocks of 4096 reads which
+  // reads overlap which read in front of them (a hash-only pass, grp_window_overlap: one call per block, nothing per
+  // batch) and a window ends in front of the first read that overlaps one of ITS reads — it becomes the next
+  // window's first read.  Only a hint; one rank (the ranks would have to agree on it).
+  const bool ask_overlap = vt_.window_overlap && env_.overlap_samples && p_.world == 1 && p_insert_mid_ >= env_.overlap_min_insert;
+  auto ends_at_overlap = [&](uint32_t at, uint32_t count) -> uint32_t { // reads [at, at + count) of the range: how many to keep
+    if (!ask_overlap || count < 3) {
+      return count;
+    }
+    if (ovl_base_ != base_ || at < ovl_lo_ || at >= ovl_hi_) {
+      // the block that starts at this window (overlaps with reads in front of `at` do not matter to it)
+      constexpr uint32_t kBlock = 4096;
+      const uint32_t nb = clamp_tiles(at, std::min<uint32_t>(kBlock, n - at), 1ull << 19);
+      ovl_prev_.assign(nb, UINT32_MAX);
+      ovl_base_ = base_;
+      ovl_lo_ = at;
+      ovl_hi_ = at + nb;
+      ++n_overlap_calls_;
+      if (nb >= 3 && vt_.window_overlap(ctx_, rg_.reads, base_ + at, nb, env_.overlap_samples, ovl_prev_.data()) != GRP_OK) {
+        ovl_prev_.assign(nb, UINT32_MAX); // no hints from this engine call
+      }
+    }
+    const uint32_t end = std::min(at + count, ovl_hi_);
+    for (uint32_t j = at + 1; j < end; ++j) {
+      const uint32_t p = ovl_prev_[j - ovl_lo_];
+      if (p != UINT32_MAX && ovl_lo_ + p >= at) {
+        ++n_batch_overlap_cuts_;
+        return j - at;
+      }
+    }
+    return count;
+  };
+  if (!have_first) {
+    B = ends_at_overlap(pos, B);
+  }
   in_batch_ = true;
   ++n_windows_;
   // Several ranks (every one holds a replica and applies the whole batch to it): the two queries
@@ -1157,6 +1207,9 @@ Classifier::batch_round(uint32_t& pos)
     const double t_query = (double)extra * avg_probes_per_read_ / 40e9;
     if (p_fail * t_query > 1.0e-4) {
       extra = 0;
+    }
+    if (extra) {
+      extra = ends_at_overlap(pos + cnt, extra); // the reads behind the batch are the next window
     }
   }
   bdec1_.resize((size_t)cnt + extra);
@@ -1620,6 +1673,7 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
     return GRP_OK;
   }
   base_ = first;
+  ovl_base_ = UINT64_MAX; // (the overlap hints of the range before are another batch's)
   rg_.reads = reads;
   rg_.lens = lens + first;
   rg_.skipped_before = skipped_before ? skipped_before + first : nullptr;

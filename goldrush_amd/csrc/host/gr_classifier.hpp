@@ -98,6 +98,8 @@ private:
   {
     std::string pipeline, stream, loop, batch; // GRP_PIPELINE / GRP_STREAM / GRP_LOOP / GRP_BATCH as found when the classifier was created
     uint64_t max_window_tiles = 0;             // GRP_MAX_WINDOW_TILES (0: unset)
+    uint32_t overlap_samples = 8;              // GRP_BATCH_OVERLAP=<n> / off: windows of batches end in front of a read sharing >= n sampled k-mers with a read in front of it (0: not asked)
+    double overlap_min_insert = 0.3;           // GRP_BATCH_OVERLAP_P: ... where at least this share of the reads inserts
   } env_;
   gr_commit_fn commit_cb_ = nullptr;
   uint32_t keep_first_[2] = { 0, 0 }, keep_count_[2] = { 0, 0 };
@@ -155,6 +157,11 @@ private:
   uint64_t n_stream_inserts_ = 0;
   uint32_t resume_clean_windows_ = 0;  // windows ended without a refused insert since resume_disabled_ was set (64: tried again)
   uint64_t n_stream_insert_fallbacks_ = 0, n_stream_relaunches_ = 0, n_stream_handbacks_ = 0;
+  uint64_t n_batch_overlap_cuts_ = 0; // windows of batches ended in front of a read grp_window_overlap named
+  uint64_t n_overlap_calls_ = 0;
+  std::vector<uint32_t> ovl_prev_;    // grp_window_overlap's answer for reads [ovl_lo_, ovl_hi_) of the range that starts at base_ == ovl_base_
+  uint32_t ovl_lo_ = 0, ovl_hi_ = 0;
+  uint64_t ovl_base_ = UINT64_MAX;
   uint64_t n_stream_rollovers_ = 0; // silver mode: inserts kept out of a parked launch because the path rolls over behind them
   uint64_t lost_at_ = UINT64_MAX;      // read at which a window was last begun again because its launch had left without deciding it
   uint32_t group_base_ = UINT32_MAX; // first read of the stripe group held in stripe_recv_

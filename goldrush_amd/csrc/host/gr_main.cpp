@@ -49,6 +49,9 @@ hip_engine()
   vt.batch_verify = [](void* c, const void* r, uint32_t first, uint32_t count, uint32_t extra, const grp_decide_params* dp, const uint32_t* id_floor, grp_read_decision* out) {
     return grp_batch_verify(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, extra, dp, id_floor, out);
   };
+  vt.window_overlap = [](void* c, const void* r, uint32_t first, uint32_t count, uint32_t threshold, uint32_t* prev_out) {
+    return grp_window_overlap(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, threshold, prev_out);
+  };
   vt.batch_undo = [](void* c, uint32_t from_read, uint32_t id_floor) { return grp_batch_undo(static_cast<grp_ctx*>(c), from_read, id_floor); };
   vt.batch_end = [](void* c) { return grp_batch_end(static_cast<grp_ctx*>(c)); };
   vt.ntcard_begin = [](void* c, uint32_t sbits) { return grp_ntcard_begin(static_cast<grp_ctx*>(c), sbits); };

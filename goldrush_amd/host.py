@@ -40,7 +40,7 @@ class gr_classifier_state(C.Structure):
                [("phred_sum_in_path", C.c_double), ("inserted_bases", C.c_uint64), ("curr_path", C.c_uint64), ("id", C.c_uint32), ("ids_inserted", C.c_uint32)] + \
                [(n, C.c_uint64) for n in ("windows", "reads_queried", "reads_committed", "inserts")] + \
                [("seconds_windows", C.c_double), ("seconds_commit", C.c_double)] + \
-               [(n, C.c_uint64) for n in ("batches", "batches_undone", "batch_reads", "batches_refused", "batches_fused", "stream_inserts", "stream_insert_fallbacks", "stream_relaunches", "stream_handbacks", "stream_rollovers")]
+               [(n, C.c_uint64) for n in ("batches", "batches_undone", "batch_reads", "batches_refused", "batches_fused", "stream_inserts", "stream_insert_fallbacks", "stream_relaunches", "stream_handbacks", "stream_rollovers", "batch_overlap_cuts", "overlap_calls")]
 
 
 # engine function table: members typed exactly like include/grpath.h
@@ -91,6 +91,7 @@ VT_TYPES = [
     ("fastq_pin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64)),
     ("fastq_unpin", C.CFUNCTYPE(C.c_int, _vp)),
     ("batch_verify", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp)),
+    ("window_overlap", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp)),
 ]
 
 

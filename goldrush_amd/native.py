@@ -120,6 +120,7 @@ SIGNATURES = {
     "grp_batch_insert_reads": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_batch_classify": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp, _vp]),
     "grp_batch_verify": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp, _vp]),
+    "grp_window_overlap": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "grp_debug_verify_stats": (C.c_int, [_vp, _vp]),
     "grp_batch_undo": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "grp_batch_end": (C.c_int, [_vp]),
@@ -564,6 +565,13 @@ class Engine:
         dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
         self._check(self.lib.grp_batch_verify(self._h, batch._h, first, count, extra, C.byref(dp), _ptr(fl), _ptr(out)))
         return out
+
+    def window_overlap(self, batch: ReadBatch, first: int, count: int, threshold: int = 8) -> np.ndarray:
+        """grp_window_overlap: per read of [first, first + count) the closest read in front of it (index relative to
+        first) that owns >= threshold of its sampled k-mers; 0xFFFFFFFF: none."""
+        out = np.full(max(count, 1), 0xFFFFFFFF, dtype=np.uint32)
+        self._check(self.lib.grp_window_overlap(self._h, batch._h, first, count, threshold, _ptr(out)))
+        return out[:count]
 
     def verify_stats(self) -> dict:
         out = np.zeros(10, dtype=np.uint64)

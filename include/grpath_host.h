@@ -84,6 +84,9 @@ typedef struct
   /* optional (with the batch_* members; round 4): the second decisions of a batch from the batch's own
    * records instead of a second query, grp_batch_verify */
   int (*batch_verify)(void* ctx, const void* reads, uint32_t first, uint32_t count, uint32_t extra, const grp_decide_params* params, const uint32_t* id_floor, grp_read_decision* out);
+  /* optional (round 4): per read of a range the closest read in front of it that it overlaps, grp_window_overlap —
+   * where most of the reads insert the classifier ends its batches in front of such reads */
+  int (*window_overlap)(void* ctx, const void* reads, uint32_t first, uint32_t count, uint32_t threshold, uint32_t* prev_out);
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */
@@ -229,6 +232,8 @@ typedef struct
   uint64_t stream_handbacks; /* records a streaming window handed back to the synchronous path (kind 0: a read of more tiles than the
                                 in-launch decision holds, a tile that needed the worst-case table) */
   uint64_t stream_rollovers; /* silver mode (round 4): inserts a parked window did not apply itself because the silver path rolls over behind them (the ID array is reset: the launches end there) */
+  uint64_t batch_overlap_cuts; /* windows of batches ended in front of a read grp_window_overlap named (round 4) */
+  uint64_t overlap_calls;      /* grp_window_overlap calls (one per block of 4096 reads where it is asked) */
 } gr_classifier_state;
 void gr_classifier_get_state(const gr_classifier* c, gr_classifier_state* out);
 

@@ -10,7 +10,9 @@ from goldrush_amd import host, native
 
 class OracleEngine:
     def __init__(self, orc, m, seeds, tile, k, reads, pipelined=False, streaming=False, redo_every=0, batching=False, batch_crowded_above=0,
-                 resume=False, resume_refuse_every=0, resume_lost_every=0, batch_verify=True):
+                 resume=False, resume_refuse_every=0, resume_lost_every=0, batch_verify=True, overlap_every=0):
+        self.overlap_every = overlap_every  # grp_window_overlap: every n-th read of the stream "overlaps" (0: the engine has no such call)
+        self.n_overlap_calls = 0
         self.batch_verify = batch_verify  # with batching: the engine has grp_batch_verify (the second decisions + the reads behind the batch)
         self.n_verifies = 0
         self.pipelined = pipelined
@@ -293,6 +295,17 @@ class OracleEngine:
             self.n_verifies += 1
             return batch_classify(ctx, reads, first, count + extra, dp_p, floor_p, out_p)
 
+        def window_overlap(ctx, reads, first, count, threshold, out_p):
+            # per read of the range the closest read in front of it that it "overlaps": every n-th read of the stream
+            # overlaps the read two places in front of it (right or wrong, the commits must not depend on it)
+            self.n_overlap_calls += 1
+            out = C.cast(out_p, C.POINTER(C.c_uint32))
+            for j in range(count):
+                out[j] = 0xFFFFFFFF
+                if j >= 2 and (first + j) % self.overlap_every == 0:
+                    out[j] = j - 2
+            return 0
+
         def batch_undo(ctx, from_read, floor_id):
             assert bt and from_read >= bt["first"]
             later = [e for e in bt["ins"] if int(e[0]) >= from_read]
@@ -331,6 +344,8 @@ class OracleEngine:
                          "batch_undo": batch_undo, "batch_end": batch_end})
             if self.batch_verify:
                 impl["batch_verify"] = batch_verify
+            if self.overlap_every:
+                impl["window_overlap"] = window_overlap
         impl.update({"query_tiles": query_tiles, "insert_tiles": insert_tiles, "reset_ids": reset_ids, "sync": sync, "last_error": last_error})
         for name, ftype in host.VT_TYPES:
             if name in impl:

@@ -166,6 +166,40 @@ def test_streaming_windows_apply_inserts_themselves(oracle, native, max_window, 
     assert cls.state()["reads_committed"] == len(exp)
 
 
+@pytest.mark.parametrize("overlap_every,verify,silver", [(5, True, False), (3, False, False), (2, True, False), (4, True, True)])
+def test_windows_of_batches_end_in_front_of_overlaps(oracle, native, overlap_every, verify, silver, monkeypatch):
+    """Round 4: where most reads insert the classifier asks the engine (grp_window_overlap) for the first read of the
+    window it is about to query that overlaps a read in front of it, and ends the window there.  Wherever the engine
+    says so — here every n-th read of the stream, right or wrong — the commits and the filter stay the serial loop's;
+    only the batch boundaries move."""
+    from goldrush_amd import host
+    from oracle_engine import OracleEngine, serial_reference
+
+    monkeypatch.setenv("GRP_BATCH", "force")
+    monkeypatch.setenv("GRP_BATCH_OVERLAP_P", "0")  # ask in every regime
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    reads = _workload()
+    m = oracle.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
+    kw = dict(silver=True, target_bases=sum(len(r) for r in reads) // 9, max_paths=3) if silver else {}
+    exp, mf_ref = serial_reference(oracle, m, seeds, tile, k, reads, block=block, **kw)
+    eng = OracleEngine(oracle, m, seeds, tile, k, reads, batching=True, batch_verify=verify, overlap_every=overlap_every)
+    ckw = dict(silver_path=True, target_bases=kw["target_bases"], max_paths=3) if silver else {}
+    cls = host.Classifier(None, eng.vt, tile=tile, block=block, k=k, h=h, max_window=64, **ckw)
+    lens = np.array([len(r) for r in reads], dtype=np.uint32)
+    cls.run(None, lens)
+    assert _strip(cls.commits) == exp
+    assert np.array_equal(eng.mf.ids(), mf_ref.ids()) and np.array_equal(eng.mf.counts(), mf_ref.counts())
+    st = cls.state()
+    assert st["batch_overlap_cuts"] >= 2 and 1 <= eng.n_overlap_calls == st["overlap_calls"] and st["reads_committed"] == len(exp)
+    # switched off: the same commits, the engine is not asked
+    monkeypatch.setenv("GRP_BATCH_OVERLAP", "off")
+    eng2 = OracleEngine(oracle, m, seeds, tile, k, reads, batching=True, batch_verify=verify, overlap_every=overlap_every)
+    cls2 = host.Classifier(None, eng2.vt, tile=tile, block=block, k=k, h=h, max_window=64, **ckw)
+    cls2.run(None, lens)
+    assert _strip(cls2.commits) == exp and cls2.state()["batch_overlap_cuts"] == 0 and eng2.n_overlap_calls == 0
+
+
 @pytest.mark.parametrize("max_window", [4096, 32])
 def test_streaming_windows_apply_inserts_in_silver_mode(oracle, native, max_window, monkeypatch):
     """Round 4: in silver mode too the parked window applies the host's inserts itself; the insert

@@ -401,3 +401,32 @@ def test_c1_stream_streaming_equals_synchronous_windows(native, monkeypatch):
     assert a[3] == b[3] and a[3]["inserts"] > 5000
     assert a[0] == b[0]
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and int((a[1] != 0).sum()) > 100_000
+
+
+def test_window_overlap_names_the_reads_that_overlap_one_in_front_of_them(oracle, native):
+    """grp_window_overlap (round 4): a hash-only pass over a range of reads — one frame in 16 under seed 0, canonical,
+    so either strand — returns per read the closest read in front of it that owns >= threshold of its samples.
+    Error-free reads with known positions: 5 kb shared is ~300 samples, 1 kb ~60, unrelated reads ~0."""
+    from goldrush_amd import synth
+
+    NONE = 0xFFFFFFFF
+    k, h, tile = 22, 3, 1000
+    g = synth.random_genome(400_000, 91)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    reads = [g[0:10_000].tobytes(), g[50_000:60_000].tobytes(), g[200_000:210_000].tobytes(), g[52_000:62_000].tobytes().translate(comp)[::-1], g[100_000:110_000].tobytes(),
+             g[5_000:15_000].tobytes(), g[109_000:112_500].tobytes(), g[300_000:300_900].tobytes(), g[8_000:14_000].tobytes()]
+    m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
+    eng = native.Engine(k, h, tile, m, default_seeds(h))
+    b = eng.upload(reads)  # (no fill, no finalize: the call reads nothing of the filter)
+    # read 3 = the other strand of read 1's second half; 5 overlaps 0; 6 overlaps 4 by 1 kb; 7 has no tile; 8 overlaps 0 AND 5:
+    # the samples of 8's first 2 kb are owned by read 0 (the first holder), the 4 kb behind them by read 5 -> the closest is 5
+    assert list(eng.window_overlap(b, 0, 9)) == [NONE, NONE, NONE, 1, NONE, 0, 4, NONE, 5]
+    assert list(eng.window_overlap(b, 0, 3)) == [NONE] * 3
+    assert list(eng.window_overlap(b, 2, 7)) == [NONE, NONE, NONE, NONE, 2, NONE, 3]   # [2, 9): 3 and 5 have lost their partners, 8 overlaps 5 (index 3)
+    assert list(eng.window_overlap(b, 2, 7, threshold=100)) == [NONE, NONE, NONE, NONE, NONE, NONE, 3]  # 6 shares only ~60 samples with 4
+    assert list(eng.window_overlap(b, 0, 1)) == [NONE] and len(eng.window_overlap(b, 0, 0)) == 0
+    # the engine is as usable as ever
+    eng.bv_insert(b)
+    eng.finalize()
+    assert len(eng.classify_reads(b)) == 9
+    eng.close()
