@@ -1026,8 +1026,9 @@ Classifier::batch_round(uint32_t& pos)
     if (!ask_overlap || count < 3) {
       return count;
     }
-    if (ovl_base_ != base_ || at < ovl_lo_ || at >= ovl_hi_) {
-      // the block that starts at this window (overlaps with reads in front of `at` do not matter to it)
+    if (ovl_base_ != base_ || at < ovl_lo_ || at >= ovl_hi_ || (at + count > ovl_hi_ && ovl_hi_ < n)) {
+      // the block that starts at this window (overlaps with reads in front of `at` do not matter to it); a window
+      // that would reach beyond the block's end begins the next block (its tail would go unexamined)
       constexpr uint32_t kBlock = 4096;
       const uint32_t nb = clamp_tiles(at, std::min<uint32_t>(kBlock, n - at), 1ull << 19);
       ovl_prev_.assign(nb, UINT32_MAX);
