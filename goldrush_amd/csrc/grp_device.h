@@ -10,22 +10,28 @@
 // phase 2 (after grp_finalize): the reference keeps the interleaved bit vector
 // + rank support (MIBloomFilter.hpp:757-759) and a separate ID array indexed by
 // rank (:758) — two dependent random DRAM accesses per probe.  Random 64-byte
-// gathers are bound by DRAM row activations on MI355X (~55 G sectors/s,
+// gathers are bound by the request rate of the memory system on MI355X (~48 G lines/s,
 // tools/gather_bench.hip), so here the bits and THEIR IDs share one 64-byte
-// bucket and a probe costs one sector:
-//   buckets[n_buckets]  64 B each:
+// line and a probe costs one line:
+//   buckets[n_buckets]  128-byte UNITS (round 5), 128-byte aligned:
+//     line 0, the QUERY's line (all a probe reads):
 //       uint32 rel        ones before this bucket, relative to its superbucket
 //       uint64 bitmap     W <= 64 consecutive filter bits (bit j = position b*W+j)
 //       uint32 ids[13]    ID of the bucket's j-th set bit (MIBloomFilter m_data)
+//     line 1, the INSERT's line (touched by inserts only):
+//       uint64 cw[8]      count word of the bucket's j-th set bit, j < 8: bits 0..27 the insert count
+//                         (MIBFConstructSupport m_counts, :338), bits 28..37 the epoch of the batch that claimed the
+//                         rank last, bits 38..63 the claiming record of that batch (grp_batch.inc)
 //   W is chosen at finalize from the measured occupancy so that a bucket holds
 //   ~6 set bits on average; the rare bucket with more than 13 set bits keeps the
-//   IDs of its 14th.. set bits in a small open-addressing table keyed by rank.
+//   IDs of its 14th.. set bits in a small open-addressing table keyed by rank, and the count words of a bucket's
+//   9th.. set bits live in a second one (`far`, keys written once at finalize: ~5 % of the ranks at W >= 13 and the
+//   design occupancy).
+//   Why a unit (round 5, tools/collect_matrix.sh -> profiles/r05_collect_matrix.txt): an insert dirties the ID (line 0)
+//   and the count (rounds 1-4: an array indexed by rank, another random line).  Two lines of ONE 128-byte block cost
+//   the memory system 0.7 x what two unrelated lines cost (17.6 against 12.3 G records/s; already 256 bytes apart the
+//   gain is gone), and the query still reads one 64-byte line.
 //   super[n_super]   uint64  absolute ones before each superbucket (2^22 buckets)
-//   counts[pop]      uint64  bits 0..27: insert count (MIBFConstructSupport m_counts, :338), indexed by
-//                            global rank; touched by inserts only.  Round 4: bits 28..37 the epoch of the
-//                            batch that claimed the rank last, bits 38..63 the claiming record of that batch
-//                            (grp_batch.inc: the claim of the collect pass and the count share one word — one
-//                            random line per record instead of two; a count that would not fit 28 bits traps)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,6 +39,10 @@
 #define GRP_DEV_MAX_H 8
 #define GRP_DEV_MAX_W 32
 #define GRP_BUCKET_IDS 13u
+#define GRP_NEAR_CW 8u           /* count words in the unit's insert line */
+#define GRP_UNIT_U4 8u           /* uint4 per bucket unit (128 B) */
+#define GRP_UNIT_DW 32u          /* dwords per unit: dword 3 + j of a unit = the ID of its j-th set bit */
+#define GRP_UNIT_QW 16u          /* 64-bit words per unit: word 8 + j = the count word of its j-th set bit */
 #define GRP_SUPER_SHIFT 22       /* buckets per superbucket = 2^22 (rel < 2^28) */
 #define GRP_CHUNK_BUCKETS 4096u  /* rank-build chunk; divides the superbucket */
 
@@ -57,9 +67,10 @@ struct DevSeeds
 struct DevFilter
 {
   uint32_t* bv;                 // phase 1
-  uint4* buckets;               // phase 2: 4 x uint4 per bucket
+  uint4* buckets;               // phase 2: units of 8 x uint4 (query line, insert line)
   const uint64_t* super;
-  unsigned long long* counts;   // per rank: insert count | batch epoch | claiming record (grp_cnt, grp_claim_* below)
+  ulonglong2* far;              // {rank + 1, count word} of the ranks beyond a bucket's 8th set bit; keys immutable after grp_finalize
+  uint64_t far_mask;
   unsigned long long* ovf_keys; // rank + 1, 0 = empty
   uint32_t* ovf_ids;
   uint64_t ovf_mask;
@@ -166,6 +177,49 @@ grp_locate(const DevFilter& f, uint64_t hash)
   p.b = grp_div_w(pos, f.w_magic);
   p.off = (uint32_t)(pos - p.b * f.W);
   return p;
+}
+
+// dword index (into f.buckets) of the ID slot of a bucket's lr-th set bit; dword 0 of the unit: the ID lives in the
+// overflow table (`loc & 31` tells)
+__host__ __device__ inline unsigned long long
+grp_id_loc(uint64_t b, uint32_t lr)
+{
+  return (lr < GRP_BUCKET_IDS) ? (unsigned long long)(b * GRP_UNIT_DW + 3u + lr) : (unsigned long long)(b * GRP_UNIT_DW);
+}
+
+// the count word of a rank beyond its bucket's 8th set bit (the key was written at finalize)
+__device__ inline unsigned long long*
+grp_far_ptr(const DevFilter& f, uint64_t rank)
+{
+  uint64_t slot = ((rank + 1) * 0x9E3779B97F4A7C15ULL) >> 19 & f.far_mask;
+  for (;;) {
+    const unsigned long long k = f.far[slot].x;
+    if (k == rank + 1) {
+      return &f.far[slot].y;
+    }
+    if (k == 0) {
+      __builtin_trap(); // a rank without a count word: the far table is complete by construction
+    }
+    slot = (slot + 1) & f.far_mask;
+  }
+}
+
+// the count word (count | epoch | claiming record) of a bucket's lr-th set bit
+__device__ inline unsigned long long*
+grp_cw_ptr(const DevFilter& f, uint64_t b, uint32_t lr, uint64_t rank)
+{
+  if (lr < GRP_NEAR_CW) {
+    return reinterpret_cast<unsigned long long*>(f.buckets) + b * GRP_UNIT_QW + 8u + lr;
+  }
+  return grp_far_ptr(f, rank);
+}
+
+// ... from the rank's ID location (grp_id_loc)
+__device__ inline unsigned long long*
+grp_cw_ptr_loc(const DevFilter& f, unsigned long long loc, uint64_t rank)
+{
+  const uint32_t dw = (uint32_t)(loc & (GRP_UNIT_DW - 1u));
+  return grp_cw_ptr(f, loc / GRP_UNIT_DW, dw ? dw - 3u : GRP_BUCKET_IDS, rank);
 }
 
 // header = first 16 bytes of a bucket: {rel, bitmap lo, bitmap hi, ids[0]}

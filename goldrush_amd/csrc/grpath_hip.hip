@@ -200,6 +200,7 @@ struct grp_ctx
   uint64_t nsb = 0;      // superbuckets
   uint64_t n_bv_words = 0;
   uint64_t n_ovf = 0;    // IDs living in the overflow table
+  uint64_t n_far = 0;    // count words living in the far table
   uint32_t uniform_weight = 0; // weight shared by all seeds, 0 if they differ
 
   // developer switches, read once at grp_create (not on every call of a latency path)
@@ -996,7 +997,7 @@ grp_destroy(grp_ctx* c)
   (void)hipFree(c->f.bv);
   (void)hipFree(c->f.buckets);
   (void)hipFree(c->d_super);
-  (void)hipFree(c->f.counts);
+  (void)hipFree(c->f.far);
   (void)hipFree(c->f.ovf_keys);
   (void)hipFree(c->f.ovf_ids);
   if (c->h_tiles) {
@@ -1352,12 +1353,12 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
     return set_err(c, GRP_ERR_STATE, "grp_finalize: the filter size is not set (grp_set_filter_size)");
   }
   HIP_TRY(c, hipSetDevice(c->device));
-  unsigned long long* d_scalars = nullptr; // [0] pop (popcount), [1] pop (scan), [2] overflow entries
-  HIP_TRY(c, hipMalloc(&d_scalars, 3 * sizeof(unsigned long long)));
-  HIP_TRY(c, hipMemsetAsync(d_scalars, 0, 3 * sizeof(unsigned long long), c->stream));
+  unsigned long long* d_scalars = nullptr; // [0] pop (popcount), [1] pop (scan), [2] overflow entries (IDs), [3] far entries (count words)
+  HIP_TRY(c, hipMalloc(&d_scalars, 4 * sizeof(unsigned long long)));
+  HIP_TRY(c, hipMemsetAsync(d_scalars, 0, 4 * sizeof(unsigned long long), c->stream));
   Timer* t = new Timer(c, GRP_K_RANK, c->n_bv_words);
   k_popcount<<<dim3(4096), dim3(THREADS), 0, c->stream>>>(c->f.bv, c->n_bv_words, d_scalars);
-  unsigned long long h_scalars[3] = { 0, 0, 0 };
+  unsigned long long h_scalars[4] = { 0, 0, 0, 0 };
   HIP_TRY(c, hipMemcpyAsync(h_scalars, d_scalars, sizeof(h_scalars), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const uint64_t h_pop = h_scalars[0];
@@ -1390,10 +1391,14 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
   }
   uint32_t* d_chunk_sum = nullptr;
   uint64_t* d_chunk_base = nullptr;
-  hipError_t e = hipMalloc(&c->f.buckets, c->f.n_buckets * 64);
+  // a bucket is a 128-byte unit since round 5: its query line {rel, bitmap, 13 IDs} and its insert line (8 count words);
+  // the count words of the ranks beyond a bucket's 8th set bit come on top (the far table below, ~5 % of the ranks x 32 B)
+  const uint64_t unit_bytes = (uint64_t)GRP_UNIT_U4 * 16;
+  hipError_t e = hipMalloc(&c->f.buckets, c->f.n_buckets * unit_bytes);
   if (e != hipSuccess) {
     delete t;
-    return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu buckets (%.1f GB) failed: %s", (unsigned long long)c->f.n_buckets, c->f.n_buckets * 64 / 1e9, hipGetErrorString(e));
+    return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu bucket units (%.1f GB: 128 B per %u filter bits, IDs and insert counts included) failed: %s", (unsigned long long)c->f.n_buckets, c->f.n_buckets * unit_bytes / 1e9, W,
+                   hipGetErrorString(e));
   }
   HIP_TRY(c, hipMalloc(&c->d_super, c->nsb * sizeof(uint64_t)));
   c->f.super = c->d_super;
@@ -1415,11 +1420,21 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
   (void)hipFree(c->f.bv); // the bits now live in the buckets
   c->f.bv = nullptr;
   c->f.pop = h_pop;
-  e = hipMalloc(&c->f.counts, std::max<uint64_t>(h_pop, 1) * sizeof(unsigned long long));
-  if (e != hipSuccess) {
-    return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu insert counts failed: %s", (unsigned long long)h_pop, hipGetErrorString(e));
+  {
+    // the count words beyond a bucket's 8th set bit: {rank + 1, word}, open addressing at load <= 1/2, keys written now
+    const uint64_t far_cap = next_pow2_64(std::max<uint64_t>(2 * h_scalars[3], 1024));
+    e = hipMalloc(&c->f.far, far_cap * sizeof(ulonglong2));
+    if (e != hipSuccess) {
+      return set_err(c, GRP_ERR_NOMEM, "hipMalloc of the far count table (%llu ranks beyond their bucket's 8th set bit, %.1f GB) failed: %s", h_scalars[3], far_cap * sizeof(ulonglong2) / 1e9, hipGetErrorString(e));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->f.far, 0, far_cap * sizeof(ulonglong2), c->stream));
+    c->f.far_mask = far_cap - 1;
+    c->n_far = h_scalars[3];
+    if (h_scalars[3]) {
+      k_far_build<<<dim3((uint32_t)std::min<uint64_t>((c->f.n_buckets + THREADS - 1) / THREADS, 65536)), dim3(THREADS), 0, c->stream>>>(c->f);
+      HIP_TRY(c, hipGetLastError());
+    }
   }
-  HIP_TRY(c, hipMemsetAsync(c->f.counts, 0, std::max<uint64_t>(h_pop, 1) * sizeof(unsigned long long), c->stream));
   const uint64_t ovf_cap = next_pow2_64(std::max<uint64_t>(2 * h_scalars[2], 1024));
   HIP_TRY(c, hipMalloc(&c->f.ovf_keys, ovf_cap * sizeof(unsigned long long)));
   HIP_TRY(c, hipMalloc(&c->f.ovf_ids, ovf_cap * sizeof(uint32_t)));
@@ -2542,7 +2557,7 @@ grp_reset_ids(grp_ctx* c)
   HIP_TRY(c, hipSetDevice(c->device));
   k_reset_bucket_ids<<<dim3(65536), dim3(THREADS), 0, c->stream>>>(c->f.buckets, c->f.n_buckets);
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemsetAsync(c->f.counts, 0, std::max<uint64_t>(c->f.pop, 1) * sizeof(unsigned long long), c->stream));
+  k_far_reset<<<dim3(4096), dim3(THREADS), 0, c->stream>>>(c->f.far, c->f.far_mask + 1); // (the insert lines went with the IDs above)
   c->batch.epoch = 0; // (the claims are gone with the counts)
   HIP_TRY(c, hipMemsetAsync(c->f.ovf_keys, 0, (c->f.ovf_mask + 1) * sizeof(unsigned long long), c->stream));
   HIP_TRY(c, hipMemsetAsync(c->f.ovf_ids, 0, (c->f.ovf_mask + 1) * sizeof(uint32_t), c->stream));

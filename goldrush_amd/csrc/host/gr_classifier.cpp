@@ -422,6 +422,9 @@ Classifier::wait_record(const StreamFlight& f, uint32_t j)
       finished_seen = st == 1; // one more round of spinning for the last store to land
     }
   }
+  if (lost_at_ == (uint64_t)base_ + f.pos + j) {
+    lost_at_ = UINT64_MAX; // the window begun again has decided the read: a later idle exit at the same index of ANOTHER run() is a new event
+  }
   return GRP_OK;
 }
 
@@ -1674,6 +1677,7 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
     return GRP_OK;
   }
   base_ = first;
+  lost_at_ = UINT64_MAX;  // (reads are numbered from the range's own first: an index of the range before means nothing here)
   ovl_base_ = UINT64_MAX; // (the overlap hints of the range before are another batch's)
   rg_.reads = reads;
   rg_.lens = lens + first;

@@ -29,6 +29,7 @@ InputFile::InputFile(const std::string& path)
       if (k >= 0 && !(k == 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {
         fd_ = fd;
         size_ = (uint64_t)st.st_size;
+        opened_ = true;
         return;
       }
     }
@@ -39,6 +40,7 @@ InputFile::InputFile(const std::string& path)
     gzbuffer(f, 1u << 20);
   }
   f_ = f;
+  opened_ = f != nullptr;
 }
 
 InputFile::~InputFile()
@@ -162,6 +164,17 @@ InputFile::read(char* dst, size_t n)
       break;
     }
     if (r == 0) {
+      // the end of the data — or of a gzip member that was cut off: zlib hands out what it could inflate and then
+      // reports 0 bytes like at a proper end.  gzerror says Z_BUF_ERROR when the cut was met inside this
+      // call, gzclose_r when an earlier call swallowed it; a stream that did not end on a complete member is an error.
+      int zerr = 0;
+      const char* msg = gzerror(static_cast<gzFile>(f_), &zerr);
+      const std::string why = (zerr != Z_OK && msg && *msg) ? msg : "";
+      const int rc = gzclose_r(static_cast<gzFile>(f_));
+      f_ = nullptr;
+      if (zerr != Z_OK || rc != Z_OK) {
+        note_input_failure("reading " + path_ + " failed: " + (why.empty() ? "the compressed stream ends early (truncated gzip data)" : why));
+      }
       break;
     }
     got += (size_t)r;

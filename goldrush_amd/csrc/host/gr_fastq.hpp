@@ -28,13 +28,14 @@ public:
   ~InputFile();
   InputFile(const InputFile&) = delete;
   InputFile& operator=(const InputFile&) = delete;
-  bool ok() const { return f_ != nullptr || fd_ >= 0; }
+  bool ok() const { return opened_; } // the file could be opened (it stays true behind the end of the data)
   size_t read(char* dst, size_t n); // 0 at the end of the data (or on a read error)
   int peek();                      // next byte without consuming it, -1 at the end
   uint64_t plain_size() const { return size_; } // bytes of a plain regular file, 0: unknown (gzip data, a pipe)
 
 private:
-  void* f_ = nullptr; // gzFile
+  void* f_ = nullptr; // gzFile; closed (nullptr) once the data has ended, so that a truncated stream is noticed
+  bool opened_ = false;
   int fd_ = -1;       // plain regular file
   uint64_t off_ = 0;  // ... and the read position in it
   uint64_t size_ = 0;

@@ -183,6 +183,38 @@ def test_a_garbage_line_ends_the_input_for_good_whatever_the_batching(oracle, na
     assert outs["cut"] and all(v == outs["cut"] for v in outs.values())
 
 
+@pytest.mark.parametrize("ingest", [False, True])
+def test_a_truncated_gzip_file_is_an_error_not_a_shorter_input(oracle, native, tmp_path, ingest):
+    """zlib hands out what it could inflate of a gzip file that was cut off and then reports the end of the
+    data like at a proper end — the run must end with an error instead of classifying a prefix of the reads (host reader
+    and the chunked source of the GPU ingest alike); the complete file passes."""
+    import gzip
+
+    raw = open(os.path.join(GOLD, "tiny.fq"), "rb").read()
+    whole = tmp_path / "whole.fq.gz"
+    cutoff = tmp_path / "cutoff.fq.gz"
+    whole.write_bytes(gzip.compress(raw))
+    z = whole.read_bytes()
+    cutoff.write_bytes(z[: len(z) // 2])
+    common = ["-k22", "-w16", "-t500", "-u5", "-a1", "-o0.1", "-h3", "-j2", "-d5", "-x10", "-s1011011110110111101101", "-g60000", "-b4", "-H600000", "-P12", "-m0"]
+    script = tmp_path / "runner.py"
+    script.write_text(RUNNER.format(root=ROOT))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    if ingest:
+        env.update(ORACLE_ENGINE_INGEST="1", GRP_INGEST_CHUNK="65536")
+    else:
+        env.update(GRP_HOST_INGEST="1")
+    rcs = {}
+    for name, path in (("whole", whole), ("cutoff", cutoff)):
+        d = tmp_path / name
+        d.mkdir()
+        rp = subprocess.run([sys.executable, str(script)] + common + ["-i", str(path), "-p", str(d / "out")], capture_output=True, text=True, timeout=900, env=env)
+        rcs[name] = (rp.returncode, rp.stderr)
+    assert rcs["whole"][0] == 0, rcs["whole"][1][-2000:]
+    assert rcs["cutoff"][0] != 0, "a truncated gzip file passed for a shorter input"
+    assert "failed" in rcs["cutoff"][1] and "cutoff.fq.gz" in rcs["cutoff"][1], rcs["cutoff"][1][-2000:]
+
+
 @pytest.mark.parametrize("mode", ["silver", "golden"])
 def test_debug_output_matches_the_oracle(oracle, native, tmp_path, mode):
     """--debug (goldrush_path.cpp:60-70, 109-124, 267-273, 907-1086): the Phred lines of the fill

@@ -17,6 +17,33 @@
 //   mode 16: quad reads a 64-B line of A, one lane writes 4 B of it back (a dirty random line)
 //   mode 20: mode 10's random lines in the loop shape of modes 11 / 17 / 18 (their reference)
 //   mode 19: random u32 load from table B, one per lane, keyed like a Bloom look-up (same as 1, kept for the tables)
+// Round 5 (where a rank's insert count should live, DESIGN 5c "collect"): one item = one record of k_batch_collect
+//   mode 21: TODAY: 16-B header of a random 64-B bucket of A, then (dependent) CAS u64 on a random word of B
+//            (the rank's count | claim), then 4 B of the bucket written back (the ID)
+//   mode 22: UNIT: A as 128-B units {bucket line, count line}: header of line 0 and claim word of line 1 loaded
+//            together, CAS u64 on the claim word, returning atomicAdd u32 on a count of line 1, 4 B of line 0 written
+//   mode 23: like 22 without the atomicAdd (claim and count in one CAS word of line 1)
+//   mode 27: like 23 plus a plain load and a plain store of a u32 count in line 1 (the claim is per BUCKET, its winner
+//            owns the slot: the count needs no atomic)
+//   mode 30: like 23 with the count line GB_L1OFF bytes (a power of two >= 64) behind its bucket line: A in blocks of
+//            2 x GB_L1OFF bytes, first half bucket lines, second half their count lines (is the unit's gain the shared
+//            DRAM page or the shared address translation?)
+//   mode 31: mode 10's quad read of the bucket lines of that blocked layout
+//   mode 32: like 23, but the count word's address DEPENDS on the header (its slot = the set bit's index): header,
+//            then atomic load of the word, then CAS — the shape of k_batch_collect
+//   mode 33: like 32 with a plain load of line 1 issued together with the header (a prefetch), the word itself read
+//            with a plain load behind the header
+//   mode 34: like 33, the ID slot read back behind the CAS (as the owner's touch does) and three 8-byte record words
+//            written per item at a fixed index (coalesced)
+//   mode 35: 33 + the read-back only; mode 36: 33 + the record words only; mode 37: 34 with the ID slot read IN FRONT of the CAS
+//   mode 50: the record shape by its parts (env GB_SHAPE, a bit mask): header of line 0, count word of line 1 (slot from the
+//            header), CAS, the ID slot of line 0 read and written, three record words.  bit 0: no load in front of the CAS
+//            (it succeeds at once); bit 1: the ID by atomicExch instead of load + store; bit 2: the ID loaded in front of
+//            the CAS (with the count word); bit 3: the ID stored write-through (agent scope); bit 4: no record words;
+//            bit 5: the header through two agent-scope 8-byte loads; bit 6: ID store skipped (a touch that does not write)
+//   mode 24: mode 10's quad read of a 64-B line where the lines lie 128 B apart (the query on the unit layout)
+//   mode 25: one 128-B unit read whole by 8 lanes, one lane writes 4 B into each half
+//   mode 26: like 21 with the count word in a SEPARATE line of a bucket-indexed table B (64 B per bucket, same index)
 // usage: gather_bench <tableA_MiB> <tableB_MiB> <items_per_lane> <mode> [unroll] [workgroups]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -166,6 +193,223 @@ __global__ void __launch_bounds__(256) k_gather(const uint4* __restrict__ A, uin
           }
         }
       }
+    } else if (mode == 21 || mode == 26) {
+      const uint64_t nb = nA / 4;
+      uint32_t* W = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(A));
+      unsigned long long* T = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(B));
+      unsigned long long v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) va[u] = A[(ia[u] % nb) * 4];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 13);
+        const uint64_t ib = (mode == 21) ? (mix64(ia[u] ^ va[u].x) % nB) : (((ia[u] % nb) * 8 + (lr & 7u)) % nB);
+        v[u] = atomicCAS(&T[ib], 0x0202020202020202ULL, 0x0202020202020202ULL + (va[u].z & 1u));
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 13);
+        W[(ia[u] % nb) * 16 + 3 + lr] = (uint32_t)v[u] | 1u;
+        acc += v[u];
+      }
+    } else if (mode == 22 || mode == 23 || mode == 27) {
+      const uint64_t nu = nA / 8; // 128-B units
+      uint32_t* W = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(A));
+      unsigned long long* T = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(A));
+      unsigned long long cw[UNR], v[UNR];
+      uint32_t c[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        va[u] = A[(ia[u] % nu) * 8];
+        cw[u] = __hip_atomic_load(&T[(ia[u] % nu) * 16 + 15], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = atomicCAS(&T[(ia[u] % nu) * 16 + 15], cw[u], cw[u] + (va[u].z & 1u));
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 13);
+        c[u] = (mode == 22) ? atomicAdd(&W[(ia[u] % nu) * 32 + 16 + lr], 1u) : (mode == 27) ? W[(ia[u] % nu) * 32 + 16 + lr] : 0u;
+      }
+      if (mode == 27) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 13);
+          W[(ia[u] % nu) * 32 + 16 + lr] = c[u] + 1u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 13);
+        W[(ia[u] % nu) * 32 + 3 + lr] = (uint32_t)v[u] | c[u] | 1u;
+        acc += v[u];
+      }
+    } else if (mode >= 32 && mode <= 37) {
+      const uint64_t nu = nA / 8; // 128-B units
+      uint32_t* W = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(A));
+      unsigned long long* T = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(A));
+      unsigned long long* R = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(B));
+      unsigned long long cw[UNR], v[UNR], pf[UNR];
+      uint32_t idv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        va[u] = A[(ia[u] % nu) * 8];
+        pf[u] = (mode >= 33) ? T[(ia[u] % nu) * 16 + 8] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 8);
+        unsigned long long* q = &T[(ia[u] % nu) * 16 + 8 + lr];
+        cw[u] = (mode >= 33) ? *q : __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 8);
+        v[u] = atomicCAS(&T[(ia[u] % nu) * 16 + 8 + lr], cw[u], cw[u] + (va[u].z & 1u) + (pf[u] & 0u));
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 8);
+        // 34 / 35: the ID slot read back behind the CAS; 37: read in front of it (with the count word)
+        idv[u] = (mode == 34 || mode == 35) ? W[(ia[u] % nu) * 32 + 3 + lr + (uint32_t)(v[u] & 0ull)] : (mode == 37) ? W[(ia[u] % nu) * 32 + 3 + lr + (uint32_t)(cw[u] & 0ull)] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 8);
+        W[(ia[u] % nu) * 32 + 3 + lr] = (uint32_t)v[u] | idv[u] | 1u;
+        if (mode == 34 || mode == 36 || mode == 37) {
+          const uint64_t ridx = ((uint64_t)(it + u) * gridDim.x * blockDim.x + gid) % (nB / 3);
+          R[ridx] = v[u];
+          R[nB / 3 + ridx] = cw[u];
+          R[2 * (nB / 3) + ridx] = idv[u];
+        }
+        acc += v[u];
+      }
+    } else if (mode == 50) {
+      const uint32_t shape = (uint32_t)lines_per_region; // GB_SHAPE rides here
+      const uint64_t nu = nA / 8;
+      uint32_t* W = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(A));
+      unsigned long long* T = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(A));
+      unsigned long long* R = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(B));
+      unsigned long long cw[UNR], v[UNR];
+      uint32_t idv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (shape & 32u) {
+          const unsigned long long a = __hip_atomic_load(&T[(ia[u] % nu) * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long b = __hip_atomic_load(&T[(ia[u] % nu) * 16 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          va[u] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+        } else {
+          va[u] = A[(ia[u] % nu) * 8];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 8);
+        cw[u] = (shape & 1u) ? 0x0101010101010101ULL : __hip_atomic_load(&T[(ia[u] % nu) * 16 + 8 + lr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idv[u] = (shape & 4u) ? W[(ia[u] % nu) * 32 + 3 + lr] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 8);
+        v[u] = atomicCAS(&T[(ia[u] % nu) * 16 + 8 + lr], cw[u], cw[u] + (va[u].z & 0u));
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 8);
+        uint32_t* p = &W[(ia[u] % nu) * 32 + 3 + lr + (uint32_t)(v[u] & 0ull)];
+        if (shape & 2u) {
+          idv[u] = atomicExch(p, (uint32_t)v[u] | 1u);
+        } else {
+          if (!(shape & 4u)) idv[u] = *p;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 8);
+        uint32_t* p = &W[(ia[u] % nu) * 32 + 3 + lr];
+        if (!(shape & 2u) && !(shape & 64u)) {
+          if (shape & 8u) __hip_atomic_store(p, idv[u] | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *p = idv[u] | 1u;
+        }
+        if (!(shape & 16u)) {
+          const uint64_t ridx = ((uint64_t)(it + u) * gridDim.x * blockDim.x + gid) % (nB / 3);
+          R[ridx] = v[u];
+          R[nB / 3 + ridx] = cw[u];
+          R[2 * (nB / 3) + ridx] = idv[u];
+        }
+        acc += v[u] + idv[u];
+      }
+    } else if (mode == 30) {
+      // region_lines carries GB_L1OFF / 64 here
+      const uint64_t nl = nA / 8; // bucket lines (half the table)
+      const uint64_t per = region_lines; // lines per half block
+      uint32_t* W = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(A));
+      unsigned long long* T = const_cast<unsigned long long*>(reinterpret_cast<const unsigned long long*>(A));
+      unsigned long long cw[UNR], v[UNR];
+      uint64_t l0[UNR], l1[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint64_t b = ia[u] % nl;
+        l0[u] = (b / per) * 2 * per + (b % per); // 64-B line index of the bucket line
+        l1[u] = l0[u] + per;
+        va[u] = A[l0[u] * 4];
+        cw[u] = __hip_atomic_load(&T[l1[u] * 8 + 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) v[u] = atomicCAS(&T[l1[u] * 8 + 7], cw[u], cw[u] + (va[u].z & 1u));
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const uint32_t lr = (uint32_t)((va[u].y ^ ia[u]) % 13);
+        W[l0[u] * 16 + 3 + lr] = (uint32_t)v[u] | 1u;
+        acc += v[u];
+      }
+    } else if (mode == 31) {
+      const uint64_t nl = nA / 8;
+      const uint64_t per = region_lines;
+      const int lane = threadIdx.x & 63;
+      const int sub = lane & 3;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        for (int g = 0; g < 4; ++g) {
+          const uint64_t b = __shfl(ia[u], (lane / 4) * 4 + g, 64) % nl;
+          const uint64_t idx = (b / per) * 2 * per + (b % per);
+          uint4 t = A[idx * 4 + sub];
+          const uint32_t want = (uint32_t)(idx >> 3) % 4u;
+          uint32_t got = __shfl(t.w, (lane / 4) * 4 + want, 64);
+          if (sub == g) acc += got + t.x;
+        }
+      }
+    } else if (mode == 24) {
+      const uint64_t nu = nA / 8;
+      const int lane = threadIdx.x & 63;
+      const int sub = lane & 3;
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        for (int g = 0; g < 4; ++g) {
+          const uint64_t idx = __shfl(ia[u], (lane / 4) * 4 + g, 64) % nu;
+          uint4 t = A[idx * 8 + sub];
+          const uint32_t want = (uint32_t)(idx >> 3) % 4u;
+          uint32_t got = __shfl(t.w, (lane / 4) * 4 + want, 64);
+          if (sub == g) acc += got + t.x;
+        }
+      }
+    } else if (mode == 25) {
+      const uint64_t nu = nA / 8;
+      const int lane = threadIdx.x & 63;
+      const int sub = lane & 7;
+      uint32_t* W = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(A));
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        for (int g = 0; g < 8; ++g) {
+          const uint64_t idx = __shfl(ia[u], (lane & ~7) + g, 64) % nu;
+          const uint4 t = A[idx * 8 + sub];
+          if (sub == g) {
+            acc += t.x;
+            W[idx * 32 + 3 + (ia[u] >> 50) % 13] = (uint32_t)ia[u] | 1u;
+            W[idx * 32 + 16 + (ia[u] >> 50) % 13] = (uint32_t)ia[u] | 1u;
+          }
+        }
+      }
     } else if (mode == 19) {
       uint32_t v[UNR];
 #pragma unroll
@@ -222,9 +466,11 @@ int main(int argc, char** argv)
   CK(hipMemset(A, 1, nA * 16)); CK(hipMemset(B, 2, nB * 8));
   const uint64_t region_bytes = getenv("GB_REGION") ? strtoull(getenv("GB_REGION"), nullptr, 10) : 2048;
   const double density = getenv("GB_DENSITY") ? atof(getenv("GB_DENSITY")) : 0.6;
-  const uint64_t region_lines = region_bytes / 64 ? region_bytes / 64 : 1;
+  uint64_t region_lines = region_bytes / 64 ? region_bytes / 64 : 1;
+  if (mode == 30 || mode == 31) region_lines = (getenv("GB_L1OFF") ? strtoull(getenv("GB_L1OFF"), nullptr, 10) : 64) / 64;
   uint64_t lines_per_region = (uint64_t)(region_lines * density + 0.5);
   if (lines_per_region == 0) lines_per_region = 1;
+  if (mode == 50) lines_per_region = getenv("GB_SHAPE") ? strtoull(getenv("GB_SHAPE"), nullptr, 10) : 0;
   if (mode == 11) { // one sweep of the table: items per lane from the table size
     const uint64_t nquads = (uint64_t)wgs * 256 / 4;
     const uint64_t total = (nA / 4) / region_lines * lines_per_region;
