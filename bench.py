@@ -350,6 +350,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     if a.share_gpu:
         local_rank = 0
+        # the ranks' persistent launches must all be resident on the one device together (their in-launch inserts wait
+        # grid-wide): one workgroup per CU each, unless the caller says otherwise — a plumbing run, not a measurement
+        os.environ.setdefault("GRP_STREAM_WGS_PER_CU", "1")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -384,17 +387,57 @@ def main():
     rs.eng = eng
     rs.get(0)
     t_synth = time.time() - t0
+    # N > 1: the ranks' node-local exchange (libgrpath_host's /dev/shm all-gather, C++: what the goldrush-path binary uses
+    # between its ranks) — opened in front of the fill since round 5: the merge of the sharded fill goes through it too
+    shm = None
+    comm_aux = None
+    if world > 1 and os.path.isdir("/dev/shm") and not os.environ.get("GRP_BENCH_NO_SHM"):
+        key = "bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run"))
+        shm = hl.gr_shm_allgather_open(world, rank, key.encode(), 120.0)
+    if world > 1:
+        # the choice is collective: one rank without the exchange (a timeout, no /dev/shm in its
+        # container) and EVERY rank takes the torch / gloo path — otherwise some ranks would enter
+        # dist.new_group while the others skip it, and the stripe widths would differ per rank
+        flag = torch.tensor([1 if shm else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if shm:
+                hl.gr_shm_allgather_close(shm)
+            shm = None
+            if rank == 0:
+                sys.stderr.write("bench: no /dev/shm exchange on every rank, using torch.distributed for the merge and a gloo group for the records\n")
     t0 = time.time()
     if world == 1:
         for rb_, _, lo_, n_ in rs.pieces(0, n_reads):
             eng.bv_insert(rb_, lo_, n_)
         eng.sync()
+    elif shm:
+        # the fill shards by reads and its merge is a bitwise OR.  THE PRODUCT'S PATH (round 5; what the
+        # goldrush-path binary does between its ranks, csrc/host/gr_ranks.cpp): the ranks agree on how to merge —
+        # RCCL inside the engine (grp_comm_unique_id on rank 0, the id handed round through the shm exchange,
+        # grp_comm_init, grp_bv_merge_ranks: ncclAllToAll of the slices, OR, ncclAllGather — 2 x (N-1)/N of one
+        # vector per rank over xGMI), or, for ranks sharing one device (the plumbing runs of a 1-GPU box), staged
+        # through host memory — torch.distributed is only the launcher here.
+        vt = host.hip_engine_vt()
+        plan = hl.gr_fill_merge_plan(C.byref(vt), eng._h, shm, world, rank, local_rank)
+        if plan == 0:
+            raise SystemExit("bench: the ranks cannot merge a sharded fill (no RCCL communicator and no staged form)")
+        shard = (n_reads + world - 1) // world
+        lo, hi = min(rank * shard, n_reads), min((rank + 1) * shard, n_reads)
+        for rb_, _, lo_, n_ in rs.pieces(lo, hi - lo):
+            eng.bv_insert(rb_, lo_, n_)
+        eng.sync()
+        mrc = hl.gr_fill_merge_run(C.byref(vt), eng._h, shm, world, rank, plan)
+        if mrc != 0:
+            raise SystemExit("bench: merging the ranks' bit vectors failed (%d): %s" % (mrc, (native.load().grp_last_error(eng._h) or b"").decode()))
+        cw, cr, cv, cm = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_uint32()
+        native.load().grp_comm_info(eng._h, C.byref(cw), C.byref(cr), C.byref(cv), C.byref(cm))
+        comm_aux = {"merge": "rccl" if plan == 2 else "staged through host memory (ranks share a device, or no RCCL)", "world": int(cw.value) if plan == 2 else world,
+                    "rccl_version": int(cv.value) or None, "merges_through_grp_bv_merge_ranks": int(cm.value),
+                    "what": "csrc/host/gr_ranks.cpp (gr_fill_merge_plan / _run) over csrc/grp_comm.inc: the goldrush-path binary's own merge"}
     else:
-        # the fill shards by reads and its merge is a bitwise OR.  RCCL has no OR
-        # reduction, so the OR "all-reduce" is spelled out as reduce-scatter + all-gather: slice r
-        # of every rank's vector goes to rank r (all-to-all), rank r ORs them (grp_words_or_device),
-        # the merged slices are all-gathered: 2 x (N-1)/N of one vector per rank over xGMI and one
-        # extra vector of HBM, instead of N-1 whole vectors each way.
+        # no /dev/shm exchange: the same reduce-scatter + all-gather spelled out with torch.distributed (kept as the
+        # fall-back; the product's path is the branch above)
         shard = (n_reads + world - 1) // world
         lo, hi = min(rank * shard, n_reads), min((rank + 1) * shard, n_reads)
         for rb_, _, lo_, n_ in rs.pieces(lo, hi - lo):
@@ -427,15 +470,17 @@ def main():
         torch.cuda.synchronize()
         eng.bv_import_device(mine.data_ptr())
         del got, mine, merged
+        comm_aux = {"merge": "torch.distributed (%s): no /dev/shm exchange between the ranks" % a.backend, "world": world, "rccl_version": None, "merges_through_grp_bv_merge_ranks": 0}
     t_fill = time.time() - t0
     fill_stats = eng.kernel_stats()["fill"]
     t0 = time.time()
     pop = eng.finalize()
     t_finalize = time.time() - t0
+    if world > 1 and shm and hl.gr_ranks_same_u64(shm, world, pop) != 1:
+        raise SystemExit("bench: the ranks' filters differ after the merge (rank %d: %d set bits)" % (rank, pop))
 
     # ---- phase 2: order-exact classification, windows sharded over the ranks ----
     allgather = None
-    shm = None
     if world > 1:
         # The decisions the ranks exchange are tiny (32 B per read, a few KB per call) and
         # already sit in host memory: they go through shared memory (one node) or, failing
@@ -443,21 +488,7 @@ def main():
         # here would need free compute units while the persistent query launch owns the
         # device, and two PCIe copies per call; RCCL is used where bulk data moves (the
         # bit-vector all-gather above).
-        if os.path.isdir("/dev/shm") and not os.environ.get("GRP_BENCH_NO_SHM"):
-            # libgrpath_host's node-local exchange (C++: no Python between the classifier and the other ranks)
-            key = "bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run"))
-            shm = hl.gr_shm_allgather_open(world, rank, key.encode(), 120.0)
-        # the choice is collective: one rank without the exchange (a timeout, no /dev/shm in its
-        # container) and EVERY rank takes the gloo path — otherwise some ranks would enter
-        # dist.new_group while the others skip it, and the stripe widths would differ per rank
-        flag = torch.tensor([1 if shm else 0], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if shm:
-                hl.gr_shm_allgather_close(shm)
-            shm = None
-            if rank == 0:
-                sys.stderr.write("bench: no /dev/shm exchange on every rank, using a gloo group\n")
+        # (the /dev/shm exchange was opened in front of the fill: `shm`)
         if shm:
             # the exchange costs tens of microseconds here, not hundreds: shorter stripes
             # (less speculative work lost per insert) still hide it behind the launches
@@ -658,6 +689,7 @@ def main():
             "aux": {"counters": {k_: int(st1[k_]) for k_ in ("valid_reads", "total_tiles", "assigned_tiles", "unassigned_tiles", "queries", "hits", "misses", "inserted_bases",
                                                              "ids_inserted", "reads_committed", "inserts")},  # the run's result: the same for every N, mode and switch
                     "pop": int(pop),
+                    "comm": comm_aux,  # N > 1: which path merged the ranks' fills (rccl: grp_comm_* / grp_bv_merge_ranks inside the engine), the communicator's size, RCCL's version
                     "fill_reads_per_s": n_reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill, "finalize_s": t_finalize,
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors OR-merged as reduce-scatter (all-to-all + OR) + all-gather" % world, "synth_s": t_synth,
                     "read_batches": rs.n_batches, "synth_in_timed_region_s": rs.synth_s - synth_before,

@@ -91,6 +91,7 @@ struct QuerySlot
   uint32_t* h_ack = nullptr;    // mapped, coherent: [0] inserts applied by the launch, [1] failure code
   uint32_t* dmap_ack = nullptr;
   bool resumable = false;       // the window in flight takes grp_classify_stream_insert
+  uint32_t stripe_reads = 0, n_owners = 1, owner = 0; // its stripes (0: the whole window is this launch's)
   uint32_t gen = 1;             // generation of the records the host is waiting for
   uint32_t cmd_seq = 0;         // commands posted to the window in flight
   uint32_t* h_stripe_tiles = nullptr; // pinned: this rank's tiles of a striped window
@@ -275,6 +276,7 @@ struct grp_ctx
   // RCCL communicator of a multi-GPU fill (grp_comm.inc), NULL on one GPU
   void* comm = nullptr;
   uint32_t comm_world = 1, comm_rank = 0;
+  uint32_t n_comm_merges = 0; // grp_bv_merge_ranks calls that succeeded
   double* d_delog = nullptr; // 10^(-Q/10) table for the FASTQ ingest
   // buffers of the FASTQ ingest, kept between chunks (round 4: a chunk used to pay seven hipMalloc / hipFree pairs,
   // 256 MiB of text among them — every hipFree waits for the device)
@@ -2047,6 +2049,44 @@ grp_classify_stream_begin_resumable(grp_ctx* c, const grp_reads* r, uint32_t fir
   return stream_begin_impl(c, r, first, count, dp, slot, 0, 1, 0, decisions, true);
 }
 
+int
+grp_classify_stream_begin_striped_resumable(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions)
+{
+  return stream_begin_impl(c, r, first, count, dp, slot, stripe_reads, n_owners, owner, decisions, true);
+}
+
+int
+grp_classify_stream_insert_done(grp_ctx* c, uint32_t slot)
+{
+  if (!c || slot > 1 || !c->slot[slot].busy || !c->slot[slot].streaming) {
+    return set_err(c, GRP_ERR_STATE, "grp_classify_stream_insert_done: no streaming window in this slot");
+  }
+  QuerySlot& sl = c->slot[slot];
+  if (__atomic_load_n(&sl.h_ack[0], __ATOMIC_ACQUIRE) == sl.cmd_seq) {
+    return 1;
+  }
+  if (__atomic_load_n(&sl.h_ack[1], __ATOMIC_ACQUIRE) != 0) {
+    return 2;
+  }
+  const hipError_t e = hipEventQuery(sl.done);
+  if (e == hipSuccess) {
+    return __atomic_load_n(&sl.h_ack[0], __ATOMIC_ACQUIRE) == sl.cmd_seq ? 1 : 2;
+  }
+  if (e != hipErrorNotReady) {
+    return set_err(c, GRP_ERR_HIP, "grp_classify_stream_insert_done: %s", hipGetErrorString(e));
+  }
+  return 0;
+}
+
+int
+grp_classify_stream_resumable(grp_ctx* c, uint32_t slot)
+{
+  if (!c || slot > 1 || !c->slot[slot].busy || !c->slot[slot].streaming) {
+    return 0;
+  }
+  return c->slot[slot].resumable ? 1 : 0;
+}
+
 static int
 stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions, bool want_resumable)
 {
@@ -2164,7 +2204,7 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
   }
   // reads without a single tile are never completed by a workgroup: decided here
   memset(sl.h_sdec, 0, (size_t)count * sizeof(grp_read_decision));
-  uint32_t n_decidable = 0;
+  uint32_t n_decidable = 0; // ... of THIS launch: a striped window completes when its own stripes' reads are decided
   uint64_t max_tiles_read = 0;
   for (uint32_t j = 0; j < count; ++j) {
     const uint64_t ntj = r->tile0[first + j + 1] - r->tile0[first + j];
@@ -2174,7 +2214,7 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
       gr::core::decide(dp->threshold, dp->unassigned_min, dp->assigned_max, 0, nullptr, nullptr, nullptr, nullptr, nullptr, d);
       d.pad = 1;
       sl.h_sdec[j] = d;
-    } else {
+    } else if (!striped || (j / stripe_reads) % n_owners == owner) {
       ++n_decidable;
     }
   }
@@ -2184,7 +2224,7 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
   // window holds its address (the window is then an ordinary one; _insert says so).
   const bool resume_off = c->env_stream_resume_off; // GRP_STREAM_RESUME=off (developer switch / tests, read at grp_create): every window ends where it parks
   sl.resumable = false;
-  if (want_resumable && !striped && !resume_off && n_mine != 0) {
+  if (want_resumable && !resume_off && n_mine != 0) {
     const uint64_t need_ranks = max_tiles_read * c->params.tile * c->params.h;
     const bool other_streaming = c->slot[slot ^ 1u].busy && c->slot[slot ^ 1u].streaming;
     if (next_pow2_64(need_ranks * 2) <= c->ir_cap || !other_streaming) {
@@ -2197,6 +2237,9 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
   }
   sl.gen = 1;
   sl.cmd_seq = 0;
+  sl.stripe_reads = striped ? stripe_reads : 0;
+  sl.n_owners = n_owners;
+  sl.owner = owner;
   __atomic_store_n(sl.h_abort, 0u, __ATOMIC_RELEASE);
   sl.reads = r;
   sl.first = first;
@@ -2245,6 +2288,7 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
     sc.n_decidable = n_decidable;
     if (sl.resumable) {
       sc.ctl = sl.d_sctl;
+      sc.cmd_while_busy = striped ? 1u : 0u;
       sc.cmd_host = sl.dmap_cmd;
       sc.ack_host = sl.dmap_ack;
       sc.tb = InsertTable{ c->d_ir_keys, c->d_ir_masks, c->d_ir_locs, c->d_ir_slots, c->d_ir_counter, c->ir_cap - 1 };
@@ -2357,12 +2401,12 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
                     sl.h_ack[8], sl.h_ack[9], sl.h_ack[10], (unsigned long long)sl.nt, sl.h_ack[11], sl.h_ack[12], sl.h_ack[13], sl.count, sl.gen, sl.cmd_seq, applied, first_open);
     }
     if (applied != sl.cmd_seq) {
-      // The launch ended without the insert posted last (an abort overtook it, or the first
-      // grid-wide wait timed out: the device is shared).  Only the scratch table may have been
+      // The launch ended without the insert posted last (an abort overtook it or the launch had left already: 1; the
+      // first grid-wide wait timed out, the device is shared: 2).  Only the scratch table may have been
       // touched; the caller applies the insert with grp_insert_read.
       HIP_TRY(c, hipMemsetAsync(c->d_ir_keys, 0, c->ir_cap * 8, c->stream));
       HIP_TRY(c, hipMemsetAsync(c->d_ir_masks, 0, c->ir_cap * 8, c->stream));
-      return 1;
+      return code == 1 ? 2 : 1;
     }
   }
   return GRP_OK;
@@ -2411,9 +2455,14 @@ grp_classify_stream_insert(grp_ctx* c, uint32_t slot, uint32_t read_idx, uint32_
     __builtin_ia32_pause();
   }
   const uint32_t x = read_idx - sl.first;
-  uint32_t decided_base = 0;
+  uint32_t decided_base = 0; // this launch's decidable reads up to the insert, and its tiles up to there (= where its dispenser starts over)
+  uint64_t resume_tile = 0;
   for (uint32_t j = 0; j <= x; ++j) {
-    decided_base += r->tile0[sl.first + j + 1] != r->tile0[sl.first + j];
+    if (sl.stripe_reads == 0 || (j / sl.stripe_reads) % sl.n_owners == sl.owner) {
+      const uint64_t ntj = r->tile0[sl.first + j + 1] - r->tile0[sl.first + j];
+      decided_base += ntj != 0;
+      resume_tile += ntj;
+    }
   }
   const uint32_t gen = ++sl.gen;
   for (uint32_t j = x + 1; j < sl.count; ++j) { // the host's own records (reads without tiles) move to the new generation
@@ -2429,7 +2478,7 @@ grp_classify_stream_insert(grp_ctx* c, uint32_t slot, uint32_t read_idx, uint32_
   w[4] = first_id;
   w[5] = id_offset;
   w[6] = x + 1;
-  w[7] = (uint32_t)(r->tile0[read_idx + 1] - sl.t0);
+  w[7] = (uint32_t)resume_tile;
   w[8] = decided_base;
   w[9] = gen;
   __atomic_store_n(&sl.h_cmd[0], ++sl.cmd_seq, __ATOMIC_RELEASE);

@@ -332,8 +332,50 @@ Classifier::launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, 
   // One rank: a window that waits where it parks and applies the insert the host commits inside its own
   // launch (stream_round; a silver-path run resets the ID array at a rollover: commit() ends the launches in
   // front of that insert); several ranks share a window in stripes: those windows end where they park.
-  const bool resumable = can_resume();
-  int rc = resumable ? vt_.stream_begin_resumable(ctx_, reads, base_ + pos, S, &dp, slot, &dec) : vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, stripe_reads(), p_.world, p_.rank, &dec);
+  bool resumable = can_resume();
+  int rc;
+  if (p_.world == 1) {
+    rc = resumable ? vt_.stream_begin_resumable(ctx_, reads, base_ + pos, S, &dp, slot, &dec) : vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, 0, 1, 0, &dec);
+  } else {
+    rc = resumable ? vt_.stream_begin_striped_resumable(ctx_, reads, base_ + pos, S, &dp, slot, stripe_reads(), p_.world, p_.rank, &dec)
+                   : vt_.stream_begin(ctx_, reads, base_ + pos, S, &dp, slot, stripe_reads(), p_.world, p_.rank, &dec);
+    if (vt_.stream_begin_striped_resumable && vt_.stream_resumable) {
+      // What the window can do is the RANKS' matter: one rank whose launch ends where it parks (the runtime refused the
+      // cooperative launch, parked windows switched off after a refused insert) or that cannot begin the window now
+      // (GRP_ERR_BUSY) — and every rank takes that form, or they would walk different stripes of different windows.
+      // Every rank calls this at the same point of the same sequence of records, whatever its own call returned.
+      uint32_t mine[2] = { rc == GRP_OK ? 0u : rc == GRP_ERR_BUSY ? 1u : 2u, (rc == GRP_OK && resumable && vt_.stream_resumable(ctx_, slot) == 1) ? 1u : 0u };
+      std::vector<uint32_t> all((size_t)2 * p_.world);
+      if (!allgather_cb_ || allgather_cb_(ag_user_, mine, sizeof(mine), all.data()) != 0) {
+        err_ = "allgather callback failed";
+        if (rc == GRP_OK) {
+          (void)vt_.stream_abort(ctx_, slot);
+          (void)vt_.stream_end(ctx_, slot, nullptr);
+        }
+        return GRP_ERR_INVALID;
+      }
+      uint32_t worst = 0;
+      bool all_resumable = true;
+      for (uint32_t q = 0; q < p_.world; ++q) {
+        worst = std::max(worst, all[(size_t)2 * q]);
+        all_resumable = all_resumable && all[(size_t)2 * q + 1] != 0;
+      }
+      if (worst != 0) {
+        if (rc == GRP_OK) { // another rank could not: this rank's window goes as well
+          (void)vt_.stream_abort(ctx_, slot);
+          (void)vt_.stream_end(ctx_, slot, nullptr);
+        }
+        if (worst == 1 && (rc == GRP_OK || rc == GRP_ERR_BUSY)) {
+          return GRP_ERR_BUSY;
+        }
+        if (rc == GRP_OK) {
+          err_ = "stream_begin failed on another rank";
+          return GRP_ERR_STATE;
+        }
+      }
+      resumable = all_resumable;
+    }
+  }
   if (rc != GRP_OK) {
     err_ = std::string("stream_begin: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
     return rc;
@@ -359,12 +401,15 @@ Classifier::end_stream(StreamFlight& f)
   f.active = false;
   uint32_t decided = 0;
   int rc = vt_.stream_end(ctx_, f.slot, &decided);
-  if (rc == 1) {
-    // the launch ended without the insert it had been handed (its workgroups were not all
-    // resident — a shared device — or an abort overtook it): nothing was inserted; the classic
-    // call applies it, stream-ordered behind whatever is queued, and windows end at inserts again
-    resume_disabled_ = true;
-    resume_clean_windows_ = 0;
+  if (rc == 1 || rc == 2) {
+    // the launch ended without the insert it had been handed: nothing was inserted; the classic call applies it,
+    // stream-ordered behind whatever is queued.  2 (one rank: also 1): its workgroups were not all resident — a shared
+    // device — and windows end at inserts again for a while; 1 with several ranks: the launch had left before the
+    // command came (its own stripes were decided, the inserting read was another rank's) — nothing is wrong
+    if (rc == 2 || p_.world == 1) {
+      resume_disabled_ = true;
+      resume_clean_windows_ = 0;
+    }
     ++n_stream_insert_fallbacks_;
     rc = GRP_OK;
     if (f.ins_posted) {
@@ -844,29 +889,54 @@ Classifier::stream_decision(uint32_t j, gr_read_decision& d)
     }
     return e;
   }
-  const uint32_t C = stripe_reads(), GW = C * W;
+  // A rank's block of the exchange: its stripe's C records behind one header record — .kind of the header != 0: this
+  // rank's launch has left without a record it owes (wait_record: STREAM_LOST).  Every rank then ends the round at this
+  // read, together: the ranks walk one sequence of records, whatever happens to one launch (round 5; a window of
+  // several ranks used to end at every insert, so a launch could not be lost behind one).
+  const uint32_t C = stripe_reads(), GW = C * W, CB = C + 1;
   if (group_base_ == UINT32_MAX || j < group_base_ || j >= group_base_ + GW) {
     group_base_ = (j / GW) * GW;
     const uint32_t lo = std::min(group_base_ + p_.rank * C, S), hi = std::min(lo + C, S);
-    stripe_send_.assign(C, gr_read_decision{});
-    for (uint32_t q = lo; q < hi; ++q) {
+    stripe_send_.assign(CB, gr_read_decision{});
+    int lost = GRP_OK;
+    if (ins_lost_) {
+      stripe_send_[0].kind = 1;
+      lost = STREAM_LOST;
+    }
+    for (uint32_t q = std::max(lo, group_from_); q < hi && lost == GRP_OK; ++q) { // (reads below group_from_ are committed: the group is gathered again behind an insert the launches applied)
       const int e = wait_record(scur_, q);
+      if (e == STREAM_LOST) {
+        lost = e;
+        stripe_send_[0].kind = 1;
+        break;
+      }
       if (e != GRP_OK) {
         return e;
       }
-      stripe_send_[q - lo] = scur_.dec[q];
+      stripe_send_[1 + q - lo] = scur_.dec[q];
       const uint32_t kind = scur_.dec[q].kind;
       if (kind == DEC_INSERT_WHOLE || kind == DEC_INSERT_TRIMMED || kind == 0) {
         break; // the launch parks itself behind such a record: later records of the stripe never come, and no rank reads them
       }
     }
-    stripe_recv_.resize(GW);
-    if (allgather_cb_(ag_user_, stripe_send_.data(), (uint64_t)C * sizeof(gr_read_decision), stripe_recv_.data()) != 0) {
+    stripe_recv_.resize((size_t)CB * W);
+    if (allgather_cb_(ag_user_, stripe_send_.data(), (uint64_t)CB * sizeof(gr_read_decision), stripe_recv_.data()) != 0) {
       err_ = "allgather callback failed";
       return GRP_ERR_INVALID;
     }
+    ins_unconfirmed_ = false;
+    for (uint32_t q = 0; q < W; ++q) {
+      if (stripe_recv_[(size_t)q * CB].kind != 0) {
+        lost = STREAM_LOST;
+      }
+    }
+    if (lost != GRP_OK) {
+      group_base_ = UINT32_MAX;
+      return lost;
+    }
   }
-  d = stripe_recv_[j - group_base_];
+  const uint32_t g = j - group_base_;
+  d = stripe_recv_[(size_t)(g / C) * CB + 1 + g % C];
   return GRP_OK;
 }
 
@@ -949,7 +1019,11 @@ Classifier::want_batch() const
 bool
 Classifier::can_resume() const
 {
-  return vt_.stream_begin_resumable && vt_.stream_insert && vt_.insert_read && p_.world == 1 && !resume_disabled_;
+  // (round 5: several ranks too — every rank's launch applies the insert on its replica, parked by the command where the
+  // inserting read is another rank's; the ranks agree per window that all of them can, launch_stream)
+  static const bool ranks_off = getenv("GRP_STREAM_RESUME_RANKS") && !strcmp(getenv("GRP_STREAM_RESUME_RANKS"), "off"); // developer switch: round 4's form, windows of several ranks end at inserts
+  const bool entry = p_.world == 1 ? vt_.stream_begin_resumable != nullptr : (vt_.stream_begin_striped_resumable && vt_.stream_resumable && vt_.stream_insert_done && !ranks_off);
+  return entry && vt_.stream_insert && vt_.insert_read && !resume_disabled_;
 }
 
 // The size of the next batch.  A read decides differently in a batch when it overlaps a read
@@ -1476,6 +1550,9 @@ Classifier::stream_round(uint32_t& pos)
   }
   const uint32_t S = scur_.S;
   group_base_ = UINT32_MAX;
+  group_from_ = 0;
+  ins_lost_ = false;
+  ins_unconfirmed_ = false;
   uint32_t j = 0;
   bool stale = false, redo = false, lost = false, next_refused = false;
   // developer hook: where the time of an insert goes (launch call, first record, drain + insert)
@@ -1563,6 +1640,31 @@ Classifier::stream_round(uint32_t& pos)
     if (resume) {
       stream_ins_ = nullptr;
       stale = !stream_ins_ok_; // the engine refused (the launches were aborted, the insert queued behind them)
+      if (!stale && p_.world > 1) {
+        // the launches carry on behind the read under the next generation: the rest of its stripe group is exchanged again
+        group_base_ = UINT32_MAX;
+        group_from_ = j + 1;
+        ins_unconfirmed_ = true;
+        // This rank's launch may have left before the command came (its own stripes were decided; the read is another
+        // rank's): then the window queued behind it must not go on unnoticed on a replica without the insert.  The launch
+        // answers within the time the owner's launch takes to apply it (the ranks wait for its next record anyway).
+        for (;;) {
+          const int st = vt_.stream_insert_done(ctx_, scur_.slot);
+          if (st == 1) {
+            break;
+          }
+          if (st == 2) {
+            ins_lost_ = true; // said in the next exchange: every rank ends the round there (end_stream applies the insert the classic way)
+            break;
+          }
+          if (st < 0) {
+            rc = st;
+            err_ = std::string("stream_insert_done: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
+            break;
+          }
+          __builtin_ia32_pause();
+        }
+      }
       if (trace_abort && !stale) {
         tr_resume0 = now();
         tr_resume_pending = true;
@@ -1580,6 +1682,21 @@ Classifier::stream_round(uint32_t& pos)
     }
   }
   pos += j;
+  if (rc == GRP_OK && p_.world > 1 && ins_unconfirmed_ && !lost) {
+    // the window's last record was an insert the launches took: one more exchange, of the headers alone — a rank whose
+    // launch had left before the command must not begin the next window by itself while the others carry on with theirs
+    gr_read_decision mine{};
+    mine.kind = ins_lost_ ? 1u : 0u;
+    std::vector<gr_read_decision> all(p_.world);
+    if (allgather_cb_(ag_user_, &mine, sizeof(mine), all.data()) != 0) {
+      err_ = "allgather callback failed";
+      rc = GRP_ERR_INVALID;
+    }
+    for (uint32_t q = 0; q < p_.world && rc == GRP_OK; ++q) {
+      lost = lost || all[q].kind != 0;
+    }
+    ins_unconfirmed_ = false;
+  }
   if (rc != GRP_OK || stale || finished_ || redo || lost) {
     const auto tr_d0 = now();
     const int drc = drop_streams();

@@ -82,6 +82,11 @@ hip_engine()
   vt.stream_insert = [](void* c, uint32_t slot, uint32_t read, uint32_t ts, uint32_t te, uint32_t block, uint32_t first_id, uint32_t off, uint32_t* gen) {
     return grp_classify_stream_insert(static_cast<grp_ctx*>(c), slot, read, ts, te, block, first_id, off, gen);
   };
+  vt.stream_begin_striped_resumable = [](void* c, const void* r, uint32_t first, uint32_t count, const grp_decide_params* dp, uint32_t slot, uint32_t stripe, uint32_t n_owners, uint32_t owner, const grp_read_decision** dec) {
+    return grp_classify_stream_begin_striped_resumable(static_cast<grp_ctx*>(c), static_cast<const grp_reads*>(r), first, count, dp, slot, stripe, n_owners, owner, dec);
+  };
+  vt.stream_resumable = [](void* c, uint32_t slot) { return grp_classify_stream_resumable(static_cast<grp_ctx*>(c), slot); };
+  vt.stream_insert_done = [](void* c, uint32_t slot) { return grp_classify_stream_insert_done(static_cast<grp_ctx*>(c), slot); };
   return vt;
 }
 

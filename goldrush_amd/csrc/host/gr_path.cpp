@@ -770,33 +770,14 @@ fill_bit_vector(PathRun& run, Resident& res)
     return run.fail_engine("bit-vector insert");
   }
   if (run.shard_fill) {
-    // the bitwise OR of the ranks' vectors (the fill is order-free)
-    if (run.merge_rccl) {
-      if (run.vt.bv_merge_ranks(run.ctx) != GRP_OK) {
-        return run.fail_engine("merging the bit vectors of the ranks (RCCL)");
-      }
-    } else {
-      uint64_t n_words = 0;
-      if (run.vt.bv_words(run.ctx, &n_words) != GRP_OK) {
-        return run.fail_engine("merging the bit vectors of the ranks");
-      }
-      const uint64_t chunk = (1u << 20) / 4; // words per exchange: one slot of the shared-memory all-gather
-      std::vector<uint32_t> mine(chunk), all((size_t)chunk * run.world);
-      for (uint64_t w0 = 0; w0 < n_words; w0 += chunk) {
-        const uint64_t n = std::min<uint64_t>(chunk, n_words - w0);
-        if (run.vt.bv_export_words(run.ctx, w0, n, mine.data()) != GRP_OK) {
-          return run.fail_engine("merging the bit vectors of the ranks");
-        }
-        if (gr_shm_allgather(run.shm, mine.data(), n * 4, all.data()) != 0) {
-          std::cerr << "goldrush-path: the exchange between the ranks failed" << std::endl;
-          return 1;
-        }
-        for (uint32_t p = 0; p < run.world; ++p) {
-          if (p != run.rank && run.vt.bv_or_words(run.ctx, w0, n, all.data() + (size_t)p * n) != GRP_OK) {
-            return run.fail_engine("merging the bit vectors of the ranks");
-          }
-        }
-      }
+    // the bitwise OR of the ranks' vectors (the fill is order-free; csrc/host/gr_ranks.cpp)
+    const int mrc = gr_fill_merge_run(&run.vt, run.ctx, run.shm, run.world, run.rank, run.merge_rccl ? GR_MERGE_RCCL : GR_MERGE_STAGED);
+    if (mrc == 1) {
+      return run.fail_engine(run.merge_rccl ? "merging the bit vectors of the ranks (RCCL)" : "merging the bit vectors of the ranks");
+    }
+    if (mrc != 0) {
+      std::cerr << "goldrush-path: the exchange between the ranks failed" << std::endl;
+      return 1;
     }
   }
   std::cerr << "finished inserting bit vector" << std::endl;
@@ -1073,39 +1054,9 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     // host-staged form (ranks sharing a device, engines without RCCL).  Every decision below is
     // taken by ALL ranks alike (flags all-gathered through /dev/shm).
     run.shm = shm.h;
-    auto all_agree = [&](bool mine) {
-      std::vector<uint8_t> one(64, mine ? 1 : 0), all(64 * run.world);
-      if (gr_shm_allgather(shm.h, one.data(), 64, all.data()) != 0) {
-        return false;
-      }
-      bool ok = true;
-      for (uint32_t p = 0; p < run.world; ++p) {
-        ok = ok && all[(size_t)p * 64] != 0;
-      }
-      return ok;
-    };
-    const bool staged_ok = all_agree(run.vt.bv_words && run.vt.bv_export_words && run.vt.bv_or_words);
-    bool rccl_ok = all_agree(run.vt.comm_unique_id && run.vt.comm_init && run.vt.bv_merge_ranks && !getenv("GRP_NO_RCCL"));
-    if (rccl_ok) { // one device per rank?  (RCCL refuses ranks that share a GPU)
-      std::vector<int32_t> dev(16, run.device), devs(16 * run.world);
-      rccl_ok = gr_shm_allgather(shm.h, dev.data(), 64, devs.data()) == 0;
-      for (uint32_t a = 0; a < run.world && rccl_ok; ++a) {
-        for (uint32_t b2 = a + 1; b2 < run.world; ++b2) {
-          rccl_ok = rccl_ok && devs[(size_t)a * 16] != devs[(size_t)b2 * 16];
-        }
-      }
-    }
-    if (rccl_ok) {
-      std::vector<char> id(128, 0), ids(128 * run.world);
-      const bool got = run.rank != 0 || run.vt.comm_unique_id(id.data(), id.size()) == GRP_OK;
-      const bool shared = gr_shm_allgather(shm.h, id.data(), 128, ids.data()) == 0;
-      rccl_ok = all_agree(got && shared);
-      if (rccl_ok) {
-        rccl_ok = all_agree(run.vt.comm_init(run.ctx, ids.data(), run.world, run.rank) == GRP_OK); // (ranks on one device: RCCL refuses, all take the staged form)
-      }
-    }
-    run.merge_rccl = rccl_ok;
-    run.shard_fill = rccl_ok || staged_ok;
+    const int plan = gr_fill_merge_plan(&run.vt, run.ctx, shm.h, run.world, run.rank, run.device);
+    run.merge_rccl = plan == GR_MERGE_RCCL;
+    run.shard_fill = plan != GR_MERGE_NONE;
   }
   ec = calc_min_phred_threshold(run);
   if (ec >= 0) {
@@ -1181,12 +1132,7 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
   if (run.world > 1 && run.shm) {
     // every rank classifies on its own replica: they must hold the same filter (a merge that failed on one rank
     // would otherwise only show as diverging decisions much later)
-    std::vector<uint64_t> one(8, pop), all((size_t)8 * run.world);
-    bool same = gr_shm_allgather(run.shm, one.data(), 64, all.data()) == 0;
-    for (uint32_t p = 0; p < run.world && same; ++p) {
-      same = all[(size_t)p * 8] == pop;
-    }
-    if (!same) {
+    if (gr_ranks_same_u64(run.shm, run.world, pop) != 1) {
       std::cerr << "ERROR: the ranks' filters differ after the merge (rank " << run.rank << ": " << pop << " set bits)" << std::endl;
       return 1;
     }

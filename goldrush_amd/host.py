@@ -47,7 +47,7 @@ class gr_classifier_state(C.Structure):
 VT_TYPES = [
     ("create", C.CFUNCTYPE(C.c_int, C.POINTER(native.grp_params), C.POINTER(_vp))),
     ("destroy", C.CFUNCTYPE(None, _vp)),
-    ("last_error", C.CFUNCTYPE(C.c_char_p, _vp)),
+    ("last_error", C.CFUNCTYPE(_vp, _vp)),  # const char*: a Python engine returns the address of a buffer it keeps (a c_char_p result of a callback cannot be kept alive by ctypes)
     ("reads_upload", C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(_vp))),
     ("reads_free", C.CFUNCTYPE(None, _vp)),
     ("bv_insert", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32)),
@@ -92,6 +92,9 @@ VT_TYPES = [
     ("fastq_unpin", C.CFUNCTYPE(C.c_int, _vp)),
     ("batch_verify", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp)),
     ("window_overlap", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp)),
+    ("stream_begin_striped_resumable", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp)),
+    ("stream_resumable", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
+    ("stream_insert_done", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
 ]
 
 
@@ -127,6 +130,9 @@ SIGNATURES = {
     "gr_classifier_kept_commits": (C.c_size_t, [_vp, _vp, C.c_size_t]),
     "gr_shm_allgather_open": (_vp, [C.c_uint32, C.c_uint32, C.c_char_p, C.c_double]),
     "gr_shm_allgather": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "gr_fill_merge_plan": (C.c_int, [C.POINTER(grp_engine_vt), _vp, _vp, C.c_uint32, C.c_uint32, C.c_int]),
+    "gr_fill_merge_run": (C.c_int, [C.POINTER(grp_engine_vt), _vp, _vp, C.c_uint32, C.c_uint32, C.c_int]),
+    "gr_ranks_same_u64": (C.c_int, [_vp, C.c_uint32, C.c_uint64]),
     "gr_shm_allgather_close": (None, [_vp]),
     "gr_classifier_set_callbacks": (None, [_vp, COMMIT_FN, ROLLOVER_FN, ALLGATHER_FN, _vp]),
     "gr_classifier_run": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_int)]),
@@ -251,7 +257,7 @@ def hip_engine_vt() -> grp_engine_vt:
     alias = {"classify_begin": "classify_reads_begin", "classify_end": "classify_reads_end", "stream_begin": "classify_stream_begin_striped",
              "stream_abort": "classify_stream_abort", "stream_insert": "classify_stream_insert", "stream_begin_resumable": "classify_stream_begin_resumable", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end",
              "loop_begin": "commit_loop_begin", "loop_stop": "commit_loop_stop", "loop_poll": "commit_loop_poll", "loop_end": "commit_loop_end",
-             "batch_insert": "batch_insert_reads"}
+             "batch_insert": "batch_insert_reads", "stream_begin_striped_resumable": "classify_stream_begin_striped_resumable", "stream_resumable": "classify_stream_resumable", "stream_insert_done": "classify_stream_insert_done"}
     dev = bool(lib.grp_dev_hooks())
     for name, ftype in VT_TYPES:
         if name.startswith("loop_") and not dev:

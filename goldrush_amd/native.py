@@ -113,6 +113,10 @@ SIGNATURES = {
     "grp_debug_decide": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint64, C.POINTER(grp_decide_params), _vp, _vp, _vp]),
     "grp_classify_stream_begin_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.POINTER(C.c_void_p)]),
     "grp_classify_stream_insert": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "grp_comm_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
+    "grp_classify_stream_begin_striped_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "grp_classify_stream_resumable": (C.c_int, [_vp, C.c_uint32]),
+    "grp_classify_stream_insert_done": (C.c_int, [_vp, C.c_uint32]),
     "grp_commit_loop_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_loop_params), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "grp_commit_loop_stop": (C.c_int, [_vp]),
     "grp_commit_loop_poll": (C.c_int, [_vp]),
@@ -494,7 +498,9 @@ class Engine:
         stripes of `owner` are worked on (grp_classify_stream_begin_striped)."""
         dp = grp_decide_params(threshold, unassigned_min, assigned_max, 0)
         ptr = C.c_void_p()
-        if resumable:
+        if resumable and n_owners > 1:  # round 5: this rank's stripes of a window that applies inserts itself
+            self._check(self.lib.grp_classify_stream_begin_striped_resumable(self._h, batch._h, first, count, C.byref(dp), slot, stripe, n_owners, owner, C.byref(ptr)))
+        elif resumable:
             self._check(self.lib.grp_classify_stream_begin_resumable(self._h, batch._h, first, count, C.byref(dp), slot, C.byref(ptr)))
         elif n_owners > 1:
             self._check(self.lib.grp_classify_stream_begin_striped(self._h, batch._h, first, count, C.byref(dp), slot, stripe, n_owners, owner, C.byref(ptr)))
@@ -517,8 +523,8 @@ class Engine:
     def stream_end(self, slot: int) -> int:
         n = C.c_uint32()
         rc = self.lib.grp_classify_stream_end(self._h, slot, C.byref(n))
-        if rc == 1:
-            raise RuntimeError("grp_classify_stream_end: the insert posted last was not applied by the launch")
+        if rc in (1, 2):
+            raise RuntimeError("grp_classify_stream_end: the insert posted last was not applied by the launch (%d)" % rc)
         self._check(rc)
         return n.value
 
@@ -528,6 +534,16 @@ class Engine:
         gen = C.c_uint32()
         self._check(self.lib.grp_classify_stream_insert(self._h, slot, read_idx, tile_start, tile_end, block, first_id, id_offset, C.byref(gen)))
         return gen.value
+
+    def stream_resumable(self, slot: int) -> bool:
+        return self.lib.grp_classify_stream_resumable(self._h, slot) == 1
+
+    def stream_insert_done(self, slot: int) -> int:
+        """1: the insert posted last has been applied, 0: not yet, 2: the launch ended without it"""
+        rc = self.lib.grp_classify_stream_insert_done(self._h, slot)
+        if rc < 0:
+            self._check(rc)
+        return rc
 
     def commit_loop(self, batch: ReadBatch, first: int, count: int, block: int = 10, threshold=10, unassigned_min=5, assigned_max=1, silver=False,
                     target_bases: int = 0, ids_inserted: int = 0, inserted_bases: int = 0, max_depth: int = 0, whole_tiles: bool = False):

@@ -198,6 +198,10 @@ int grp_bv_import_device(grp_ctx* ctx, const void* d_src);
 int grp_comm_unique_id(void* out, size_t cap);
 int grp_comm_init(grp_ctx* ctx, const void* unique_id, uint32_t world, uint32_t rank);
 int grp_bv_merge_ranks(grp_ctx* ctx);
+/* what the context's communicator is (round 5: a bench line says which path merged its fill): *world = 0 without one;
+ * *rccl_version = ncclGetVersion's code (e.g. 22606), 0 if the library does not say; *merges = grp_bv_merge_ranks calls
+ * that returned GRP_OK on this context */
+int grp_comm_info(const grp_ctx* ctx, uint32_t* world, uint32_t* rank, int* rccl_version, uint32_t* merges);
 int grp_bv_export_words(grp_ctx* ctx, uint64_t first, uint64_t n_words32, uint32_t* words);
 int grp_bv_or_words(grp_ctx* ctx, uint64_t first, uint64_t n_words32, const uint32_t* words);
 
@@ -349,10 +353,11 @@ int grp_classify_reads_end(grp_ctx* ctx, uint32_t slot, grp_read_decision* decis
  *           to grow its buffers returns GRP_ERR_BUSY instead — begin it when the window has ended.
  *           GRP_ERR_STATE: this window cannot (not resumable; more than 64 ID blocks; GRP_STREAM_RESUME=off)
  *           — the caller aborts it and issues grp_insert_read as before.
- *   _end    returns 1 instead of GRP_OK when the launch ended WITHOUT applying the insert posted
- *           last (an abort overtook it, or the launch's workgroups were not all resident — a
- *           shared device — and the first grid-wide wait ran into its time limit): nothing was
- *           inserted, the caller issues grp_insert_read for it.
+ *   _end    returns 1 or 2 instead of GRP_OK when the launch ended WITHOUT applying the insert posted
+ *           last: nothing was inserted, the caller issues grp_insert_read for it.  1: the launch had left
+ *           before the command reached it (an abort overtook it; a striped window whose own stripes were
+ *           all decided) — nothing is wrong.  2: its workgroups were not all resident (a shared device) and
+ *           the first grid-wide wait ran into its time limit — parked windows do not work here.
  * Stream-ordered like every other call: an insert issued after _abort runs behind the
  * (draining) window.
  * Memory ordering inside the launch (gfx942 / gfx950 only, checked at _begin): summaries, lists
@@ -368,6 +373,23 @@ int grp_classify_stream_begin(grp_ctx* ctx, const grp_reads* reads, uint32_t fir
  * stripes while their launches run.  n_owners = 1 is grp_classify_stream_begin. */
 int grp_classify_stream_begin_striped(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions);
 int grp_classify_stream_begin_resumable(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, const grp_read_decision** decisions);
+/* Round 5 — the two together: the stripes of `owner` in a window that applies inserts itself, so that the ranks of a
+ * multi-GPU run keep their launches across an insert like one rank does (goldrush_path.cpp:988-990 / :1048-1049 inside
+ * the serial loop :1229-1256, every rank on its replica).  The read that inserts lies in ONE rank's stripe: that rank's
+ * launch parks itself at the record; the others learn of it from the ranks' record exchange and their launches are
+ * parked BY THE COMMAND — grp_classify_stream_insert may name any read of the window behind the last insert, whoever
+ * owns it; the launch drops what it holds of the reads behind it, applies the insert, and carries on with its own
+ * stripes' reads behind `read_idx` under the new generation.  grp_classify_stream_resumable: 1 if the window in
+ * `slot` takes _insert (the runtime may have refused the cooperative launch: a shared device), 0 if it ends where it
+ * parks — the ranks agree on it before they rely on it. */
+int grp_classify_stream_begin_striped_resumable(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions);
+int grp_classify_stream_resumable(grp_ctx* ctx, uint32_t slot);
+/* ... and whether the insert posted last has been applied: 1 yes, 0 not yet, 2 the launch has ended (or given up) without
+ * it — a striped window's launch leaves when its own stripes are decided, and the read that inserts may be another
+ * rank's: the caller then ends the window (grp_classify_stream_end says 1 or 2) and issues grp_insert_read.  A rank of
+ * several waits for this before it goes on, so that no window queued behind this one starts on a replica without
+ * the insert unnoticed. */
+int grp_classify_stream_insert_done(grp_ctx* ctx, uint32_t slot);
 int grp_classify_stream_insert(grp_ctx* ctx, uint32_t slot, uint32_t read_idx, uint32_t tile_start, uint32_t tile_end, uint32_t block_tiles, uint32_t first_id, uint32_t id_offset, uint32_t* generation);
 int grp_classify_stream_abort(grp_ctx* ctx, uint32_t slot);
 int grp_classify_stream_poll(grp_ctx* ctx, uint32_t slot);

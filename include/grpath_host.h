@@ -87,6 +87,12 @@ typedef struct
   /* optional (round 4): per read of a range the closest read in front of it that it overlaps, grp_window_overlap —
    * where most of the reads insert the classifier ends its batches in front of such reads */
   int (*window_overlap)(void* ctx, const void* reads, uint32_t first, uint32_t count, uint32_t threshold, uint32_t* prev_out);
+  /* optional (all three, with stream_insert; round 5): striped windows that apply inserts themselves — the ranks of a
+   * multi-GPU run keep their launches across an insert, grp_classify_stream_begin_striped_resumable /
+   * grp_classify_stream_resumable; stream_end may then also return 2 (a wait inside the launch timed out) */
+  int (*stream_begin_striped_resumable)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions);
+  int (*stream_resumable)(void* ctx, uint32_t slot);
+  int (*stream_insert_done)(void* ctx, uint32_t slot); /* grp_classify_stream_insert_done */
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */
@@ -175,6 +181,20 @@ typedef int (*gr_allgather_fn)(void* user, const void* send, uint64_t bytes, voi
 void* gr_shm_allgather_open(uint32_t world, uint32_t rank, const char* key, double timeout_s);
 int gr_shm_allgather(void* handle, const void* send, uint64_t bytes, void* recv);
 void gr_shm_allgather_close(void* handle);
+
+/* ---- the fill of several ranks merged into every rank's bit vector (csrc/host/gr_ranks.cpp) -------
+ * One implementation for the goldrush-path binary and bench.py's N > 1 runs.  All three are COLLECTIVE over the ranks of
+ * `shm` (gr_shm_allgather_open).  _plan: how the ranks will merge — GR_MERGE_RCCL inside the engine (one GPU per rank:
+ * grp_comm_unique_id / grp_comm_init, the communicator is up on return), GR_MERGE_STAGED through host memory and /dev/shm
+ * (ranks sharing a device, engines without RCCL), GR_MERGE_NONE (every rank fills every read); every decision is taken by
+ * all ranks alike.  _run: the merge, between the ranks' fills and finalize — 0 done, 1 an engine call failed, 2 the
+ * exchange failed.  gr_ranks_same_u64: 1 if every rank holds `value` (the population behind the merge), 0 / -1. */
+#define GR_MERGE_NONE 0
+#define GR_MERGE_STAGED 1
+#define GR_MERGE_RCCL 2
+int gr_fill_merge_plan(const grp_engine_vt* vt, void* ctx, void* shm, uint32_t world, uint32_t rank, int device);
+int gr_fill_merge_run(const grp_engine_vt* vt, void* ctx, void* shm, uint32_t world, uint32_t rank, int plan);
+int gr_ranks_same_u64(void* shm, uint32_t world, uint64_t value);
 
 typedef struct gr_classifier gr_classifier;
 

@@ -130,6 +130,21 @@ class OracleEngine:
             stream_info[slot]["resumable"] = True
             return rc
 
+        # round 5: this rank's stripes of a window that applies inserts itself (grp_classify_stream_begin_striped_resumable)
+        def stream_begin_striped_resumable(ctx, reads, first, count, dp_p, slot, stripe, n_owners, owner, out_pp):
+            rc = stream_begin(ctx, reads, first, count, dp_p, slot, stripe, n_owners, owner, out_pp)
+            self.n_striped_resumable = getattr(self, "n_striped_resumable", 0) + 1
+            # every n-th window is one the runtime "refused to launch cooperatively": it ends where it parks (the ranks must agree)
+            stream_info[slot]["resumable"] = not (self.resume_refuse_every and self.n_striped_resumable % self.resume_refuse_every == 0)
+            return rc
+
+        def stream_resumable(ctx, slot):
+            return 1 if slot in streams and stream_info[slot]["resumable"] else 0
+
+        def stream_insert_done(ctx, slot):
+            assert slot in streams
+            return 2 if stream_info[slot]["lost"] else 1
+
         def stream_begin(ctx, reads, first, count, dp_p, slot, stripe, n_owners, owner, out_pp):
             assert slot in (0, 1) and slot not in streams and slot not in slots, "slot busy"
             dp = C.cast(dp_p, C.POINTER(native.grp_decide_params))[0]
@@ -151,7 +166,7 @@ class OracleEngine:
             self.n_queries += sum(1 for j in range(count) if arr[j].pad)
             self.n_streams += 1
             streams[slot] = (arr, count)
-            stream_info[slot] = dict(first=first, dp=(dp.threshold, dp.unassigned_min, dp.assigned_max), striped=n_owners > 1, gen=1, lost=False, resumable=False)
+            stream_info[slot] = dict(first=first, dp=(dp.threshold, dp.unassigned_min, dp.assigned_max), striped=n_owners > 1, gen=1, lost=False, resumable=False, stripe=stripe, n_owners=n_owners, owner=owner)
             C.cast(out_pp, C.POINTER(C.c_void_p))[0] = C.addressof(arr)
             return 0
 
@@ -162,9 +177,12 @@ class OracleEngine:
             info = stream_info[slot]
             arr, count = streams[slot]
             x = read_idx - info["first"]
-            assert 0 <= x < count and arr[x].pad == info["gen"] and arr[x].kind in (2, 4), "the window is not parked at this read"
+            mine = lambda j: not info["striped"] or (j // info["stripe"]) % info["n_owners"] == info["owner"]  # noqa: E731
+            assert 0 <= x < count
+            if mine(x):
+                assert arr[x].pad == info["gen"] and arr[x].kind in (2, 4), "the window is not parked at this read"
             self.n_stream_insert_calls = getattr(self, "n_stream_insert_calls", 0) + 1
-            if not info["resumable"] or (self.resume_refuse_every and self.n_stream_insert_calls % self.resume_refuse_every == 0):
+            if not info["resumable"] or (not info["striped"] and self.resume_refuse_every and self.n_stream_insert_calls % self.resume_refuse_every == 0):
                 self.n_stream_refused += 1
                 return native.GRP_ERR_STATE
             info["gen"] += 1
@@ -180,6 +198,8 @@ class OracleEngine:
             for j in range(x + 1, count):
                 if parked:
                     break
+                if not mine(j):
+                    continue  # another rank's stripe
                 self.n_stream_records = getattr(self, "n_stream_records", 0) + 1
                 if self.redo_every and self.n_stream_records % self.redo_every == 0:
                     arr[j] = host.gr_read_decision()
@@ -195,12 +215,12 @@ class OracleEngine:
                 if o == slot:
                     continue
                 oinfo = stream_info[o]
-                assert oinfo["gen"] == 1 and oinfo["resumable"]
+                assert oinfo["gen"] == 1
                 odp = native.grp_decide_params(*oinfo["dp"], 0)
                 parked = False
                 for j in range(ocount):
                     oarr[j] = host.gr_read_decision()
-                    if parked:
+                    if parked or (oinfo["striped"] and (j // oinfo["stripe"]) % oinfo["n_owners"] != oinfo["owner"]):
                         continue
                     oarr[j] = _decide(oinfo["first"] + j, odp)
                     oarr[j].pad = 1
@@ -329,8 +349,10 @@ class OracleEngine:
         def sync(ctx):
             return 0
 
+        self._err_text = C.create_string_buffer(b"oracle engine")  # kept by the engine: the table hands out its address
+
         def last_error(ctx):
-            return b"oracle engine"
+            return C.addressof(self._err_text)
 
         impl = {}
         if self.pipelined:
@@ -338,7 +360,8 @@ class OracleEngine:
         if self.streaming:
             impl.update({"stream_begin": stream_begin, "stream_abort": stream_abort, "stream_poll": stream_poll, "stream_end": stream_end})
             if self.resume:
-                impl.update({"stream_begin_resumable": stream_begin_resumable, "stream_insert": stream_insert, "insert_read": insert_read})
+                impl.update({"stream_begin_resumable": stream_begin_resumable, "stream_insert": stream_insert, "insert_read": insert_read,
+                             "stream_begin_striped_resumable": stream_begin_striped_resumable, "stream_resumable": stream_resumable, "stream_insert_done": stream_insert_done})
         if self.batching:
             impl.update({"classify_reads": classify_reads, "insert_read": insert_read, "batch_insert": batch_insert, "batch_classify": batch_classify,
                          "batch_undo": batch_undo, "batch_end": batch_end})
@@ -471,8 +494,10 @@ class OracleCliEngine:
         def destroy(ctx):
             self.ctx = None
 
+        self._err_text = C.create_string_buffer(b"oracle cli engine")
+
         def last_error(ctx):
-            return b"oracle cli engine"
+            return C.addressof(self._err_text)
 
         def reads_upload(ctx, packed_p, word_off_p, len_p, n, out_pp):
             word_off = np.ctypeslib.as_array(C.cast(word_off_p, C.POINTER(C.c_uint64)), shape=(n + 1,))

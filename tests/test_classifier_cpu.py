@@ -363,7 +363,12 @@ m = orc.load().orc_calc_optimal_size(1_500_000, 1, 0.1)
 PIPE = os.environ.get("GRP_PIPELINE") == "force"
 STREAM = os.environ.get("GRP_STREAM") == "force"
 BATCH = os.environ.get("GRP_BATCH") == "force"   # windows committed as batches: every rank applies and checks the whole batch on its replica
-eng = OracleEngine(orc, m, seeds, tile, k, reads, pipelined=PIPE, streaming=STREAM, redo_every=11 if STREAM else 0, batching=BATCH)   # every rank holds a full replica
+# round 5: the ranks' striped windows apply inserts themselves.  RESUME = "plain": every launch takes every insert; "refuse":
+# every third window of rank 1 is one that ends where it parks (a refused cooperative launch: the ranks must agree per
+# window); "lost": every second insert reaches rank 1's launch too late (it had left: the ranks end the round together)
+RESUME = os.environ.get("TEST_RESUME", "")
+eng = OracleEngine(orc, m, seeds, tile, k, reads, pipelined=PIPE, streaming=STREAM, redo_every=11 if STREAM else 0, batching=BATCH, resume=bool(RESUME),
+                   resume_refuse_every=3 if RESUME == "refuse" and rank == 1 else 0, resume_lost_every=2 if RESUME == "lost" and rank == 1 else 0)   # every rank holds a full replica
 
 
 def allgather(user, send, nbytes, recv):
@@ -390,6 +395,12 @@ dist.all_reduce(tot)
 assert mine < int(tot.item())
 assert not PIPE or (eng.n_begun >= 2 and eng.n_abandoned >= 1)
 assert not STREAM or (eng.n_streams >= 3 and eng.n_stream_aborts >= 2 and eng.n_redo >= 1)
+if RESUME:
+    st = cls.state()
+    ins = torch.tensor([eng.n_stream_inserts, st["stream_inserts"], st["stream_insert_fallbacks"]], dtype=torch.int64)
+    dist.all_reduce(ins)
+    assert int(ins[0]) >= 2 and int(ins[1]) >= 2, "no insert was applied inside the ranks' launches: %s" % ins.tolist()
+    assert RESUME != "lost" or int(ins[2]) >= 1, "no launch was lost"
 assert not BATCH or (eng.n_batches >= 2 and cls.state()["batch_reads"] > 0)  # both queries of a batch are striped over the ranks (GRP_BATCH_STRIPE_MIN=2)
 dist.barrier()
 dist.destroy_process_group()
@@ -397,7 +408,7 @@ print("rank", rank, "ok", mine, int(tot.item()), eng.n_begun, eng.n_abandoned)
 """
 
 
-@pytest.mark.parametrize("pipeline", ["off", "force", "stream", "batch"])
+@pytest.mark.parametrize("pipeline", ["off", "force", "stream", "batch", "stream_resume", "stream_resume_refuse", "stream_resume_lost"])
 def test_two_ranks_gloo(oracle, native, tmp_path, pipeline):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
@@ -408,7 +419,8 @@ def test_two_ranks_gloo(oracle, native, tmp_path, pipeline):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
-                   **({"GRP_STREAM": "force", "GRP_STRIPE": "3"} if pipeline == "stream" else {"GRP_BATCH": "force", "GRP_STREAM": "off", "GRP_BATCH_STRIPE_MIN": "2"} if pipeline == "batch"
+                   **({"GRP_STREAM": "force", "GRP_STRIPE": "3", "GRP_BATCH": "off", "TEST_RESUME": pipeline[14:] or "plain"} if pipeline.startswith("stream_resume") else
+                      {"GRP_STREAM": "force", "GRP_STRIPE": "3"} if pipeline == "stream" else {"GRP_BATCH": "force", "GRP_STREAM": "off", "GRP_BATCH_STRIPE_MIN": "2"} if pipeline == "batch"
                       else {"GRP_PIPELINE": pipeline, "GRP_STREAM": "off"}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]

@@ -59,3 +59,7 @@ def test_two_ranks_on_the_one_gpu_end_where_one_rank_ends():
     assert a["aux"]["pop"] == b["aux"]["pop"]
     assert a["aux"]["counters"] == b["aux"]["counters"]
     assert a["aux"]["counters"]["inserts"] > 1000 and b["aux"]["timed"]["batches"] > 10
+    # round 5: the merge of the sharded fill is the product's (csrc/host/gr_ranks.cpp: staged here, the ranks share the
+    # device; RCCL where every rank has its own), and the ranks' striped windows apply inserts inside their launches
+    assert b["aux"]["comm"]["world"] == 2 and b["aux"]["comm"]["merge"].startswith("staged"), b["aux"]["comm"]
+    assert b["aux"]["timed"]["stream_inserts"] > 0, b["aux"]["timed"]
