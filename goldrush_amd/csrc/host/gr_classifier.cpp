@@ -257,13 +257,18 @@ Classifier::window_plan() const
     // a window that ends at the insert: drain + insert kernels + relaunch, ~400 us on C2 (tools/abort_matrix.sh);
     // a window that applies the insert itself (round 3): ~240 us until the first record behind it, ~100 us of
     // device time — 200 us fitted on C2's transition zone (tools/dev/r3_thresholds.sh)
-    const double t_abort = t_abort_env > 0.0 ? t_abort_env : (can_resume() ? 200e-6 : 400e-6);
+    // (several ranks: what the RANKS agreed on for the last window, not this rank's own view — the plan must come out the same on every rank)
+    const bool resume_plan = p_.world == 1 ? can_resume() : (ranks_resume_ok_ && vt_.stream_begin_striped_resumable && vt_.stream_resumable && vt_.stream_insert_done && vt_.stream_insert && vt_.insert_read);
+    const double t_abort = t_abort_env > 0.0 ? t_abort_env : (resume_plan ? 200e-6 : 400e-6);
     // the window size does not matter to an abort (only the resident workgroups are lost),
     // so the launches are as long as allowed.  Several ranks: every rank works on its own
     // stripe of the current group, an insert also discards about half a group; the
     // stripe exchange (~150 us per group) is hidden behind the launches unless it is the
     // longer of the two.
-    const uint32_t S = p_.max_window;
+    // (round 5: a window of several ranks that applies inserts itself only leaves on the host's word — the GPUs idle for
+    // the host's lag behind them at every window's end, ~100 us — and a rank's launch covers 1 / world of it: the
+    // windows grow with the number of ranks)
+    const uint32_t S = (p_.world > 1 && resume_plan) ? (uint32_t)std::min<uint64_t>((uint64_t)p_.max_window * std::min<uint32_t>(p_.world, 8u), 1u << 16) : p_.max_window;
     // a record handed back (a tile needed the worst-case table) costs an abort plus a
     // synchronous single-read round: where that is frequent (large h on repeat-rich
     // data) the windows that redo flagged tiles in bulk win
@@ -374,6 +379,7 @@ Classifier::launch_stream(void* reads, uint32_t pos, uint32_t S, uint32_t slot, 
         }
       }
       resumable = all_resumable;
+      ranks_resume_ok_ = all_resumable;
     }
   }
   if (rc != GRP_OK) {
@@ -1712,6 +1718,9 @@ Classifier::stream_round(uint32_t& pos)
       }
     }
   } else {
+    if (p_.world > 1) {
+      (void)vt_.stream_abort(ctx_, scur_.slot); // every read of the window is committed: a striped window that takes inserts stays until it is told
+    }
     rc = end_stream(scur_); // completed: returns at once
     if (rc != GRP_OK) {
       drop_streams();

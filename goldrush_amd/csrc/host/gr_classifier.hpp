@@ -165,6 +165,7 @@ private:
   uint64_t n_stream_rollovers_ = 0; // silver mode: inserts kept out of a parked launch because the path rolls over behind them
   uint64_t lost_at_ = UINT64_MAX;      // read at which a window was last begun again because its launch had left without deciding it
   uint32_t group_base_ = UINT32_MAX; // first read of the stripe group held in stripe_recv_
+  bool ranks_resume_ok_ = true;      // several ranks: the last window begun was one every rank's launch applies inserts in (what the window plan prices an insert with: the same on every rank)
   bool ins_unconfirmed_ = false;     // several ranks: an insert went to the launches and no exchange has followed yet (the ranks have not told each other whether every launch took it)
   bool ins_lost_ = false;            // several ranks: this rank's launch had left before the insert command reached it — said in the next exchange, the ranks end the round together
   uint32_t group_from_ = 0;          // reads of the window below this one are committed: a group gathered again behind an insert the launches applied themselves starts here

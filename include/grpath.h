@@ -379,7 +379,9 @@ int grp_classify_stream_begin_resumable(grp_ctx* ctx, const grp_reads* reads, ui
  * launch parks itself at the record; the others learn of it from the ranks' record exchange and their launches are
  * parked BY THE COMMAND — grp_classify_stream_insert may name any read of the window behind the last insert, whoever
  * owns it; the launch drops what it holds of the reads behind it, applies the insert, and carries on with its own
- * stripes' reads behind `read_idx` under the new generation.  grp_classify_stream_resumable: 1 if the window in
+ * stripes' reads behind `read_idx` under the new generation.  Such a window does not leave by itself when its own
+ * stripes are decided (the next insert may be another rank's): the host ends it with _abort once it has committed the
+ * window's last read.  grp_classify_stream_resumable: 1 if the window in
  * `slot` takes _insert (the runtime may have refused the cooperative launch: a shared device), 0 if it ends where it
  * parks — the ranks agree on it before they rely on it. */
 int grp_classify_stream_begin_striped_resumable(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions);

@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """A time model of the whole-stream bench at N = 2, 4, 8 GPUs from a measured N = 1 line.
 
-  python3 tools/scale_model.py profiles/r04_..._bench_default_flags.json [--park] [--json]
+  python3 tools/scale_model.py <N = 1 bench line> [--ranks <1-rank line> <2-rank line>] [--no-park] [--json]
+
+Round 5: the striped windows of several ranks apply inserts inside their launches (the model's default now; --no-park is
+round 4's form, windows that end at every insert), and the constants that can be COUNTED come from a measured pair of
+runs of one stream — one rank and two ranks (tools/dev/rank_truth_check.sh keeps both lines): the speculative share of
+the query work (2 x rank 0's executed probes / the single rank's - 1) and the share of the inserts the launches took
+themselves (aux.timed.stream_inserts against stream_insert_fallbacks).  Times cannot come from that pair on this pool
+(its two ranks share ONE GPU): they stay named constants with the place they were measured at.
 
 What it takes from the N = 1 JSON line of bench.py: the phases (head / steady seconds, reads, inserts), the kernel
 families' summed times (aux.kernel_stats) and the speculation counters (aux.timed).  What it assumes is written
@@ -26,10 +33,23 @@ SPEC = 0.11                # speculative stripes thrown away per insert, share o
 T_INSERT_STRIPED = 0.45e-3  # s per insert when the launch ends and the insert kernels run between launches (r03: 424 us + restart)
 T_INSERT_PARKED = 0.238e-3  # s per insert applied inside a parked launch (r03 measurement, one rank)
 T_EXCHANGE = 30e-6         # s per /dev/shm all-gather of decision records
+T_WINDOW_END = 100e-6      # s the GPUs idle at the end of a window of several ranks that applies inserts itself: it leaves on the host's word (host lag: one exchange + the commits of a group)
+WINDOW_READS = 8192        # reads per streaming window and rank count unit (Classifier::window_plan: max_window x min(N, 8) when the ranks' windows take inserts)
 HOST_PER_BATCH = 0.05e-3   # s of host work per batch (window plan, commit loop)
 
 
-def model(d, park=False):
+def measured_pair(one, two):
+    """what a (1 rank, 2 ranks) pair of runs of the same stream says: counts only"""
+    q1 = one["aux"]["kernel_stats"]["query"]["units"]
+    q2 = two["aux"]["kernel_stats"]["query"]["units"]  # rank 0's launches
+    t = two["aux"]["timed"]
+    took, fell = t.get("stream_inserts", 0), t.get("stream_insert_fallbacks", 0)
+    assert one["aux"]["counters"] == two["aux"]["counters"], "the pair does not describe one stream"
+    return {"spec": 2.0 * q2 / q1 - 1.0, "in_launch_share": took / (took + fell) if took + fell else None, "stream_inserts_2ranks": took, "fallbacks_2ranks": fell,
+            "from": "2 x %d / %d executed probes; %d inserts applied inside the ranks' launches, %d fell back" % (q2, q1, took, fell)}
+
+
+def model(d, park=True, pair=None):
     a = d["aux"]
     ph = d["phases"]
     ks = a["kernel_stats"]
@@ -47,13 +67,22 @@ def model(d, park=False):
     head_insert = ks.get("batch_insert", {"ms": 0.0})["ms"] * 1e-3  # collect + apply of the batches (0 in lines older than round 4 v2)
     head_rest = head_insert + batches * HOST_PER_BATCH
     head_query = max(head_s - head_verify - head_decide - head_rest, 0.0)
+    spec = pair["spec"] if pair else SPEC
+    share = pair["in_launch_share"] if pair and pair["in_launch_share"] is not None else 1.0
+    reads_steady = ph["steady"]["reads"]
     rows = []
     for n in (1, 2, 4, 8):
         if n == 1:
             steady_n, head_n = steady_s, head_s
         else:
-            t_ins = T_INSERT_PARKED if park else T_INSERT_STRIPED
-            steady_n = steady_query * (1 + SPEC) / n + steady_ins * t_ins
+            if park:
+                # an insert the launches apply themselves: the parked launch's own cost, one exchange round for the record
+                # to reach the other ranks and their command to reach their launches; the rest ends the launches as before
+                t_ins = share * (T_INSERT_PARKED + 2 * T_EXCHANGE) + (1 - share) * T_INSERT_STRIPED
+                windows = reads_steady / (WINDOW_READS * min(n, 8))
+                steady_n = steady_query * (1 + spec) / n + steady_ins * t_ins + windows * T_WINDOW_END
+            else:
+                steady_n = steady_query * (1 + spec) / n + steady_ins * T_INSERT_STRIPED
             head_n = head_query / n + batches * 2 * T_EXCHANGE + head_verify + head_decide + head_rest
         total = steady_n + head_n
         reads = ph["head"]["reads"] + ph["steady"]["reads"]
@@ -63,29 +92,34 @@ def model(d, park=False):
         r["speedup"] = r["reads_per_s"] / base
         r["efficiency"] = r["speedup"] / r["gpus"]
     terms = {"steady_query_s": steady_query, "steady_inserts": steady_ins, "head_query_s": head_query, "head_verify_s": head_verify, "head_decide_s": head_decide,
-             "head_replicated_rest_s": head_rest, "batches": batches, "insert_cost_s": T_INSERT_PARKED if park else T_INSERT_STRIPED,
-             "amdahl_replicated_s_at_any_n": head_verify + head_decide + head_rest + steady_ins * (T_INSERT_PARKED if park else T_INSERT_STRIPED)}
+             "head_replicated_rest_s": head_rest, "batches": batches, "speculative_share_of_query_work": spec, "inserts_taken_by_the_launches_share": share if park else 0.0,
+             "insert_cost_s": (share * (T_INSERT_PARKED + 2 * T_EXCHANGE) + (1 - share) * T_INSERT_STRIPED) if park else T_INSERT_STRIPED,
+             "amdahl_replicated_s_at_any_n": head_verify + head_decide + head_rest + steady_ins * ((share * (T_INSERT_PARKED + 2 * T_EXCHANGE) + (1 - share) * T_INSERT_STRIPED) if park else T_INSERT_STRIPED),
+             "constants_from": pair["from"] if pair else "named constants (no --ranks pair given)"}
     fill = {"fill_s_n1": a["fill_s"], "rank_build_s": a.get("finalize_s"), "note": "hashing sharded by reads (/ N), merge 2 x (N-1)/N bit vectors over xGMI, rank build replicated; not in the metric"}
-    return {"model": "replicated miBF, query work sharded (DESIGN.md 7)", "park_inserts_in_launch": park, "terms": terms, "rows": rows, "fill": fill}
+    return {"model": "replicated miBF, query work sharded (DESIGN.md 7)", "inserts_inside_the_ranks_launches": park, "terms": terms, "rows": rows, "fill": fill}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("bench_json")
-    ap.add_argument("--park", action="store_true", help="what-if: the in-launch insert also under striping (host-commanded park, not built)")
+    ap.add_argument("--no-park", action="store_true", help="round 4's form: a window of several ranks ends at every insert")
+    ap.add_argument("--park", action="store_true", help="(the default since round 5; kept for old command lines)")
+    ap.add_argument("--ranks", nargs=2, metavar=("ONE_RANK_JSON", "TWO_RANKS_JSON"), help="a measured pair of runs of one stream: the counted constants come from it")
     ap.add_argument("--json", action="store_true")
     a = ap.parse_args()
-    line = [l for l in open(a.bench_json).read().strip().splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    load = lambda f: json.loads([l for l in open(f).read().strip().splitlines() if l.startswith("{")][-1])  # noqa: E731
+    d = load(a.bench_json)
     if d.get("n_gpus", 1) != 1:
         sys.exit("scale_model: needs the N = 1 line")
-    m = model(d, a.park)
+    pair = measured_pair(load(a.ranks[0]), load(a.ranks[1])) if a.ranks else None
+    m = model(d, not a.no_park, pair)
     if a.json:
         print(json.dumps(m, indent=1))
         return
-    print("model: %s%s" % (m["model"], "; inserts applied inside the parked launches (what-if)" if a.park else ""))
+    print("model: %s%s" % (m["model"], "; inserts applied inside the ranks' launches" if not a.no_park else "; windows of several ranks end at every insert (round 4)"))
     for k, v in m["terms"].items():
-        print("  %-32s %s" % (k, ("%.3f" % v) if isinstance(v, float) else v))
+        print("  %-36s %s" % (k, ("%.6g" % v) if isinstance(v, float) else v))
     print("  N   head s  steady s  total s   reads/s   speed-up  efficiency")
     for r in m["rows"]:
         print("  %d  %7.2f  %8.2f  %7.2f  %9.0f   %6.2f    %5.2f" % (r["gpus"], r["head_s"], r["steady_s"], r["total_s"], r["reads_per_s"], r["speedup"], r["efficiency"]))
