@@ -72,8 +72,9 @@ class ReadStream:
     region); otherwise batches of `batch` reads generated on demand, one resident at a time
     (C4: 50 M reads = 312 GB of 2-bit bases do not fit 288 GB of HBM)."""
 
-    def __init__(self, native, n_reads: int, genome: int, batch: int, sigma: float = 0.25):
+    def __init__(self, native, n_reads: int, genome: int, batch: int, sigma: float = 0.25, repeat_frac: float = 0.0):
         self.native, self.n, self.G = native, n_reads, genome
+        self.repeat_frac = repeat_frac  # share of the genome made of repeat families (grpath_synth.h); 0: the uniform genome
         self.plan = native.synth_read_plan(n_reads, genome, sigma=sigma)
         self.batch = batch if batch else n_reads
         self.n_batches = (n_reads + self.batch - 1) // self.batch
@@ -90,7 +91,7 @@ class ReadStream:
             self.drop()
             lo, hi = self.bounds(b)
             t0 = time.perf_counter()
-            dr = self.native.synth_reads_range(self.plan, lo, hi, self.G)
+            dr = self.native.synth_reads_range(self.plan, lo, hi, self.G, repeat_frac=self.repeat_frac)
             rb = self.eng.wrap_device(dr.d_ptr, dr.word_off, dr.lens)
             self.synth_s += time.perf_counter() - t0
             self.cur = (b, dr, rb, np.ascontiguousarray(dr.lens, dtype=np.uint32))
@@ -306,6 +307,8 @@ def main():
     ap.add_argument("--silver", type=int, default=-1, help="silver-path mode with this many paths (-M); default: the config's")
     ap.add_argument("--stream-batch", type=int, default=-1, help="reads per resident batch (0: all resident; default: 2 M when the packed reads exceed 100 GB)")
     ap.add_argument("--max-window", type=int, default=0)
+    ap.add_argument("--repeat-frac", type=float, default=0.0, help="share of the genome made of repeat families (2-6 kb units at 1-5 %% divergence, ~30 / ~1 000 / ~10 000 copies; include/grpath_synth.h); "
+                    "0 = the headline workload's uniform genome, where two reads share k-mers only where they overlap.  Not the headline: the line's config says so and aux.repeats sums up what the speculation did")
     ap.add_argument("--len-sigma", type=float, default=0.25, help="sigma of the log-normal read lengths (mean 25 kb, floor 20 kb); 0.25 = the headline workload (no read above ~64 kb), "
                     "0.6 = a realistic ONT tail (reads of 100 kb and more: the decision path for reads of more than 64 tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -382,7 +385,7 @@ def main():
     # ---- untimed setup: inputs resident in HBM, phase 1 -------------------------
     t0 = time.time()
     stream_batch = a.stream_batch if a.stream_batch >= 0 else (2_000_000 if n_reads * 6400 > 100e9 else 0)
-    rs = ReadStream(native, n_reads, G, stream_batch, sigma=a.len_sigma)
+    rs = ReadStream(native, n_reads, G, stream_batch, sigma=a.len_sigma, repeat_frac=a.repeat_frac)
     eng = native.Engine(k, h, tile, m, seeds, device=local_rank)
     rs.eng = eng
     rs.get(0)
@@ -668,6 +671,7 @@ def main():
                            cfg["name"], " [C3: stream shared by %d GPUs]" % world if (world > 1 and a.config == "C2") else "", h,
                            "silver-path mode, %d paths (the run ends behind the last path: reads_timed = reads consumed)" % max_paths if silver else "golden-path mode"),
                        "reads": n_reads, "reads_timed": reads_done, "reads_per_step": per_step, "genome": G, "filter_bits": m, "pop": pop,
+                       **({"repeat_frac": a.repeat_frac, "NOT_THE_HEADLINE_WORKLOAD": "repeat-rich genome (--repeat-frac)"} if a.repeat_frac > 0 else {}),
                        "read_lengths": {"sigma": a.len_sigma, "mean": float(rs.plan[1].mean()), "max": int(rs.plan[1].max()), "reads_over_64_tiles": int((rs.plan[1] >= 65 * tile).sum())},
                        "parallelism": ("one GPU: windows committed as batches where >= ~1 % of the reads insert, streaming windows elsewhere" if world == 1 else "replicated miBF on %d GPUs: batches on every rank where >= ~1 %% of the reads insert, streaming windows striped over the ranks elsewhere (32-B decisions all-gathered per stripe group)" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
@@ -740,8 +744,19 @@ def main():
                 "inserts": int(sst["inserts"]), "paths_completed": int(sst["curr_path"]) - 1 if s_fin else int(sst["curr_path"]) - 1, "finished": bool(s_fin),
                 "batches": int(sst["batches"]), "batches_undone": int(sst["batches_undone"]), "reads_queried": int(sst["reads_queried"]),
                 "stream_inserts": int(sst["stream_inserts"]), "stream_rollovers": int(sst["stream_rollovers"]), "batch_overlap_cuts": int(sst["batch_overlap_cuts"]),
+                "batches_refused": int(sst["batches_refused"]), "stream_handbacks": int(sst["stream_handbacks"]),
                 "kernel_stats": {k_: v_ for k_, v_ in eng.kernel_stats().items() if v_["launches"]}}  # of this pass alone (HIP events, summed ms)
             del scls
+        if a.repeat_frac > 0:
+            # what the speculation did on a genome with repeats: exactness never depends on it, speed does
+            ps = out["aux"].get("pipeline_shaped") or {}
+            out["aux"]["repeats"] = {
+                "repeat_frac": a.repeat_frac, "genome": "slots of 6144 bases, a repeat copy with probability 1.5 f: units of 2-6 kb at 1-5 % divergence in families of ~30 / ~1 000 / ~10 000 copies (include/grpath_synth.h)",
+                "golden": {"reads_per_s": out["value"], "head_s": out["phases"]["head"]["seconds"], "steady_reads_per_s": out["phases"]["steady"]["reads_per_s"], "inserts": int(st1["inserts"] - st0["inserts"]),
+                           "batches": int(st1["batches"] - st0["batches"]), "batches_taken_back": int(st1["batches_undone"] - st0["batches_undone"]),
+                           "batches_refused_chain_overflow_or_size": int(st1["batches_refused"] - st0["batches_refused"]), "records_handed_back": int(st1["stream_handbacks"] - st0["stream_handbacks"]),
+                           "verify": out["aux"]["batch_verify"]},
+                "pipeline_shaped": {k_: ps.get(k_) for k_ in ("reads_per_s", "seconds", "inserts", "batches", "batches_undone", "batches_refused", "stream_handbacks")} if ps else None}
         print(json.dumps(out), flush=True)
     if world > 1:
         if shm:

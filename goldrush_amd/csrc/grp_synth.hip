@@ -22,9 +22,44 @@ mix64(uint64_t x)
 }
 
 __host__ __device__ inline uint32_t
-genome_base(uint64_t seed, uint64_t i)
+unique_base(uint64_t seed, uint64_t i)
 {
   return (uint32_t)(mix64(seed ^ (i * 0xD1342543DE82EF95ULL)) >> 62);
+}
+
+constexpr uint64_t REP_SLOT = 6144; // bases per slot of a repeat-rich genome (grpath_synth.h)
+
+// base i of the genome: unique sequence, or — inside the unit of a slot that is a repeat copy — the family's
+// consensus with this copy's substitutions
+__host__ __device__ inline uint32_t
+genome_base(const grp_synth_params& p, uint64_t i)
+{
+  if (!(p.repeat_frac > 0.0f)) {
+    return unique_base(p.genome_seed, i);
+  }
+  const uint64_t slot = i / REP_SLOT, off = i - slot * REP_SLOT;
+  const uint64_t h = mix64(p.genome_seed ^ 0x5EEDC0DE5EEDC0DEULL ^ (slot * 0xC2B2AE3D27D4EB4FULL));
+  const float p_slot = p.repeat_frac * 1.5f < 1.0f ? p.repeat_frac * 1.5f : 1.0f; // mean unit 4096 of 6144 bases
+  if ((float)(h & 0xFFFFFFu) >= p_slot * 16777216.0f) {
+    return unique_base(p.genome_seed, i);
+  }
+  const uint32_t tier = (uint32_t)((h >> 24) % 3u);
+  const uint64_t copies = tier == 0 ? 10000u : tier == 1 ? 1000u : 30u;
+  const uint64_t tier_slots = (uint64_t)((double)(p.genome_len / REP_SLOT) * p_slot / 3.0);
+  const uint64_t n_fam = tier_slots / copies > 0 ? tier_slots / copies : 1;
+  const uint64_t fam = ((uint64_t)tier << 48) | ((h >> 28) % n_fam);
+  const uint64_t fh = mix64(p.genome_seed ^ 0xFA111E5FA111E5ULL ^ (fam * 0x9E3779B97F4A7C15ULL));
+  const uint64_t unit = 2048 + fh % 4097; // 2 .. 6 kb
+  if (off >= unit) {
+    return unique_base(p.genome_seed, i);
+  }
+  uint32_t b = (uint32_t)(mix64(fh ^ (off * 0xD6E8FEB86659FD93ULL)) >> 62); // the family's consensus
+  const uint32_t div = 1u + (uint32_t)((fh >> 13) % 5u);                       // 1 .. 5 % of the positions differ in a copy
+  const uint64_t m = mix64(p.genome_seed ^ 0xD17E26E7CEULL ^ (i * 0xA24BAED4963EE407ULL));
+  if ((uint32_t)(m % 100u) < div) {
+    b = (b + 1u + (uint32_t)((m >> 32) % 3u)) & 3u;
+  }
+  return b;
 }
 
 constexpr int T = 256;
@@ -55,7 +90,7 @@ k_synth(grp_synth_params p,
   for (uint64_t c0 = 0; flushed < L; c0 += T) {
     const uint64_t i = c0 + threadIdx.x;
     uint64_t coord = rev ? (s0 + p.genome_len - (i % p.genome_len)) % p.genome_len : (s0 + i) % p.genome_len;
-    uint32_t b = genome_base(p.genome_seed, coord);
+    uint32_t b = genome_base(p, coord);
     if (rev) {
       b = 3u - b;
     }

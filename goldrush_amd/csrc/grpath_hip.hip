@@ -223,6 +223,7 @@ struct grp_ctx
   uint64_t n_batch_sweeps = 0; // times the batch epochs wrapped and the claims were swept out of the count words
   uint64_t n_stream_idle_exits = 0, n_stream_coop_refused = 0; // parked windows that left by themselves (idle limit); resumable windows whose cooperative launch was refused
   uint64_t n_flagged_tiles = 0, n_flagged_distinct = 0, n_flagged_list = 0; // statistics: tiles redone with the worst-case table; why (distinct IDs / list length)
+  uint64_t n_verify_impossible = 0;
   uint64_t n_verify_tiles = 0, n_verify_queried = 0, n_verify_flagged = 0, n_verify_fallbacks = 0, n_verify_uncertified = 0, n_verify_unpatched = 0; // grp_batch_verify: tiles patched from records / queried again / patched tiles redone / calls that took the second query
   uint64_t n_direct_windows = 0, n_direct_fallbacks = 0, n_general_windows = 0, n_redo_launches = 0; // GRP_DEBUG_STATS
   uint64_t n_chunks = 0; // rank-build chunks
@@ -2986,3 +2987,4 @@ grp_dev_hooks(void)
 #include "grp_ingest.inc"
 #include "grp_ntcard.inc"
 #include "grp_comm.inc"
+#include "grp_pshard.inc"

@@ -1049,6 +1049,11 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
       return run.fail_engine("allocating the bit vector");
     }
   }
+  if (run.world > 1 && shm.h && gr_ranks_share_device(shm.h, run.world, run.device) == 1) {
+    // ranks on one device (a test box): their windows' launches must all fit it at once — the in-launch inserts of
+    // the ranks' windows wait grid-wide (read at the engine's first streaming launch; an explicit setting stands)
+    setenv("GRP_STREAM_WGS_PER_CU", "1", 0);
+  }
   if (run.world > 1 && !getenv("GRP_REPLICATED_FILL")) {
     // A sharded fill needs a way to merge: RCCL inside the engine (one GPU per rank), else the
     // host-staged form (ranks sharing a device, engines without RCCL).  Every decision below is

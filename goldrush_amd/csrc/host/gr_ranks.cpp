@@ -99,6 +99,26 @@ gr_fill_merge_run(const grp_engine_vt* vt, void* ctx, void* shm, uint32_t world,
   return 0;
 }
 
+// 1: at least two ranks of the node run on the same device (the plumbing runs of a one-GPU box), 0: every rank has its
+// own, -1: the exchange failed.  The ranks' persistent launches must then all be resident on that device TOGETHER (their
+// in-launch inserts wait grid-wide): the caller limits them to one workgroup per CU (GRP_STREAM_WGS_PER_CU).  Collective.
+int
+gr_ranks_share_device(void* shm, uint32_t world, int device)
+{
+  std::vector<int32_t> dev(16, device), devs((size_t)16 * world);
+  if (!shm || gr_shm_allgather(shm, dev.data(), 64, devs.data()) != 0) {
+    return -1;
+  }
+  for (uint32_t a = 0; a < world; ++a) {
+    for (uint32_t b = a + 1; b < world; ++b) {
+      if (devs[(size_t)a * 16] == devs[(size_t)b * 16]) {
+        return 1;
+      }
+    }
+  }
+  return 0;
+}
+
 // 1: every rank holds `value` (the filter's population behind the merge: the replicas are the same filter), 0: they
 // differ, -1: the exchange failed.  Collective.
 int

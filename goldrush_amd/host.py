@@ -133,6 +133,7 @@ SIGNATURES = {
     "gr_fill_merge_plan": (C.c_int, [C.POINTER(grp_engine_vt), _vp, _vp, C.c_uint32, C.c_uint32, C.c_int]),
     "gr_fill_merge_run": (C.c_int, [C.POINTER(grp_engine_vt), _vp, _vp, C.c_uint32, C.c_uint32, C.c_int]),
     "gr_ranks_same_u64": (C.c_int, [_vp, C.c_uint32, C.c_uint64]),
+    "gr_ranks_share_device": (C.c_int, [_vp, C.c_uint32, C.c_int]),
     "gr_shm_allgather_close": (None, [_vp]),
     "gr_classifier_set_callbacks": (None, [_vp, COMMIT_FN, ROLLOVER_FN, ALLGATHER_FN, _vp]),
     "gr_classifier_run": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_uint32, C.POINTER(C.c_int)]),

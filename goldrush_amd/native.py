@@ -113,6 +113,7 @@ SIGNATURES = {
     "grp_debug_decide": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint64, C.POINTER(grp_decide_params), _vp, _vp, _vp]),
     "grp_classify_stream_begin_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.POINTER(C.c_void_p)]),
     "grp_classify_stream_insert": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "grp_pshard_query": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
     "grp_comm_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "grp_classify_stream_begin_striped_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "grp_classify_stream_resumable": (C.c_int, [_vp, C.c_uint32]),
@@ -151,7 +152,7 @@ SIGNATURES = {
 
 class grp_synth_params(C.Structure):
     _fields_ = [("genome_len", C.c_uint64), ("genome_seed", C.c_uint64), ("error_seed", C.c_uint64),
-                ("p_sub", C.c_float), ("p_ins", C.c_float), ("p_del", C.c_float)]
+                ("p_sub", C.c_float), ("p_ins", C.c_float), ("p_del", C.c_float), ("repeat_frac", C.c_float)]
 
 
 # include/grpath_synth.h (measurement support)
@@ -447,6 +448,20 @@ class Engine:
             self._check(rc)
             return tiles, lists[: used.value], {"queries": st.queries, "hits": st.hits, "misses": st.misses}
 
+    def pshard_query(self, batch: ReadBatch, first: int, count: int, n_owners: int = 8):
+        """Measurement: query_tiles' result through the position-sharded form with `n_owners` virtual owners on this one
+        device (grp_pshard_query).  Returns (tiles, lists, {"partition_ms", "gather_ms", "vote_ms"})."""
+        nt = int(batch.tile0[first + count] - batch.tile0[first])
+        tiles = np.zeros(nt, dtype=tile_summary_dtype)
+        cap = max(8 * nt, 1024)
+        lists = np.zeros(cap, dtype=id_count_dtype)
+        used = C.c_uint64()
+        times = (C.c_float * 3)()
+        self._check(self.lib.grp_pshard_query(self._h, batch._h, first, count, n_owners, _ptr(tiles), _ptr(lists), cap, C.byref(used), times))
+        if used.value > cap:
+            raise GrpError(GRP_ERR_NOMEM, "pshard_query: %d list entries, room for %d" % (used.value, cap))
+        return tiles, lists[: used.value], {"partition_ms": times[0], "gather_ms": times[1], "vote_ms": times[2]}
+
     def classify_reads(self, batch: ReadBatch, first: int = 0, count: int | None = None, threshold=10, unassigned_min=5, assigned_max=1):
         """Query + decision on the device; returns an array of decision_dtype."""
         count = batch.n_reads - first if count is None else count
@@ -590,9 +605,9 @@ class Engine:
         return out[:count]
 
     def verify_stats(self) -> dict:
-        out = np.zeros(10, dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
         self._check(self.lib.grp_debug_verify_stats(self._h, _ptr(out)))
-        return dict(zip(("patched", "queried", "flagged", "fallbacks", "uncertified", "unpatched", "window_flagged", "flagged_distinct", "flagged_list", "claim_sweeps"), (int(x) for x in out)))
+        return dict(zip(("patched", "queried", "flagged", "fallbacks", "uncertified", "unpatched", "window_flagged", "flagged_distinct", "flagged_list", "claim_sweeps", "impossible_deltas", "far_count_words"), (int(x) for x in out)))
 
     def batch_undo(self, from_read: int, id_floor: int):
         """takes back the inserts of reads >= from_read (batch index); id_floor = the first ID read from_read could allocate"""
@@ -732,7 +747,7 @@ def synth_read_plan(n_reads: int, genome_len: int, mean_len: int = 25000, min_le
     return start, lens, strand, word_off
 
 
-def synth_reads_range(plan, lo: int, hi: int, genome_len: int, genome_seed: int = 1, error_seed: int = 3, p_sub=0.03, p_ins=0.01, p_del=0.01, stream: int = 0) -> DeviceReads:
+def synth_reads_range(plan, lo: int, hi: int, genome_len: int, genome_seed: int = 1, error_seed: int = 3, p_sub=0.03, p_ins=0.01, p_del=0.01, stream: int = 0, repeat_frac: float = 0.0) -> DeviceReads:
     """Reads [lo, hi) of a plan (synth_read_plan) generated into their own device buffer: a read
     set larger than HBM is streamed through it batch by batch.  The error pattern of a read
     depends on its index INSIDE the call, so the passes of one run must use the same batches."""
@@ -746,7 +761,7 @@ def synth_reads_range(plan, lo: int, hi: int, genome_len: int, genome_seed: int 
     d = lib.grp_synth_alloc(int(wo[-1]) * 4 + 64)
     if not d:
         raise GrpError(GRP_ERR_NOMEM, lib.grp_synth_last_error().decode())
-    p = grp_synth_params(genome_len, genome_seed, error_seed, p_sub, p_ins, p_del)
+    p = grp_synth_params(genome_len, genome_seed, error_seed, p_sub, p_ins, p_del, repeat_frac)
     rc = lib.grp_synth_reads(C.byref(p), _ptr(st), _ptr(ln), _ptr(sd), _ptr(wo), n, C.c_void_p(d), C.c_void_p(stream))
     if rc != 0:
         raise GrpError(rc, lib.grp_synth_last_error().decode())
@@ -754,13 +769,13 @@ def synth_reads_range(plan, lo: int, hi: int, genome_len: int, genome_seed: int 
 
 
 def synth_reads(n_reads: int, genome_len: int, genome_seed: int = 1, error_seed: int = 3, p_sub=0.03, p_ins=0.01, p_del=0.01,
-                stream: int = 0, **plan_kw) -> DeviceReads:
+                stream: int = 0, repeat_frac: float = 0.0, **plan_kw) -> DeviceReads:
     lib = load()
     start, lens, strand, word_off = synth_read_plan(n_reads, genome_len, **plan_kw)
     d = lib.grp_synth_alloc(int(word_off[-1]) * 4 + 64)
     if not d:
         raise GrpError(GRP_ERR_NOMEM, lib.grp_synth_last_error().decode())
-    p = grp_synth_params(genome_len, genome_seed, error_seed, p_sub, p_ins, p_del)
+    p = grp_synth_params(genome_len, genome_seed, error_seed, p_sub, p_ins, p_del, repeat_frac)
     rc = lib.grp_synth_reads(C.byref(p), _ptr(start), _ptr(lens), _ptr(strand), _ptr(word_off), n_reads, C.c_void_p(d), C.c_void_p(stream))
     if rc != 0:
         raise GrpError(rc, lib.grp_synth_last_error().decode())

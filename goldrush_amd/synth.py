@@ -20,6 +20,27 @@ def random_genome(length: int, seed: int = 1) -> np.ndarray:
     return _ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)]
 
 
+def repeat_genome(length: int, seed: int = 1, families=((3000, 12, 0.02), (2000, 8, 0.04), (5000, 5, 0.01))) -> np.ndarray:
+    """A random genome with repeat families planted in it: (unit length, copies, divergence) each — every copy is the
+    family's unit with i.i.d. substitutions at `divergence` of its positions, on either strand, at a random place (later
+    copies may overwrite earlier ones).  What the uniform genome lacks: reads that share k-mers WITHOUT overlapping."""
+    rng = np.random.default_rng(seed)
+    g = _ACGT[rng.integers(0, 4, size=length, dtype=np.uint8)].copy()
+    for unit_len, copies, div in families:
+        unit = _ACGT[rng.integers(0, 4, size=unit_len, dtype=np.uint8)]
+        for _ in range(copies):
+            c = unit.copy()
+            m = rng.random(unit_len) < div
+            k = int(m.sum())
+            if k:
+                c[m] = _ACGT[(np.searchsorted(_ACGT, c[m]) + rng.integers(1, 4, size=k)) % 4]
+            if rng.random() < 0.5:
+                c = _COMP[c[::-1]]
+            at = int(rng.integers(0, length - unit_len))
+            g[at:at + unit_len] = c
+    return g
+
+
 def revcomp(seq: np.ndarray) -> np.ndarray:
     return _COMP[seq[::-1]]
 

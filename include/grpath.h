@@ -649,8 +649,10 @@ int grp_debug_decide(grp_ctx* ctx, uint32_t n_reads, const uint64_t* tile0, cons
  * [6] flagged tiles redone with the worst-case table by all synchronous forms (grp_classify_reads / grp_batch_* /
  * grp_query_tiles), of which [7] held more distinct IDs than the small count table takes and [8] had a count > 2
  * list longer than its LDS area; [9] times the batch epochs wrapped and the claims were swept out of the count
- * words (every 1023 batches; GRP_BATCH_EPOCHS=<n> for tests) */
-int grp_debug_verify_stats(const grp_ctx* ctx, uint64_t out[10]);
+ * words (every 1023 batches; GRP_BATCH_EPOCHS=<n> for tests); round 5: [10] tiles whose patch failed its self-check
+ * (an impossible delta: queried again through the log, the run goes on), [11] count words living in the far table
+ * (ranks beyond their bucket's 8th set bit, csrc/grp_device.h) */
+int grp_debug_verify_stats(const grp_ctx* ctx, uint64_t out[12]);
 
 /* 1: the library was built with GRP_DEV_HOOKS (make DEV=1): the frozen commit loop (grp_commit_loop_*) and the
  * developer kernels / switches (GRP_BATCH_COLLECT3 ...) are compiled in; 0: the product build — grp_commit_loop_*
@@ -692,6 +694,16 @@ int grp_reset_kernel_stats(grp_ctx* ctx);
 
 /* HIP stream the context launches on (hipStream_t as void*) */
 void* grp_stream(grp_ctx* ctx);
+
+/*
+ * Measurement (round 5): grp_query_tiles' result through the POSITION-SHARDED form of the query — the filter cut into
+ * `n_owners` ranges of buckets, every probe a record in its owner's bin (partition), the bins gathered in owner order,
+ * the IDs handed back and voted on per tile (csrc/grp_pshard.inc) — with the owners on ONE device: what the
+ * partition and return passes cost beside the gather, before any xGMI traffic.  Same tile summaries as
+ * grp_query_tiles (lists in any order); times_ms[3] = partition, gather, vote (HIP events).  Not on the product's
+ * path (DESIGN.md 7 has the decision it feeds).
+ */
+int grp_pshard_query(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, uint32_t n_owners, grp_tile_summary* tiles, grp_id_count* lists, uint64_t list_cap, uint64_t* list_used, float* times_ms);
 
 #ifdef __cplusplus
 }

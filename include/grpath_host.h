@@ -195,6 +195,9 @@ void gr_shm_allgather_close(void* handle);
 int gr_fill_merge_plan(const grp_engine_vt* vt, void* ctx, void* shm, uint32_t world, uint32_t rank, int device);
 int gr_fill_merge_run(const grp_engine_vt* vt, void* ctx, void* shm, uint32_t world, uint32_t rank, int plan);
 int gr_ranks_same_u64(void* shm, uint32_t world, uint64_t value);
+/* 1: at least two ranks run on the same device (then their persistent launches must share it: one workgroup per CU each,
+ * GRP_STREAM_WGS_PER_CU), 0: none do, -1: the exchange failed.  Collective. */
+int gr_ranks_share_device(void* shm, uint32_t world, int device);
 
 typedef struct gr_classifier gr_classifier;
 

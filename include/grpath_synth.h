@@ -4,7 +4,8 @@
  * goldrush-path CLI).  Exported by libgrpath_hip.so.
  *
  * Model: uniform random genome of `genome_len` bases defined
- * by a counter-based generator (base i = f(genome_seed, i)); read r is the
+ * by a counter-based generator (base i = f(genome_seed, i); optionally repeat-rich,
+ * repeat_frac below); read r is the
  * substring starting at start[r] (genome coordinates wrap), reverse-
  * complemented when strand[r] != 0, passed through i.i.d. errors: each source
  * base is deleted with probability p_del, otherwise emitted (substituted by a
@@ -27,6 +28,13 @@ typedef struct
   uint64_t genome_seed;
   uint64_t error_seed;
   float p_sub, p_ins, p_del;
+  /* Round 5: the share of the genome made of REPEATS, 0 = none (the uniform genome of rounds
+   * 1-4: two reads share k-mers only where they overlap).  With f > 0 the genome is cut into slots of 6144 bases; a
+   * slot is a repeat copy with probability 1.5 f and then begins with its family's unit — 2 to 6 kb long (per family),
+   * the family's consensus with a copy-specific substitution at 1 to 5 % of the positions (per family) — the rest of
+   * the slot and every other slot are unique sequence.  Families come in three tiers of ~10 000, ~1 000 and ~30 copies
+   * (a third of the repeat slots each; fewer copies where the genome is too small for that many). */
+  float repeat_frac;
 } grp_synth_params;
 
 /*

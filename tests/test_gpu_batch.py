@@ -193,6 +193,22 @@ def test_claim_epochs_wrap(oracle, native, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("window,verify", [(7, None), (32, "check"), (200, "chain")])
+def test_batches_on_a_repeat_rich_genome(oracle, native, window, verify):
+    """a third of this genome is repeat copies (units of 2-5 kb, 5-12 copies, 1-4 % divergence, either
+    strand), so reads of one window share ranks WITHOUT overlapping — chains, confirmations that fail far from any
+    overlap, IDs of other loci in the votes.  Everything the batches do must still be the serial loop: records, IDs,
+    every count."""
+    from goldrush_amd import synth
+
+    tile, k, h, block = 500, 22, 3, 4
+    g = synth.repeat_genome(150_000, 31)
+    reads = [r[1] for r in synth.make_reads(g, 140, mean_len=5000, min_len=3500, seed=32, max_len=9000)]
+    m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
+    stats, exp = _run(oracle, native, reads, tile, k, h, m, block, window, "loop_repeats", verify)
+    assert stats["batches"] > 0 and {e[1] for e in exp} >= {2, 3}
+
+
 @pytest.mark.parametrize("verify", [None, "check", "chain"])
 def test_batches_on_a_small_crowded_filter(oracle, native, verify):
     """A filter far too small for its reads (occupancy ~0.5, most ranks shared by many tiles):

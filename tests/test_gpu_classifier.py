@@ -59,6 +59,34 @@ def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, mo
         assert st["batches_refused"] >= 2 and st["batches"] >= 1
 
 
+@pytest.mark.parametrize("mode", ["auto", "batch", "stream"])
+def test_hip_classifier_on_a_repeat_rich_genome(oracle, native, mode, monkeypatch):
+    """The product's classifier (its own choice of windows and batches, batches forced, streaming windows forced) on a
+    genome a third of which is repeat copies: commits, IDs and counts of the oracle's serial loop."""
+    from goldrush_amd import host, synth
+    from oracle_engine import cached_serial_reference
+
+    for key, val in {"auto": {}, "batch": {"GRP_BATCH": "force"}, "stream": {"GRP_BATCH": "off", "GRP_STREAM": "force"}}[mode].items():
+        monkeypatch.setenv(key, val)
+    tile, k, h, block = 500, 22, 3, 4
+    seeds = default_seeds(h)
+    g = synth.repeat_genome(150_000, 31)
+    reads = [r[1] for r in synth.make_reads(g, 160, mean_len=5000, min_len=3500, seed=33, max_len=9000)]
+    m = oracle.load().orc_calc_optimal_size(2_000_000, 1, 0.1)
+    exp, ref_ids, ref_counts, ref_pop = cached_serial_reference("classifier_repeats", oracle, m, seeds, tile, k, reads, block=block, silver=True, target_bases=120_000, max_paths=3)
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    assert eng.finalize() == ref_pop
+    cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, k=k, h=h, target_bases=120_000, max_paths=3, silver_path=True, max_window=4096)
+    cls.run(b._h, b.lens)
+    eng.sync()
+    assert [c[:8] for c in cls.commits] == exp
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, ref_ids) and np.array_equal(counts, ref_counts)
+    eng.close()
+
+
 def test_golden_fixture_through_cli(native, tmp_path):
     from goldrush_amd import host
 

@@ -46,6 +46,22 @@ def _compare_queries(eng, omf, batch, reads, first, count):
     assert (stats["queries"], stats["hits"], stats["misses"]) == (q, h, ms)
 
 
+def _compare_pshard(eng, omf, batch, reads, first, count, n_owners):
+    """the position-sharded form of the query (grp_pshard_query: partition into owners' bins, gather in owner order, vote
+    on what comes back; csrc/grp_pshard.inc) against the oracle, tile by tile"""
+    tiles, lists, times = eng.pshard_query(batch, first, count, n_owners)
+    ti = 0
+    for seq in reads[first:first + count]:
+        for top_id, top_count, lst, ctr in omf.query_read(seq):
+            t = tiles[ti]
+            assert (int(t["top_id"]), int(t["top_count"])) == (top_id, top_count), (ti, n_owners)
+            got = sorted(((int(a), int(c)) for a, c in lists[t["list_off"]: t["list_off"] + t["list_n"]]), key=lambda e: (-e[1], e[0]))
+            assert got == canon_list(lst), (ti, n_owners)
+            assert (int(t["hits"]), int(t["misses"])) == (ctr[1], ctr[2]), (ti, n_owners)
+            ti += 1
+    assert ti == len(tiles) and all(v >= 0 for v in times.values())
+
+
 def _insert_whole(eng, omf, batch, reads, ri, next_id):
     seq = reads[ri]
     nt = len(seq) // TILE
@@ -150,6 +166,10 @@ def test_filter_of_c2_size_matches_oracle(oracle, native):
     assert np.array_equal(ids, omf.ids()) and np.array_equal(counts, omf.counts())
     _compare_queries(eng, omf, batch, reads, 0, 24)
     _compare_queries(eng, omf, batch, reads, 88, 6)
+    # round 5: the same reads through the position-sharded form of the query (8 virtual owners as on a node, and 3: a
+    # number that does not divide anything)
+    _compare_pshard(eng, omf, batch, reads, 0, 24, 8)
+    _compare_pshard(eng, omf, batch, reads, 88, 6, 3)
     eng.close()
     dr.free()
 

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""GPU box: the position-sharded form of the query priced on one device (csrc/grp_pshard.inc).
+
+  python3 tools/pshard_bench.py [--reads 10000000] [--head 900000] [--window 8192] [--owners 8] [out.json]
+
+C2's filter (m = 61 146 729 472) filled with all reads, the first --head reads classified (the insert-heavy head:
+the ID array of the whole genome is populated behind it), then ONE window of --window reads of the steady state is
+queried three ways, each on the same state: k_query (grp_query_tiles: the product's synchronous form), and the
+position-sharded form with 1 and --owners virtual owners (partition -> gather in owner order -> vote).  The tile summaries
+of the forms are compared (top ID / count, hits, misses, count > 2 lists as sets): identical or the run fails."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import argparse
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--head", type=int, default=900_000)
+    ap.add_argument("--window", type=int, default=8192)
+    ap.add_argument("--owners", type=int, default=8)
+    ap.add_argument("--genome", type=float, default=3e9)
+    ap.add_argument("out", nargs="?")
+    a = ap.parse_args()
+    import bench
+    from goldrush_amd import host, native
+
+    G, k, w, tile, h, block = int(a.genome), 22, 16, 1000, 3, 10
+    hl = host.load()
+    seeds = host.make_seed_pattern(bench.PRESET, k, w, h)
+    m = hl.gr_calc_optimal_size(hl.gr_hash_universe(w, G, h), 1, 0.1)
+    rs = bench.ReadStream(native, a.reads, G, 0)
+    eng = native.Engine(k, h, tile, m, seeds)
+    rs.eng = eng
+    t0 = time.time()
+    for rb_, _, lo_, n_ in rs.pieces(0, a.reads):
+        eng.bv_insert(rb_, lo_, n_)
+    eng.sync()
+    pop = eng.finalize()
+    t_fill = time.time() - t0
+    cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=10, unassigned_min=5, assigned_max=1, k=k, h=h, target_bases=int(0.9 * G), max_paths=1, silver_path=False, record=False)
+    t0 = time.time()
+    for rb_, lens_, lo_, n_ in rs.pieces(0, a.head):
+        cls.run_range(rb_._h, lens_, lo_, n_)
+    eng.sync()
+    t_head = time.time() - t0
+    st = cls.state()
+    first = a.head
+    _, rb, lens = rs.get(0)
+    res = {"what": "one window of the C2 steady state queried by k_query (synchronous form) and by the position-sharded form on one device", "filter_bits": int(m), "pop": int(pop), "reads_filled": a.reads,
+           "head_reads_classified": a.head, "head_inserts": int(st["inserts"]), "window_reads": a.window, "fill_s": t_fill, "head_s": t_head}
+    probes = None
+    base = None
+    for rep in range(3):
+        eng.reset_kernel_stats()
+        t0 = time.perf_counter()
+        tiles, lists, stats = eng.query_tiles(rb, first, a.window)
+        t_call = time.perf_counter() - t0
+        ks = eng.kernel_stats()["query"]
+        probes = stats["hits"] + stats["misses"] if probes is None else probes
+        base = {"kernel_ms": ks["ms"], "launches": ks["launches"], "call_ms": t_call * 1e3, "probes_with_all_bits_set": int(probes), "tiles": int(tiles.size)}
+    n_probes = int(np.sum(np.minimum(lens[first:first + a.window] // tile, 10**9)) * tile * h)  # frames x seeds (the last tile of a read is full: tail >= k - 1 here)
+    res["k_query"] = dict(base, G_probes_per_s=n_probes / base["kernel_ms"] / 1e6)
+
+    def canon(tiles_, lists_):
+        out = []
+        for t in tiles_:
+            lst = sorted((int(x), int(c)) for x, c in lists_[t["list_off"]: t["list_off"] + t["list_n"]])
+            out.append((int(t["top_id"]), int(t["top_count"]), int(t["hits"]), int(t["misses"]), tuple(lst)))
+        return out
+
+    want = canon(tiles, lists)
+    for owners in (1, a.owners):
+        best = None
+        for rep in range(3):
+            pt, pl, times = eng.pshard_query(rb, first, a.window, owners)
+            tot = times["partition_ms"] + times["gather_ms"] + times["vote_ms"]
+            if best is None or tot < best["total_ms"]:
+                best = dict(times, total_ms=tot)
+        got = canon(pt, pl)
+        same = got == want
+        best.update(identical_to_k_query=bool(same), overhead_vs_k_query=best["total_ms"] / base["kernel_ms"] - 1.0, G_probes_per_s=n_probes / best["total_ms"] / 1e6,
+                    gather_G_lines_per_s=n_probes / best["gather_ms"] / 1e6,
+                    stream_bytes_per_probe={"partition writes": 10, "gather reads + writes": 12, "vote reads": 6})
+        res["pshard_%d_owners" % owners] = best
+        if not same:
+            bad = next(i for i in range(len(want)) if want[i] != got[i])
+            res["first_difference"] = {"tile": bad, "k_query": str(want[bad])[:300], "pshard": str(got[bad])[:300]}
+    # the links: what N GPUs would move per probe (the owners' side of the query), against a GPU's seven xGMI links
+    rate = res["pshard_%d_owners" % a.owners]["G_probes_per_s"] * 1e9
+    res["xgmi"] = {"bytes_out_per_probe": 8, "bytes_back_per_probe": 4, "share_remote": (a.owners - 1) / a.owners,
+                   "GB_per_s_out_per_gpu_at_this_rate": rate * 8 * (a.owners - 1) / a.owners / 1e9, "GB_per_s_back_per_gpu_at_this_rate": rate * 4 * (a.owners - 1) / a.owners / 1e9,
+                   "links": "7 x ~153 GB/s per GPU (the task's hardware note: xGMI is point-to-point, 7 links x ~153 GB/s); an all-to-all uses all seven at once, each carrying 1 / 7 of the remote share",
+                   "GB_per_s_per_link_out": rate * 8 / a.owners / 1e9}
+    line = json.dumps(res)
+    print(line)
+    if a.out:
+        open(a.out, "w").write(json.dumps(res, indent=1) + "\n")
+    if not all(res[k_].get("identical_to_k_query", True) for k_ in res if k_.startswith("pshard_")):
+        sys.exit("pshard_bench: the position-sharded form's summaries differ from k_query's")
+
+
+if __name__ == "__main__":
+    main()
