@@ -59,6 +59,9 @@ struct QuerySlot
   uint32_t* d_dec_ids = nullptr;
   uint8_t* d_dec_asg = nullptr;
   uint64_t* d_dec_scratch = nullptr;
+  std::vector<uint32_t> h_long_reads; // reads of the window of more than 256 tiles: decided by a launch of their own (classify_enqueue_decide)
+  uint32_t* d_long_reads = nullptr;
+  uint64_t long_reads_cap = 0;
   uint64_t d_dec_cap = 0;
   grp_read_decision* d_dec = nullptr;
   grp_read_decision* h_dec = nullptr; // pinned
@@ -911,6 +914,7 @@ grp_destroy(grp_ctx* c)
     (void)hipFree(sl.d_dec_ids);
     (void)hipFree(sl.d_dec_asg);
     (void)hipFree(sl.d_dec_scratch);
+    (void)hipFree(sl.d_long_reads);
     (void)hipFree(sl.d_dec);
     if (sl.h_dec) {
       (void)hipHostFree(sl.h_dec);
@@ -1780,13 +1784,37 @@ int
 classify_enqueue_decide(grp_ctx* c, QuerySlot& sl, hipStream_t st)
 {
   Timer t(c, GRP_K_DECIDE, sl.count, st);
-  const uint32_t lds_tiles = decide_lds_tiles(sl.reads->tile0.data() + sl.first, sl.count);
-  const size_t lds = decide_lds_bytes(lds_tiles);
-  if (const int rc = ensure_lds(c, k_decide, lds); rc != GRP_OK) {
-    return rc;
+  // Reads of more than 256 tiles keep their state in LDS (up to 148 KB at 4096 tiles): sized for the longest read and
+  // applied to the whole launch, ONE such read used to drop every workgroup of the window to about one per CU (ADVICE
+  // r04).  They get a launch of their own over an index list; the common launch carries no dynamic LDS.
+  const uint64_t* tile0 = sl.reads->tile0.data() + sl.first;
+  std::vector<uint32_t>& longs = sl.h_long_reads;
+  longs.clear();
+  uint64_t most = 0;
+  for (uint32_t i = 0; i < sl.count; ++i) {
+    const uint64_t n = tile0[i + 1] - tile0[i];
+    if (n > 4 * LANE_TILES) {
+      longs.push_back(i);
+      most = std::max(most, n);
+    }
   }
-  k_decide<<<dim3(sl.count), dim3(DECIDE_THREADS), lds, st>>>(sl.reads->dev, sl.first, sl.count, sl.dp, sl.d_tiles, sl.d_lists, sl.list_cap, sl.d_dec_ids, sl.d_dec_asg, sl.d_dec_scratch, sl.d_dec, lds_tiles);
+  k_decide<<<dim3(sl.count), dim3(DECIDE_THREADS), 0, st>>>(sl.reads->dev, sl.first, sl.count, sl.dp, sl.d_tiles, sl.d_lists, sl.list_cap, sl.d_dec_ids, sl.d_dec_asg, sl.d_dec_scratch, sl.d_dec, 0u, nullptr,
+                                                            longs.empty() ? 0u : 4u * LANE_TILES);
   HIP_TRY(c, hipGetLastError());
+  if (!longs.empty()) {
+    const uint32_t lds_tiles = (uint32_t)std::min<uint64_t>((most + 63) / 64 * 64, DECIDE_LDS_MAX_TILES);
+    const size_t lds = decide_lds_bytes(lds_tiles);
+    if (const int rc = ensure_lds(c, k_decide, lds); rc != GRP_OK) {
+      return rc;
+    }
+    if (const int rc = ensure_dev(c, sl.d_long_reads, sl.long_reads_cap, longs.size()); rc != GRP_OK) {
+      return rc;
+    }
+    HIP_TRY(c, hipMemcpyAsync(sl.d_long_reads, longs.data(), longs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st)); // (pageable: staged before the call returns)
+    k_decide<<<dim3((uint32_t)longs.size()), dim3(DECIDE_THREADS), lds, st>>>(sl.reads->dev, sl.first, sl.count, sl.dp, sl.d_tiles, sl.d_lists, sl.list_cap, sl.d_dec_ids, sl.d_dec_asg, sl.d_dec_scratch, sl.d_dec, lds_tiles,
+                                                                            sl.d_long_reads, 0u);
+    HIP_TRY(c, hipGetLastError());
+  }
   return GRP_OK;
 }
 

@@ -36,6 +36,7 @@ Classifier::Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, v
       env_.overlap_samples = 0;
     } else if (!t.empty()) {
       env_.overlap_samples = (uint32_t)std::max(1l, atol(t.c_str()));
+      env_.overlap_fixed = true;
     }
     const std::string pmin = env("GRP_BATCH_OVERLAP_P");
     if (!pmin.empty()) {
@@ -1119,7 +1120,43 @@ Classifier::batch_round(uint32_t& pos)
       ovl_lo_ = at;
       ovl_hi_ = at + nb;
       ++n_overlap_calls_;
-      if (nb >= 3 && vt_.window_overlap(ctx_, rg_.reads, base_ + at, nb, env_.overlap_samples, ovl_prev_.data()) != GRP_OK) {
+      // How many shared samples end a window: 8 tells every true overlap of a uniform genome (an error-free kilobase
+      // is ~60 samples, unrelated reads share ~0.01) — and, on a genome with repeats, nearly every read: the windows
+      // end after ~50 reads and the batches' fixed cost (worth ~70 reads) is what the run pays (bench.py --repeat-frac
+      // 0.4: 75 k reads/s at 8, 103 k at 64; uniform genome: 127 k at 8, 123 k at 64).  So the threshold climbs the
+      // block-by-block efficiency — reads committed per (70 x batches + reads queried), from the classifier's own
+      // counters: deterministic — while the batches are short; where they are long already (>= 128 reads at the base
+      // threshold) it stays.  A hint either way: every batch is still confirmed by its second decisions.
+      if (!env_.overlap_fixed) {
+        if (ovl_thr_ == 0) {
+          ovl_thr_ = env_.overlap_samples;
+        } else {
+          const uint64_t db = n_batches_ - ovl_s_batches_, dr = n_batch_reads_ - ovl_s_reads_, dq = n_queried_ - ovl_s_queried_;
+          if (db >= 8) {
+            const double eff = (double)dr / (70.0 * (double)db + (double)dq);
+            if (!(ovl_thr_ == env_.overlap_samples && dr >= 128 * db)) {
+              if (eff < ovl_last_eff_) {
+                ovl_dir_ = -ovl_dir_;
+              }
+              uint32_t next = ovl_dir_ > 0 ? ovl_thr_ * 2u : ovl_thr_ / 2u;
+              if (next < env_.overlap_samples) {
+                next = env_.overlap_samples;
+                ovl_dir_ = 1;
+              } else if (next > 256u) {
+                next = 256u;
+                ovl_dir_ = -1;
+              }
+              ovl_thr_ = next;
+            }
+            ovl_last_eff_ = eff;
+          }
+        }
+        ovl_s_batches_ = n_batches_;
+        ovl_s_reads_ = n_batch_reads_;
+        ovl_s_queried_ = n_queried_;
+      }
+      const uint32_t threshold = env_.overlap_fixed || ovl_thr_ == 0 ? env_.overlap_samples : ovl_thr_;
+      if (nb >= 3 && vt_.window_overlap(ctx_, rg_.reads, base_ + at, nb, threshold, ovl_prev_.data()) != GRP_OK) {
         ovl_prev_.assign(nb, UINT32_MAX); // no hints from this engine call
       }
     }

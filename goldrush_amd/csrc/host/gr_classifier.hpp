@@ -98,6 +98,7 @@ private:
   {
     std::string pipeline, stream, loop, batch; // GRP_PIPELINE / GRP_STREAM / GRP_LOOP / GRP_BATCH as found when the classifier was created
     uint64_t max_window_tiles = 0;             // GRP_MAX_WINDOW_TILES (0: unset)
+    bool overlap_fixed = false;                // GRP_BATCH_OVERLAP was given: the threshold stays what it says (else it adapts, batch_round)
     uint32_t overlap_samples = 8;              // GRP_BATCH_OVERLAP=<n> / off: windows of batches end in front of a read sharing >= n sampled k-mers with a read in front of it (0: not asked)
     double overlap_min_insert = 0.3;           // GRP_BATCH_OVERLAP_P: ... where at least this share of the reads inserts
   } env_;
@@ -162,6 +163,12 @@ private:
   std::vector<uint32_t> ovl_prev_;    // grp_window_overlap's answer for reads [ovl_lo_, ovl_hi_) of the range that starts at base_ == ovl_base_
   uint32_t ovl_lo_ = 0, ovl_hi_ = 0;
   uint64_t ovl_base_ = UINT64_MAX;
+  // the overlap threshold adapts (round 5): on a repeat-rich genome nearly every read shares a few sampled k-mers with a
+  // read in front of it, the windows end after ~50 reads and the batches' fixed cost (~70 reads) is what the run pays
+  uint32_t ovl_thr_ = 0;             // the threshold in use (0: not started, env_.overlap_samples)
+  int ovl_dir_ = 1;                  // the way the last change went (x 2 / / 2)
+  double ovl_last_eff_ = 0.0;        // committed reads per unit of cost over the block before
+  uint64_t ovl_s_batches_ = 0, ovl_s_reads_ = 0, ovl_s_queried_ = 0; // counters at the last block's start
   uint64_t n_stream_rollovers_ = 0; // silver mode: inserts kept out of a parked launch because the path rolls over behind them
   uint64_t lost_at_ = UINT64_MAX;      // read at which a window was last begun again because its launch had left without deciding it
   uint32_t group_base_ = UINT32_MAX; // first read of the stripe group held in stripe_recv_

@@ -80,6 +80,23 @@ struct PtrState
   GR_HD grp_id_count list_entry(size_t k) const { return load_list_entry(lists + k); }
   // entry j of tile i's count>2 list
   GR_HD grp_id_count tile_list_entry(size_t i, uint32_t j) const { return load_list_entry(lists + tiles[i].list_off + j); }
+  // is `want` in tile i's count>2 list, and with which count (:646-661: the reference walks the whole list; an ID is in
+  // it at most once).  The device's wave-resident states search with the whole wave (grp_kernels.inc): on a
+  // repeat-rich genome a tile's list holds hundreds of IDs and the entry-by-entry walk — one dependent load each — made
+  // the decisions the largest kernel of the run (round 5, bench.py --repeat-frac)
+  GR_HD bool find_in_list(size_t i, uint32_t want, uint32_t& count) const
+  {
+    const uint32_t ln = list_n(i);
+    bool found = false;
+    for (uint32_t j = 0; j < ln; ++j) {
+      const grp_id_count e = tile_list_entry(i, j);
+      if (e.id == want) {
+        count = e.count;
+        found = true;
+      }
+    }
+    return found;
+  }
   GR_HD uint32_t id(size_t i) const { return ids[i]; }
   GR_HD void set_id(size_t i, uint32_t v) { ids[i] = v; }
   GR_HD uint32_t asg(size_t i) const { return flags[i]; }
@@ -166,13 +183,10 @@ adopt_neighbour(size_t i, size_t nb, size_t x, S& s)
   if (s.id(i) == want) {
     return;
   }
-  const uint32_t ln = s.list_n(i);
-  for (uint32_t j = 0; j < ln; ++j) {
-    const grp_id_count e = s.tile_list_entry(i, j);
-    if (e.id == want) {
-      s.set_id(i, want);
-      s.set_asg(i, e.count > x ? 1u : 0u);
-    }
+  uint32_t count = 0;
+  if (s.find_in_list(i, want, count)) {
+    s.set_id(i, want);
+    s.set_asg(i, count > x ? 1u : 0u);
   }
 }
 
