@@ -686,6 +686,14 @@ def main():
                          "line_rate_Gprobes_per_s": gprobes,
                          "line_rate_ceiling_Gps": ceiling, "line_rate_ceiling_source": (os.path.basename(ceiling_file) if ceiling_file else None),
                          "line_rate_frac": (gprobes / ceiling if ceiling else None)},
+            # the insert side (round 5, SURVEY 8(d): 2 x 128 B per unique rank — count RMW + ID RMW): k_batch_collect + k_batch_apply of the
+            # batches in the timed region, per record slot ((frame, seed) of an inserted tile: what the pass walks; ~all of them unique ranks)
+            "roofline_insert": ({"bound": "hbm", "kernel": "k_batch_collect + k_batch_apply (windows committed as batches)", "record_slots": int(ks["batch_insert"]["units"]), "kernel_ms": ks["batch_insert"]["ms"],
+                                 "launches": int(ks["batch_insert"]["launches"]), "G_record_slots_per_s": ks["batch_insert"]["units"] / ks["batch_insert"]["ms"] / 1e6, "bytes_per_record_slot": 256,
+                                 "achieved": ks["batch_insert"]["units"] * 256 / ks["batch_insert"]["ms"] / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": ks["batch_insert"]["units"] * 256 / ks["batch_insert"]["ms"] / 1e6 / HBM_PEAK_GBPS,
+                                 "note": "the pass pays per memory request, not per byte (DESIGN 4): a record is a 64-B quad read of the query line, one compare-and-swap on the insert line of the same 128-B unit and a 4-B store"}
+                                if ks["batch_insert"]["ms"] > 0 else None),
             "phases": {"slice_reads": PHASE_SLICE,
                        "head": {"reads": head_reads, "seconds": head_s, "reads_per_s": head_reads / head_s if head_s > 0 else None, "inserts": head_ins,
                                 "definition": "slices before the first %d-read slice with an insert rate < 1 %%" % PHASE_SLICE},

@@ -289,6 +289,11 @@ struct grp_ctx
     uint8_t* text[2] = { nullptr, nullptr }; // two chunks can be alive at once (parsed / being packed)
     uint64_t text_cap[2] = { 0, 0 };
     bool text_used[2] = { false, false };
+    int last_slot = 1; // the slot the chunk before took (the next one takes the other)
+    // grp_fastq_prefetch: the text of the next chunk is on its way into this slot (-1: none)
+    int pre_slot = -1;
+    const char* pre_text = nullptr;
+    uint64_t pre_bytes = 0;
     uint32_t* d_counts = nullptr;
     uint64_t counts_cap = 0;
     uint64_t *d_base = nullptr, *d_super = nullptr, *d_total = nullptr, *d_nl = nullptr;
@@ -299,6 +304,7 @@ struct grp_ctx
     uint32_t* d_len = nullptr;
     uint64_t so_cap = 0, wo_cap = 0, len_cap = 0;
     hipEvent_t uploaded = nullptr; // the chunk's text has arrived (copied on the side stream, beside the fill of the chunk before)
+    hipEvent_t text_done[2] = { nullptr, nullptr }; // the main stream's last use of the slot's text (grp_fastq_free records it: the next upload into the slot waits for it, not the host)
   } ingest;
   const char* reg_text = nullptr; // the caller's text buffer, page-locked by grp_fastq_pin
   size_t reg_bytes = 0;
@@ -327,6 +333,11 @@ struct grp_reads
   std::vector<uint64_t> tile0;  // host copy
   std::vector<uint64_t> chunk0; // host copy
   std::vector<uint32_t> len;    // host copy
+  // grp_fastq_pack (round 5): one device allocation behind all index arrays, filled by asynchronous copies out of these
+  // vectors — they live as long as the batch, so no call has to wait for a copy
+  void* d_slab = nullptr;
+  std::vector<uint64_t> h_word_off, h_seq_off;
+  std::vector<uint32_t> h_tile_read, h_chunk_read;
   DevReads dev{};
 };
 
@@ -835,7 +846,18 @@ grp_create(const grp_params* p, grp_ctx** out)
     c->coherent_arch = c->arch.compare(0, 5, "gfx94") == 0 || c->arch.compare(0, 5, "gfx95") == 0;
   }
   CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  CREATE_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  {
+    // The side stream runs what must not queue behind a device-filling launch of the main stream: the parse of the
+    // next FASTQ chunk beside the fill of the chunk before (the fill's grid holds ~10^6 workgroups: at equal priority
+    // the parse kernels were dispatched behind them and the chunk's chain was fill + parse, round 5), the decisions and
+    // copy-back of a pipelined window beside the next window's query.  Highest priority the device offers.
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) {
+      lo = hi = 0;
+      (void)hipGetLastError();
+    }
+    CREATE_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
+  }
   CREATE_TRY(hipMalloc(&c->d_seeds, sizeof(DevSeeds)));
   CREATE_TRY(hipMemcpyAsync(c->d_seeds, &c->h_seeds, sizeof(DevSeeds), hipMemcpyHostToDevice, c->stream));
   if (p->m != 0) {
@@ -1036,6 +1058,12 @@ grp_destroy(grp_ctx* c)
   (void)hipFree(c->ingest.d_so);
   (void)hipFree(c->ingest.d_wo);
   (void)hipFree(c->ingest.d_len);
+  for (hipEvent_t& e : c->ingest.text_done) {
+    if (e) {
+      (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+  }
   if (c->ingest.uploaded) {
     (void)hipEventDestroy(c->ingest.uploaded);
   }
@@ -1116,6 +1144,45 @@ reads_build(grp_ctx* c, grp_reads* r, const uint64_t* word_off, const uint32_t* 
   return GRP_OK;
 }
 
+// the host half of reads_build for grp_fastq_pack: lengths, tile / fill-chunk prefixes and the tile -> read, chunk -> read
+// maps, kept in the batch (its asynchronous uploads read them)
+int
+reads_index(grp_ctx* c, grp_reads* r, const uint64_t* word_off, const uint32_t* len, uint32_t n)
+{
+  const uint32_t tile = c->params.tile;
+  const uint32_t k = c->params.k;
+  const uint32_t min_len = c->params.k + c->params.h - 1;
+  r->ctx = c;
+  r->n_reads = n;
+  r->n_words = word_off[n];
+  r->len.assign(len, len + n);
+  r->tile0.resize((size_t)n + 1);
+  r->chunk0.resize((size_t)n + 1);
+  uint64_t t = 0, ch = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    r->tile0[i] = t;
+    r->chunk0[i] = ch;
+    t += len[i] / tile;
+    if (len[i] >= min_len) { // (see reads_build)
+      const uint64_t npos = (uint64_t)len[i] - k + 1;
+      ch += (npos + FILL_CHUNK - 1) / FILL_CHUNK;
+    }
+  }
+  r->tile0[n] = t;
+  r->chunk0[n] = ch;
+  r->h_tile_read.resize(t);
+  r->h_chunk_read.resize(ch);
+  for (uint32_t i = 0; i < n; ++i) {
+    for (uint64_t j = r->tile0[i]; j < r->tile0[i + 1]; ++j) {
+      r->h_tile_read[j] = i;
+    }
+    for (uint64_t j = r->chunk0[i]; j < r->chunk0[i + 1]; ++j) {
+      r->h_chunk_read[j] = i;
+    }
+  }
+  return GRP_OK;
+}
+
 int
 grp_reads_upload(grp_ctx* c, const uint32_t* packed, const uint64_t* word_off, const uint32_t* len, uint32_t n, grp_reads** out)
 {
@@ -1186,6 +1253,11 @@ grp_reads_free(grp_reads* r)
   }
   if (r->owns_packed) {
     (void)hipFree(r->d_packed);
+  }
+  if (r->d_slab) { // the index arrays are parts of one allocation
+    (void)hipFree(r->d_slab);
+    delete r;
+    return;
   }
   (void)hipFree(r->d_word_off);
   (void)hipFree(r->d_len);

@@ -218,7 +218,7 @@ public:
       chunk_ = std::min<size_t>(chunk_, std::max<size_t>((size_t)in_.plain_size() + 1, size_t(1) << 16));
     }
     front_ = std::min<size_t>(std::max<size_t>(chunk_ / 16, 4096), size_t(16) << 20);
-    buf_.resize(2 * (front_ + chunk_));
+    buf_.resize((size_t)kSlots * (front_ + chunk_));
     const char* pin_min = getenv("GRP_PIN_MIN_BYTES"); // tests: page-lock small buffers too
     if (run_.vt.fastq_pin && run_.vt.fastq_unpin && buf_.size() >= (pin_min ? (size_t)atoll(pin_min) : (size_t(8) << 20))) {
       pinned_ = run_.vt.fastq_pin(run_.ctx, buf_.data(), buf_.size()) == GRP_OK;
@@ -235,6 +235,9 @@ public:
       reader_.join();
     }
     release();
+    if (getenv("GRP_TRACE_INGEST")) {
+      std::cerr << "GRP_TRACE_INGEST source: " << n_pre_[0] << " chunks, next chunk not ready at " << n_pre_[1] << ", uploads started ahead " << n_pre_[2] << std::endl;
+    }
     if (pinned_) {
       run_.vt.fastq_unpin(run_.ctx); // before the buffer goes away: the engine cannot know when the host frees memory
     }
@@ -260,7 +263,7 @@ public:
         cv_.wait(g, [&] { return slot_[take_].state == Slot::READY; });
         sl = &slot_[take_];
         held_ = take_;
-        take_ ^= 1;
+        take_ = (take_ + 1) % kSlots;
       }
       const bool eof = sl->eof;
       char* data = slot_data(held_);
@@ -269,7 +272,7 @@ public:
       size_t fill = carry_.size() + sl->n;
       if (carry_.size() <= front_) {
         text = data - carry_.size();
-        if (!carry_.empty()) {
+        if (!carry_.empty() && text != pre_text_) { // (a prefetched text has its carry in place: the copy is reading it)
           memcpy(text, carry_.data(), carry_.size());
         }
       } else {
@@ -316,9 +319,42 @@ public:
         b.rec[i] = Rec{ (size_t)m.id_off, m.id_len, (size_t)m.seq_off, m.seq_len, (size_t)m.qual_off, m.qual_len };
       }
       b.seq_is_upper = false;
+      prefetch_next();
       return true;
     }
     return false;
+  }
+  // The next chunk's upload, started NOW if the reader has it: the caller is about to queue this chunk's fill, and a
+  // copy issued behind that launch only begins when it has ended (round 5, tools/dev/r5_ingest_timeline.sh: fill 7 ms,
+  // then copy 9 ms, then parse 4.5 ms — one after the other); in front of it, it runs beside it.
+  void prefetch_next()
+  {
+    pre_text_ = nullptr;
+    ++n_pre_[0];
+    if (!run_.vt.fastq_prefetch || done_ || carry_.size() > front_) {
+      return;
+    }
+    size_t n = 0;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      if (slot_[take_].state != Slot::READY) {
+        ++n_pre_[1];
+        return; // the reader is still at it: the parse uploads as before
+      }
+      n = slot_[take_].n; // (a READY slot is the consumer's until it releases it)
+    }
+    const size_t fill = carry_.size() + n;
+    if (fill == 0) {
+      return;
+    }
+    char* text = slot_data(take_) - carry_.size();
+    if (!carry_.empty()) {
+      memcpy(text, carry_.data(), carry_.size());
+    }
+    if (run_.vt.fastq_prefetch(run_.ctx, text, fill) == GRP_OK) {
+      pre_text_ = text;
+      ++n_pre_[2];
+    }
   }
   void stats(Batch& b, size_t min_len, bool) override
   {
@@ -356,7 +392,7 @@ private:
   void read_loop()
   {
     uint64_t off = 0;
-    for (int i = 0;; i ^= 1) {
+    for (int i = 0;; i = (i + 1) % kSlots) {
       {
         std::unique_lock<std::mutex> g(mu_);
         cv_.wait(g, [&] { return stop_ || slot_[i].state == Slot::FREE; });
@@ -396,7 +432,9 @@ private:
   }
   PathRun& run_;
   InputFile in_;
-  std::vector<char> buf_;  // [slot 0: front | chunk][slot 1: front | chunk]
+  std::vector<char> buf_;  // kSlots x [front | chunk]
+  uint64_t n_pre_[3] = { 0, 0, 0 }; // developer trace: chunks returned, next slot not ready, prefetches the engine took
+  const char* pre_text_ = nullptr; // the text whose upload prefetch_next has started (the next call's text, carry included)
   std::vector<char> carry_; // unconsumed tail of the chunk before
   std::vector<char> big_;
   size_t chunk_ = 0, front_ = 0;
@@ -404,7 +442,11 @@ private:
   std::thread reader_;
   std::mutex mu_;
   std::condition_variable cv_;
-  Slot slot_[2];
+  // three chunk buffers (round 5; two before): the caller's batch lives in one, the next one's upload has been started
+  // ahead (prefetch_next) and the reader fills the third — with two the reader could only begin when the caller came
+  // back for the next chunk, and was not done when the upload should have started
+  static constexpr int kSlots = 3;
+  Slot slot_[kSlots];
   int take_ = 0;  // the slot the next chunk arrives in
   int held_ = -1; // the slot the caller's current batch lives in
   bool stop_ = false;
@@ -663,7 +705,16 @@ fill_bit_vector(PathRun& run, Resident& res)
   std::vector<uint32_t> sel, lens;
   uint32_t lead_skipped = 0;
   uint64_t n_batches = 0;
-  while (src->next(b)) {
+  // developer trace (GRP_TRACE_INGEST): where the host's time of this pass goes, per call site
+  static const bool trace = getenv("GRP_TRACE_INGEST") != nullptr;
+  double t_next = 0, t_filter = 0, t_upload = 0, t_fill = 0, t_keep = 0;
+  for (;;) {
+    const double tn0 = trace ? now_s() : 0.0;
+    if (!src->next(b)) {
+      break;
+    }
+    const double tn1 = trace ? now_s() : 0.0;
+    t_next += tn1 - tn0;
     src->stats(b, opt.min_length, true);
     sel.clear();
     ResidentBatch keep;
@@ -709,21 +760,28 @@ fill_bit_vector(PathRun& run, Resident& res)
       res.batches.back().skipped_after += skipped; // a batch without a single selected read
       skipped = 0;
     }
+    const double tf1 = trace ? now_s() : 0.0;
+    t_filter += tf1 - tn1;
     if (!sel.empty()) {
       void* h = nullptr;
       if (src->upload(b, sel, lens, &h) != GRP_OK) {
         return run.fail_engine("uploading reads");
       }
+      const double tu1 = trace ? now_s() : 0.0;
+      t_upload += tu1 - tf1;
       if (prev) {
         run.vt.reads_free(prev); // waits for the previous batch's kernel
         prev = nullptr;
       }
       // multiLensfrHashIterator itr(record.seq, seeds); miBFCS.insertBV(itr)  (:304-305)
-      const bool mine = !run.shard_fill || (n_batches % run.world) == run.rank;
+      static const bool trace_nofill = trace && getenv("GRP_TRACE_NOFILL") != nullptr; // developer: the pass without its fill kernels (timing only: the filter stays empty)
+      const bool mine = !trace_nofill && (!run.shard_fill || (n_batches % run.world) == run.rank);
       ++n_batches;
       if (mine && run.vt.bv_insert(run.ctx, h, 0, (uint32_t)sel.size()) != GRP_OK) {
         return run.fail_engine("bit-vector insert");
       }
+      const double tb1 = trace ? now_s() : 0.0;
+      t_fill += tb1 - tu1;
       if (res.on) {
         for (uint32_t l : lens) {
           res.packed_bytes += ((uint64_t)l + 15) / 16 * 4;
@@ -766,8 +824,14 @@ fill_bit_vector(PathRun& run, Resident& res)
               << "Try again with a lower Phred threshold or lower min length" << std::endl;
     return 1;
   }
+  const double ts0 = trace ? now_s() : 0.0;
   if (run.vt.sync(run.ctx) != GRP_OK) {
     return run.fail_engine("bit-vector insert");
+  }
+  if (trace) {
+    (void)t_keep;
+    std::cerr << "GRP_TRACE_INGEST fill pass: " << n_batches << " batches; host seconds in next() (read + parse) " << t_next << ", filter " << t_filter << ", upload (pack) " << t_upload << ", bv_insert call " << t_fill
+              << ", final sync " << now_s() - ts0 << std::endl;
   }
   if (run.shard_fill) {
     // the bitwise OR of the ranks' vectors (the fill is order-free; csrc/host/gr_ranks.cpp)

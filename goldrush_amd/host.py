@@ -95,6 +95,7 @@ VT_TYPES = [
     ("stream_begin_striped_resumable", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp)),
     ("stream_resumable", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("stream_insert_done", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
+    ("fastq_prefetch", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64)),
 ]
 
 

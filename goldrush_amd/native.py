@@ -113,6 +113,7 @@ SIGNATURES = {
     "grp_debug_decide": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint64, C.POINTER(grp_decide_params), _vp, _vp, _vp]),
     "grp_classify_stream_begin_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.POINTER(C.c_void_p)]),
     "grp_classify_stream_insert": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "grp_debug_touch_filter": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "grp_pshard_query": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
     "grp_comm_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "grp_classify_stream_begin_striped_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
@@ -169,6 +170,7 @@ fastq_record_dtype = np.dtype([("id_off", "<u8"), ("seq_off", "<u8"), ("qual_off
 
 # include/grpath_ingest.h
 SIGNATURES.update({
+    "grp_fastq_prefetch": (C.c_int, [_vp, _vp, C.c_uint64]),
     "grp_fastq_parse": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.POINTER(_vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "grp_fastq_records": (C.c_int, [_vp, _vp]),
     "grp_fastq_pack": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(_vp)]),

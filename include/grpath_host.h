@@ -93,6 +93,8 @@ typedef struct
   int (*stream_begin_striped_resumable)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, uint32_t slot, uint32_t stripe_reads, uint32_t n_owners, uint32_t owner, const grp_read_decision** decisions);
   int (*stream_resumable)(void* ctx, uint32_t slot);
   int (*stream_insert_done)(void* ctx, uint32_t slot); /* grp_classify_stream_insert_done */
+  /* optional (with the fastq_* members; round 5): the next chunk's upload started ahead of its parse, grp_fastq_prefetch */
+  int (*fastq_prefetch)(void* ctx, const char* text, uint64_t n_bytes);
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */

@@ -50,6 +50,15 @@ typedef struct
  * the reader ends there, like a reader at end of input).
  */
 int grp_fastq_parse(grp_ctx* ctx, const char* text, uint64_t n_bytes, int final_chunk, grp_fastq** out, uint64_t* n_records, uint64_t* bytes_consumed, int* stopped);
+/*
+ * Optional (round 5): start the upload of the NEXT chunk now — the very (text, n_bytes) the next grp_fastq_parse will be
+ * given; it then finds its text on the device.  The copy of a 256 MiB chunk takes ~9 ms and, issued from inside
+ * grp_fastq_parse, only began when the fill of the chunk before had ended (the timeline: tools/dev/r5_ingest_timeline.sh);
+ * issued in FRONT of that fill it runs beside it.  The text must stay unchanged until that parse returns.  A prefetch
+ * that is not followed by the matching parse is simply dropped.  GRP_ERR_BUSY: no device buffer is free for it right
+ * now (not an error: the parse uploads as before).
+ */
+int grp_fastq_prefetch(grp_ctx* ctx, const char* text, uint64_t n_bytes);
 /* copy the record table (n_records entries) to the host */
 int grp_fastq_records(grp_fastq* fq, grp_fastq_record* out);
 /*

@@ -41,16 +41,24 @@ def main():
     tmp = os.environ.get("TMPDIR", "/tmp")
     fq = os.path.join(tmp, "cli_e2e.fq")
     t0 = time.perf_counter()
-    g = synth.random_genome(genome, 1)
-    with open(fq, "wb") as fh:
-        done = 0
-        while done < n_reads:  # in slices: the Python objects of 100 k reads would not fit comfortably
-            n = min(5000, n_reads - done)
-            for rid, seq, qual in synth.make_reads(g, n, mean_len=25000, min_len=20000, seed=2 + done):
-                fh.write(b"@r%d\n" % done + seq + b"\n+\n" + qual + b"\n")
-                done += 1
+    # tools/fqgen.c (OpenMP: the reads of a block made by all cores, written in order) where a C compiler is at hand — the
+    # Python generator wrote C1's 51 GB in 227 s, most of a GPU call; the same read model either way
+    gen = os.path.join(os.environ.get("FQGEN_DIR", "/tmp"), "fqgen")  # (not TMPDIR: /dev/shm is mounted noexec)
+    built = subprocess.run(["gcc", "-O3", "-fopenmp", "-o", gen, os.path.join(ROOT, "tools", "fqgen.c"), "-lm"], capture_output=True).returncode == 0
+    if built and subprocess.run([gen, fq, str(n_reads), str(genome), "1"], capture_output=True).returncode == 0:
+        generator = "tools/fqgen.c"
+    else:
+        generator = "goldrush_amd/synth.py"
+        g = synth.random_genome(genome, 1)
+        with open(fq, "wb") as fh:
+            done = 0
+            while done < n_reads:  # in slices: the Python objects of 100 k reads would not fit comfortably
+                n = min(5000, n_reads - done)
+                for rid, seq, qual in synth.make_reads(g, n, mean_len=25000, min_len=20000, seed=2 + done):
+                    fh.write(b"@r%d\n" % done + seq + b"\n+\n" + qual + b"\n")
+                    done += 1
     size = os.path.getsize(fq)
-    res = {"fastq_bytes": size, "reads": n_reads, "genome": genome, "fastq_written_s": time.perf_counter() - t0, "runs": {}}
+    res = {"fastq_bytes": size, "reads": n_reads, "genome": genome, "fastq_written_s": time.perf_counter() - t0, "fastq_generator": generator, "runs": {}}
     base = ["-k22", "-w16", "-t1000", "-u5", "-a1", "-o0.1", "-h3", "-j16", "-P10", "-d5", "-x10", "-s" + SEED, "-g%d" % genome, "-b10", "--verbose"]
     pdir = os.path.join(tmp, "cli_e2e_out")
     os.makedirs(pdir, exist_ok=True)

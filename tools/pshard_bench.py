@@ -100,6 +100,30 @@ def main():
                    "GB_per_s_out_per_gpu_at_this_rate": rate * 8 * (a.owners - 1) / a.owners / 1e9, "GB_per_s_back_per_gpu_at_this_rate": rate * 4 * (a.owners - 1) / a.owners / 1e9,
                    "links": "7 x ~153 GB/s per GPU (the task's hardware note: xGMI is point-to-point, 7 links x ~153 GB/s); an all-to-all uses all seven at once, each carrying 1 / 7 of the remote share",
                    "GB_per_s_per_link_out": rate * 8 / a.owners / 1e9}
+    # ---- a hashed filter of the ranks a batch touched in front of the second query ---------------
+    # The second decisions of the tiles nobody inserted ask the bucket lines again (k_query<.., VER>: the rate of
+    # k_query above) to find the few probes whose rank the batch wrote.  A filter pass instead: hash, test 1 or 2 bits
+    # of a small table, evaluate only the frames that hit.  Sized for a batch of the head: 6 M touched ranks.
+    import ctypes as C
+
+    lib = native.load()
+    touched = 6_000_000
+    rows = []
+    for mib, n_hash in ((2, 1), (8, 1), (16, 1), (16, 2), (64, 2)):
+        bits = mib * (1 << 23)
+        fill = 1.0 - np.exp(-n_hash * touched / bits)
+        ms, dirty, frames = C.c_float(), C.c_uint64(), C.c_uint64()
+        rc = lib.grp_debug_touch_filter(eng._h, rb._h, first, a.window, mib, float(fill), n_hash, C.byref(ms), C.byref(dirty), C.byref(frames))
+        if rc != 0:
+            raise SystemExit("grp_debug_touch_filter: %d" % rc)
+        share = dirty.value / frames.value
+        # a dirty frame is evaluated through the log with h divergent lane-level bucket loads: 27 G/s (tools/gather_bench.hip mode 7)
+        eval_ms = share * frames.value * h / 27e9 * 1e3
+        rows.append({"table_MiB": mib, "hashes": n_hash, "bits_set_share": float(fill), "filter_pass_ms": ms.value, "G_probes_per_s": n_probes / ms.value / 1e6, "dirty_frames_share": share,
+                     "dirty_frames_evaluation_ms_at_27G_lane_loads": eval_ms, "total_ms": ms.value + eval_ms, "second_query_ms_it_replaces": base["kernel_ms"],
+                     "saves_share_of_second_query": 1.0 - (ms.value + eval_ms) / base["kernel_ms"]})
+    res["touched_rank_filter"] = {"what": "hash-and-test pass of a hashed set of the (bucket, bit) positions a batch of 6 M records touched, over the same window; beside it what the frames that hit still cost",
+                                  "rows": rows, "not_counted": "building the filter in the collect pass: one more request per record on a table of this size (the collect pass pays per request, DESIGN 4)"}
     line = json.dumps(res)
     print(line)
     if a.out:
