@@ -130,6 +130,7 @@ struct BatchRun
   uint64_t rec_cap = 0;
   uint32_t* d_ovf_next = nullptr; // touches of a rank by other (read, block)s than its owner's, chained per record
   uint32_t* d_ovf_jb = nullptr;
+  uint32_t* d_chained = nullptr; // the records that own a chain (k_batch_apply walks these, not all records)
   uint64_t ovf_cap = 0;
   unsigned long long* d_log_keys = nullptr;
   uint32_t* d_log_head = nullptr;
@@ -1006,6 +1007,7 @@ grp_destroy(grp_ctx* c)
     (void)hipFree(b.d_rec_chain);
     (void)hipFree(b.d_ovf_next);
     (void)hipFree(b.d_ovf_jb);
+    (void)hipFree(b.d_chained);
     (void)hipFree(b.d_log_keys);
     (void)hipFree(b.d_log_head);
     (void)hipFree(b.d_log_bits);

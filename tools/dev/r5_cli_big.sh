@@ -1,14 +1,13 @@
 #!/bin/bash
-# round 5, GPU box: the binary end to end at C1 size (1 M reads, 51 GB of FASTQ in /tmp) and at C2 size (10 M reads of a 3 Gbp
-# genome, ~256 GB of FASTQ in /dev/shm: the box's /tmp holds 79 GB, its RAM 3 TB), one run each, reads kept on the device
+# round 5, GPU box: the binary end to end at C1 size (1 M reads, 51 GB of FASTQ in /tmp: the largest input this pool's boxes
+# hold), one run each, reads kept on the device
 out=gpurun_out
 mkdir -p $out
 export CLI_E2E_REPEATS=1 CLI_E2E_MODES=resident
 TMPDIR=/tmp timeout 1500 python3 tools/cli_end_to_end.py $out/r05_cli_end_to_end_c1.json 1000000 > $out/r05_cli_e2e_c1.log 2>&1
-df -h /dev/shm | tail -1
-TMPDIR=/dev/shm timeout 2400 python3 tools/cli_end_to_end.py $out/r05_cli_end_to_end_c2.json 10000000 3000000000 > $out/r05_cli_e2e_c2.log 2>&1
-rm -rf /dev/shm/cli_e2e* 2>/dev/null
-python3 - $out/r05_cli_end_to_end_c1.json $out/r05_cli_end_to_end_c2.json <<'PY'
+# (A C2-size run — 10 M reads, ~256 GB of FASTQ — does not fit this pool's boxes: /tmp holds 79 GB, and /dev/shm counts against
+# the container's memory: writing the file there took the box down, round 5.  Do not try again.)
+python3 - $out/r05_cli_end_to_end_c1.json <<'PY'
 import json, sys
 for f in sys.argv[1:]:
     try:

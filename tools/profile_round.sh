@@ -25,7 +25,13 @@ python3 bench.py --config C4 --reads 4000000 --no-cpu-baseline > $out/${tag}_ben
 # exactness at full size: C2's head (61 Gbit filter, 700 k reads) through the default path twice and
 # through the classic windows only; one rank against two ranks (C1 and C2): the run's counters
 tools/dev/mode_truth_check.sh C2 1500000 > $out/${tag}_truth_modes_c2.txt 2>&1
-(tools/dev/rank_truth_check.sh C1 300000; tools/dev/rank_truth_check.sh C2 600000) > $out/${tag}_truth_ranks.txt 2>&1
+(tools/dev/rank_truth_check.sh C1 300000 ${tag}; tools/dev/rank_truth_check.sh C2 600000 ${tag}) > $out/${tag}_truth_ranks.txt 2>&1
+# the N = 8 time model from this build's default line and the measured 1-rank / 2-rank pair (counted constants)
+python3 tools/scale_model.py $out/${tag}_bench_default_flags.json --ranks $out/${tag}_ranks_C1_one.json $out/${tag}_ranks_C1_two.json > $out/${tag}_scale_model.txt 2>&1
+# a repeat-rich genome (40 % repeat families): golden pass + pipeline-shaped pass, aux.repeats
+python3 bench.py --repeat-frac 0.4 --no-cpu-baseline > $out/${tag}_bench_repeats.json 2> /dev/null
+# what a record of the collect pass costs by where its count lives (gather_bench modes 21-37, 50)
+tools/collect_matrix.sh ${tag} > /dev/null 2>&1
 # the drop-in binary end to end: 100 k reads of C1 as a 5 GB FASTQ, silver and golden, reads kept on the device / second parse
 timeout 1500 python3 tools/cli_end_to_end.py $out/${tag}_cli_end_to_end.json 100000 > $out/${tag}_cli_e2e.log 2>&1
 # two ranks on the one GPU (gloo): plumbing of the N > 1 path (fill merge, striped windows, shm exchange)
