@@ -52,7 +52,7 @@ struct QuerySlot
   grp_id_count* d_lists = nullptr;
   uint64_t d_lists_cap = 0;
   uint64_t* d_qctr = nullptr; // [3] list arena cursor, [4] flagged tiles (kept zero between calls)
-  uint64_t* h_qctr = nullptr; // pinned
+  uint64_t* h_qctr = nullptr; // pinned: the first 64 bytes of h_dec_raw (one copy brings counters and decisions, slot_dec_alloc)
   uint32_t* d_flag_idx = nullptr;
   uint64_t d_flag_cap = 0;
   // decide scratch
@@ -63,8 +63,10 @@ struct QuerySlot
   uint32_t* d_long_reads = nullptr;
   uint64_t long_reads_cap = 0;
   uint64_t d_dec_cap = 0;
-  grp_read_decision* d_dec = nullptr;
-  grp_read_decision* h_dec = nullptr; // pinned
+  grp_read_decision* d_dec = nullptr; // = d_dec_raw + 2: two entries (64 bytes) in front of the decisions carry the window's counters
+  grp_read_decision* h_dec = nullptr; // = h_dec_raw + 2, pinned
+  grp_read_decision* d_dec_raw = nullptr;
+  grp_read_decision* h_dec_raw = nullptr;
   uint64_t dec_cap = 0;
   // a window in flight (grp_classify_reads_begin)
   hipEvent_t done = nullptr;   // decisions of the window are in h_dec
@@ -116,9 +118,12 @@ struct BatchRun
   bool active = false;
   uint32_t n_ins = 0, block_tiles = 0;
   uint64_t n_units = 0, n_rec = 0;
-  uint32_t h_counters[4] = { 0, 0, 0, 0 }; // -, chained touches, log entries, error
+  uint32_t* h_counters = nullptr; // page-locked [4]: records that own a chain, chained touches, log entries, error
   std::vector<uint32_t> h_ins;    // [n_ins][6]: read, tile_start, tile_end, first_id, id_offset, first unit
-  uint32_t* d_counters = nullptr;
+  uint32_t* h_ins_stage = nullptr; // page-locked copy of h_ins: the upload does not wait for the stream
+  uint64_t ins_stage_cap = 0;
+  uint32_t* d_counters = nullptr; // two sets of 4: a batch's clean-up zeroes the NEXT batch's set (k_batch_clear)
+  uint32_t ctr_set = 0;
   uint32_t* d_ins = nullptr;
   uint64_t ins_cap = 0;
   uint32_t epoch = 0; // of the current / last batch: the claim field of the count words (grp_device.h), 1 .. GRP_EPOCH_MAX
@@ -201,6 +206,8 @@ struct grp_ctx
   std::vector<std::string> seeds;
   DevSeeds h_seeds{};
   DevSeeds* d_seeds = nullptr;
+  uint32_t* d_gtab = nullptr; // count tables of k_query<..., GT> (query_geom: tiles whose worst case does not fit the LDS)
+  uint64_t gtab_cap = 0;
   DevFilter f{};
   uint64_t nsb = 0;      // superbuckets
   uint64_t n_bv_words = 0;
@@ -540,11 +547,41 @@ decide_lds_bytes(uint32_t lds_tiles)
     default: { constexpr int HH = 8; CALL; } break;                                                                    \
   }
 
+// decision buffers of a slot: [64 bytes of counters][cap decisions], on the device and page-locked on the host
+int
+slot_dec_alloc(grp_ctx* c, QuerySlot& sl, uint64_t cap)
+{
+  static_assert(2 * sizeof(grp_read_decision) == 8 * sizeof(uint64_t), "the counters take two decision entries");
+  (void)hipFree(sl.d_dec_raw);
+  sl.d_dec_raw = sl.d_dec = nullptr;
+  if (sl.h_dec_raw) {
+    (void)hipHostFree(sl.h_dec_raw);
+    sl.h_dec_raw = sl.h_dec = nullptr;
+  }
+  sl.h_qctr = nullptr;
+  sl.dec_cap = 0;
+  HIP_TRY(c, hipMalloc(&sl.d_dec_raw, (cap + 2) * sizeof(grp_read_decision)));
+  HIP_TRY(c, hipHostMalloc(&sl.h_dec_raw, (cap + 2) * sizeof(grp_read_decision), hipHostMallocDefault));
+  memset(sl.h_dec_raw, 0, 2 * sizeof(grp_read_decision));
+  sl.d_dec = sl.d_dec_raw + 2;
+  sl.h_dec = sl.h_dec_raw + 2;
+  sl.h_qctr = reinterpret_cast<uint64_t*>(sl.h_dec_raw);
+  sl.dec_cap = cap;
+  return GRP_OK;
+}
+
+template<typename T>
+int ensure_dev(grp_ctx* c, T*& p, uint64_t& cap, uint64_t want);
+
+constexpr size_t LDS_PER_WORKGROUP = 160 * 1024 - 512; // gfx950, less the kernels' static shared variables
+constexpr uint32_t GT_SLICE = 256;                     // workgroups of one launch with global count tables
+
 struct QueryGeom
 {
   uint32_t hist_cap;       // slots of the per-tile count table (even; 6 bytes each: a key and a 16-bit count)
   uint32_t distinct_limit; // distinct IDs it takes (the rest is room for the claims in flight)
   size_t lds;
+  bool global_table = false; // the worst-case table does not fit the LDS: it lives in global memory (k_query<..., GT>; the redo launches only)
 };
 
 // The per-tile count table (k_query).  full = worst case: every probe of the tile a different ID — tile * h slots
@@ -580,6 +617,12 @@ query_geom(const grp_ctx* c, bool full)
   }
   g.distinct_limit = g.hist_cap - THREADS * h - 1;
   g.lds = lds_of(g.hist_cap);
+  if (full && g.lds > LDS_PER_WORKGROUP) {
+    // Round 5: tiles beyond ~9 000 frames at h = 3 (the reference has no such limit).  The first step's table is LDS-sized
+    // (above: the three-workgroups budget); what it cannot hold is redone with the worst-case table in global memory.
+    g.global_table = true;
+    g.lds = lds_of(0);
+  }
   return g;
 }
 
@@ -624,7 +667,8 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
         uint32_t a_fcap = (uint32_t)c->q->d_flag_cap, a_ds = direct_stride, a_blk0 = blk0;
         DevStreamCtl a_sc = *stream_ctl;
         DevBatchView a_bv{};
-        void* args[] = { &a_f, &a_rd, &a_sd, &a_tile, &a_t0, &a_idx, &a_cap, &a_lim, &a_tiles, &a_lists, &a_lcap, &a_ctr, &a_flag, &a_fcap, &a_ds, &a_blk0, &a_sc, &a_bv };
+        uint32_t* a_gtab = nullptr;
+        void* args[] = { &a_f, &a_rd, &a_sd, &a_tile, &a_t0, &a_idx, &a_cap, &a_lim, &a_tiles, &a_lists, &a_lcap, &a_ctr, &a_flag, &a_fcap, &a_ds, &a_blk0, &a_sc, &a_bv, &a_gtab };
         const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3((uint32_t)n_launch), dim3(THREADS), args, (unsigned int)g.lds, c->stream);
         if (e == hipSuccess) {
           return GRP_OK;
@@ -633,7 +677,7 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
         return set_err(c, GRP_ERR_BUSY, "cooperative launch of a resumable window refused: %s", hipGetErrorString(e));
       }
     }
-    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, blk0, stream_ctl ? *stream_ctl : DevStreamCtl{}, (c->view && !plain) ? *c->view : DevBatchView{});
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, blk0, stream_ctl ? *stream_ctl : DevStreamCtl{}, (c->view && !plain) ? *c->view : DevBatchView{}, nullptr);
     return GRP_OK;
   };
   // The synchronous forms (large windows, the two queries of a batch): two frames per lane and pass
@@ -641,6 +685,41 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
   // at h = 5; C4 geometry +4 %, h = 3 -3 %: measured, tools/dev/r3_fr1.sh of round 3; round 4 again with the 24 KB count table:
   // the head of C2 2.94 - 3.04 s against 2.94 - 2.96 s, no gain, the switch is gone)
   constexpr int SFR = (HH <= 3) ? 2 : 1;
+  if (g.global_table) {
+    // the worst-case table in global memory, GT_SLICE workgroups (and tables) per launch
+    if (stream_ctl || direct_stride) {
+      return set_err(c, GRP_ERR_STATE, "launch_query: a global count table in a streaming / zero-copy launch");
+    }
+    const uint64_t words = (uint64_t)g.hist_cap + g.hist_cap / 2u;
+    if (const int rc = ensure_dev(c, c->d_gtab, c->gtab_cap, words * GT_SLICE); rc != GRP_OK) {
+      return rc;
+    }
+    const bool ver = c->view && !plain;
+    for (uint64_t off = 0; off < n_launch; off += GT_SLICE) {
+      const uint32_t nb = (uint32_t)std::min<uint64_t>(GT_SLICE, n_launch - off);
+      const uint32_t* idx = d_tile_idx ? d_tile_idx + off : nullptr;
+      const uint32_t b0 = d_tile_idx ? blk0 : blk0 + (uint32_t)off;
+      uint32_t* const flag_out = (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx;
+      if (ver) {
+        DevBatchView v = *c->view;
+        if (v.redo_count && off) {
+          break; // (a launch sized before its list was known covers one slice: longer lists take the host's way)
+        }
+        auto kern = k_query<HH, 1, 0, false, true, true>;
+        if (const int rc = ensure_lds(c, kern, g.lds); rc != GRP_OK) {
+          return rc;
+        }
+        kern<<<dim3(nb), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, idx, g.hist_cap, g.distinct_limit, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), flag_out, (uint32_t)c->q->d_flag_cap, 0u, b0, DevStreamCtl{}, v, c->d_gtab);
+      } else {
+        auto kern = k_query<HH, 1, 0, false, false, true>;
+        if (const int rc = ensure_lds(c, kern, g.lds); rc != GRP_OK) {
+          return rc;
+        }
+        kern<<<dim3(nb), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, idx, g.hist_cap, g.distinct_limit, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), flag_out, (uint32_t)c->q->d_flag_cap, 0u, b0, DevStreamCtl{}, DevBatchView{}, c->d_gtab);
+      }
+    }
+    return GRP_OK;
+  }
   if (c->view && !stream_ctl && !plain) { // grp_batch_classify: every read sees the state in front of its own insert
     return go(k_query<HH, SFR, 0, false, true>);
   }
@@ -779,6 +858,9 @@ grp_create(const grp_params* p, grp_ctx** out)
   if (p->tile < p->k + p->h - 1) {
     return set_err(nullptr, GRP_ERR_INVALID, "tile length %u shorter than the longest seed span %u", p->tile, p->k + p->h - 1);
   }
+  if (p->tile > 65535u) {
+    return set_err(nullptr, GRP_ERR_INVALID, "tile length %u: a tile holds at most 65 535 frames (an ID's count per tile is 16 bits)", p->tile);
+  }
   // m = 0: the size is not known yet (--ntcard estimates it from the reads);
   // grp_set_filter_size() must follow before the first grp_bv_insert
   if (p->m != 0 && (p->m < 64 || p->m >= (1ULL << 50))) {
@@ -825,9 +907,9 @@ grp_create(const grp_params* p, grp_ctx** out)
   }
   // LDS geometry of the query kernel's worst-case launch must fit one workgroup
   {
-    const QueryGeom g = query_geom(c, true);
-    if (g.lds > 160 * 1024 - 512) {
-      set_err(c, GRP_ERR_INVALID, "tile*h=%llu needs %zu B of LDS per workgroup (limit 160 KiB)", (unsigned long long)p->tile * p->h, g.lds);
+    const QueryGeom g = query_geom(c, true), g1 = query_geom(c, false);
+    if (g.lds > LDS_PER_WORKGROUP || g1.lds > LDS_PER_WORKGROUP || g1.hist_cap <= (uint32_t)THREADS * p->h + 64) {
+      set_err(c, GRP_ERR_INVALID, "tile=%u h=%u needs %zu B of LDS per workgroup beside the count table (limit 160 KiB)", p->tile, p->h, std::max(g.lds, g1.lds));
       return fail(GRP_ERR_INVALID);
     }
   }
@@ -871,7 +953,9 @@ grp_create(const grp_params* p, grp_ctx** out)
   }
   for (QuerySlot& sl : c->slot) {
     CREATE_TRY(hipMalloc(&sl.d_qctr, 8 * sizeof(uint64_t)));
-    CREATE_TRY(hipHostMalloc(&sl.h_qctr, 8 * sizeof(uint64_t), hipHostMallocDefault));
+    if (const int arc = slot_dec_alloc(c, sl, 1024); arc != GRP_OK) {
+      return fail(arc);
+    }
     CREATE_TRY(hipMemsetAsync(sl.d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
     CREATE_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&sl.qdone, hipEventDisableTiming));
@@ -930,17 +1014,14 @@ grp_destroy(grp_ctx* c)
     (void)hipFree(sl.d_tiles);
     (void)hipFree(sl.d_lists);
     (void)hipFree(sl.d_qctr);
-    if (sl.h_qctr) {
-      (void)hipHostFree(sl.h_qctr);
-    }
     (void)hipFree(sl.d_flag_idx);
     (void)hipFree(sl.d_dec_ids);
     (void)hipFree(sl.d_dec_asg);
     (void)hipFree(sl.d_dec_scratch);
     (void)hipFree(sl.d_long_reads);
-    (void)hipFree(sl.d_dec);
-    if (sl.h_dec) {
-      (void)hipHostFree(sl.h_dec);
+    (void)hipFree(sl.d_dec_raw);
+    if (sl.h_dec_raw) {
+      (void)hipHostFree(sl.h_dec_raw);
     }
     if (sl.done) {
       (void)hipEventDestroy(sl.done);
@@ -1020,11 +1101,18 @@ grp_destroy(grp_ctx* c)
     if (b.h_vf_stage) {
       (void)hipHostFree(b.h_vf_stage);
     }
+    if (b.h_counters) {
+      (void)hipHostFree(b.h_counters);
+    }
+    if (b.h_ins_stage) {
+      (void)hipHostFree(b.h_ins_stage);
+    }
   }
   (void)hipFree(c->d_ntc);
   (void)hipFree(c->d_ntc_chunks);
   (void)hipFree(c->d_ntc_extra);
   (void)hipFree(c->d_seeds);
+  (void)hipFree(c->d_gtab);
   (void)hipFree(c->f.bv);
   (void)hipFree(c->f.buckets);
   (void)hipFree(c->d_super);
@@ -1873,7 +1961,7 @@ classify_enqueue_decide(grp_ctx* c, QuerySlot& sl, hipStream_t st)
     }
   }
   k_decide<<<dim3(sl.count), dim3(DECIDE_THREADS), 0, st>>>(sl.reads->dev, sl.first, sl.count, sl.dp, sl.d_tiles, sl.d_lists, sl.list_cap, sl.d_dec_ids, sl.d_dec_asg, sl.d_dec_scratch, sl.d_dec, 0u, nullptr,
-                                                            longs.empty() ? 0u : 4u * LANE_TILES);
+                                                            longs.empty() ? 0u : 4u * LANE_TILES, reinterpret_cast<unsigned long long*>(sl.d_qctr), reinterpret_cast<unsigned long long*>(sl.d_dec_raw));
   HIP_TRY(c, hipGetLastError());
   if (!longs.empty()) {
     const uint32_t lds_tiles = (uint32_t)std::min<uint64_t>((most + 63) / 64 * 64, DECIDE_LDS_MAX_TILES);
@@ -1892,13 +1980,18 @@ classify_enqueue_decide(grp_ctx* c, QuerySlot& sl, hipStream_t st)
   return GRP_OK;
 }
 
-// counters + decisions to pinned memory, counters re-zeroed, completion event
+// counters + decisions to pinned memory, completion event.  ONE copy: the window's k_decide has moved the counters into the
+// 64 bytes in front of the decisions and zeroed them (round 5: this was two copies and a fill, each with its gap on the stream,
+// behind every window and every batch).
 int
 classify_enqueue_fetch(grp_ctx* c, QuerySlot& sl, hipStream_t st)
 {
-  HIP_TRY(c, hipMemcpyAsync(sl.h_qctr, sl.d_qctr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-  HIP_TRY(c, hipMemcpyAsync(sl.h_dec, sl.d_dec, (size_t)sl.count * sizeof(grp_read_decision), hipMemcpyDeviceToHost, st));
-  HIP_TRY(c, hipMemsetAsync(sl.d_qctr, 0, 8 * sizeof(uint64_t), st));
+  if (sl.count == 0) { // no decide launch: the counters alone
+    HIP_TRY(c, hipMemcpyAsync(sl.h_qctr, sl.d_qctr, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(c, hipMemsetAsync(sl.d_qctr, 0, 8 * sizeof(uint64_t), st));
+  } else {
+    HIP_TRY(c, hipMemcpyAsync(sl.h_dec_raw, sl.d_dec_raw, ((size_t)sl.count + 2) * sizeof(grp_read_decision), hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(c, hipEventRecord(sl.done, st));
   sl.side_used = (st != c->stream);
   return GRP_OK;
@@ -1968,17 +2061,9 @@ classify_setup(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count, c
   c->q = &sl;
   // decision buffers + scratch for reads too long for the LDS path
   if (count > sl.dec_cap) {
-    (void)hipFree(sl.d_dec);
-    sl.d_dec = nullptr;
-    if (sl.h_dec) {
-      (void)hipHostFree(sl.h_dec);
-      sl.h_dec = nullptr;
+    if (const int rc = slot_dec_alloc(c, sl, std::max<uint64_t>((uint64_t)count + count / 4, 1024)); rc != GRP_OK) {
+      return rc;
     }
-    sl.dec_cap = 0;
-    const uint64_t cap = std::max<uint64_t>((uint64_t)count + count / 4, 1024);
-    HIP_TRY(c, hipMalloc(&sl.d_dec, cap * sizeof(grp_read_decision)));
-    HIP_TRY(c, hipHostMalloc(&sl.h_dec, cap * sizeof(grp_read_decision), hipHostMallocDefault));
-    sl.dec_cap = cap;
   }
   if (nt + 1 > sl.d_dec_cap) {
     (void)hipFree(sl.d_dec_ids);

@@ -87,6 +87,38 @@ def test_hip_classifier_on_a_repeat_rich_genome(oracle, native, mode, monkeypatc
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["auto", "batch", "stream"])
+def test_hip_classifier_with_tiles_of_12000_bases(oracle, native, mode, monkeypatch):
+    """-t 12000 at h = 3: 36 000 possible IDs per tile do not fit the LDS (rounds 1-4: a loud error at grp_create; the
+    reference has no such limit).  The product's windows, batches and streaming launches on that geometry against the
+    oracle's serial loop (-x 1500: the reference's threshold is a count per tile, and a tile of 12 000 frames collects
+    a few hundred chance hits per ID at this occupancy)."""
+    from goldrush_amd import host, synth
+    from oracle_engine import cached_serial_reference
+
+    env = {"auto": {}, "batch": {"GRP_BATCH": "force"}, "stream": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "force"}}[mode]
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    tile, k, h, block = 12000, 22, 3, 2
+    seeds = default_seeds(h)
+    g = synth.random_genome(3_000_000, 23)
+    reads = [r[1] for r in synth.make_reads(g, 48, mean_len=200000, min_len=120000, seed=24, max_len=330000)]
+    m = oracle.load().orc_calc_optimal_size(12_000_000, 1, 0.1)
+    exp, ref_ids, ref_counts, ref_pop = cached_serial_reference("classifier_tile12000", oracle, m, seeds, tile, k, reads, block=block, threshold=1500, u=3, silver=True, target_bases=2_500_000, max_paths=3)
+    eng = native.Engine(k, h, tile, m, seeds)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    assert eng.finalize() == ref_pop
+    cls = host.Classifier(eng._h, host.hip_engine_vt(), tile=tile, block=block, threshold=1500, unassigned_min=3, k=k, h=h, target_bases=2_500_000, max_paths=3, silver_path=True, max_window=4096)
+    cls.run(b._h, b.lens)
+    eng.sync()
+    assert [c[:8] for c in cls.commits] == exp
+    ids, counts = eng.export_ids()
+    assert np.array_equal(ids, ref_ids) and np.array_equal(counts, ref_counts)
+    st = cls.state()
+    assert st["inserts"] == sum(1 for e in exp if e[1] in (2, 4)) and st["inserts"] >= 3
+
+
 def test_golden_fixture_through_cli(native, tmp_path):
     from goldrush_amd import host
 

@@ -194,6 +194,32 @@ def test_tiles_where_every_probe_returns_another_id(oracle, native, h):
     eng.stream_end(0)
 
 
+@pytest.mark.parametrize("tile,h", [(12000, 3), (20000, 2), (9000, 5)])
+def test_tiles_whose_worst_case_table_does_not_fit_the_lds(oracle, native, tile, h):
+    """tile x h distinct IDs beyond what 160 KB of LDS hold (the reference has no such limit; rounds 1-4 refused these
+    geometries): the first step's table is LDS-sized, the tiles it cannot hold are redone with the table in global
+    memory (k_query<.., GT>) - in grp_query_tiles and in grp_classify_reads.  Every probe another ID = the worst case;
+    a handful of IDs = the first step alone.  Same results as the oracle either way."""
+    eng, oseeds, omf, m = _mk(oracle, native, h=h, tile=tile, m=oracle.load().orc_calc_optimal_size(600_000, 1, 0.1))
+    reads = random_reads(4, 2 * tile + 300, 3 * tile + 900, seed=71 + h)
+    b = eng.upload(reads)
+    eng.bv_insert(b)
+    for s in reads:
+        omf.bv_insert_read(s)
+    pop = eng.finalize()
+    assert pop == omf.finalize()
+    rng = np.random.default_rng(9)
+    for n_ids, flagged in ((1 << 30, True), (25, False)):
+        ids = rng.integers(1, n_ids, size=pop, dtype=np.uint32)
+        eng.import_ids(0, ids=ids, counts=np.zeros(pop, dtype=np.uint32))
+        omf.ids()[:] = ids
+        before = eng.verify_stats()["window_flagged"]
+        _compare_queries(eng, omf, b, reads)
+        dec = eng.classify_reads(b)
+        assert all(int(d["num_tiles"]) == len(r) // tile for d, r in zip(dec, reads))
+        assert (eng.verify_stats()["window_flagged"] > before) == flagged
+
+
 @pytest.mark.parametrize("h,tile", [(1, 1000), (5, 1000), (3, 500), (2, 64), (4, 1000), (6, 250), (7, 1000), (4, 190)])
 def test_other_geometries(oracle, native, h, tile):
     k = 22
