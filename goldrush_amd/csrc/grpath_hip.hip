@@ -191,6 +191,8 @@ struct LoopRun
   const grp_reads* reads_for_trace = nullptr;
 };
 
+constexpr int FQ_TEXT_SLOTS = 3; // device text buffers of the FASTQ ingest (grp_ingest.inc)
+
 struct grp_ctx
 {
   int device = 0;
@@ -202,6 +204,7 @@ struct grp_ctx
   // decision kernel + copy-back of a pipelined window run here, next to the following
   // window's query kernel on `stream`
   hipStream_t stream2 = nullptr;
+  hipStream_t stream3 = nullptr; // the uploads of coming FASTQ chunks (grp_fastq_prefetch): a copy must not stand in front of the parse of the chunk before it
   grp_params params{};
   std::vector<std::string> seeds;
   DevSeeds h_seeds{};
@@ -294,14 +297,18 @@ struct grp_ctx
   // 256 MiB of text among them — every hipFree waits for the device)
   struct IngestPool
   {
-    uint8_t* text[2] = { nullptr, nullptr }; // two chunks can be alive at once (parsed / being packed)
-    uint64_t text_cap[2] = { 0, 0 };
-    bool text_used[2] = { false, false };
-    int last_slot = 1; // the slot the chunk before took (the next one takes the other)
-    // grp_fastq_prefetch: the text of the next chunk is on its way into this slot (-1: none)
-    int pre_slot = -1;
-    const char* pre_text = nullptr;
-    uint64_t pre_bytes = 0;
+    uint8_t* text[FQ_TEXT_SLOTS] = {}; // the chunk being packed, the next one (uploaded ahead) and the one after (uploading)
+    uint64_t text_cap[FQ_TEXT_SLOTS] = {};
+    bool text_used[FQ_TEXT_SLOTS] = {};
+    int last_slot = FQ_TEXT_SLOTS - 1; // the slot handed out last (the next one takes the one after it)
+    // grp_fastq_prefetch: bodies of coming chunks on their way into slots, oldest first
+    struct Pre
+    {
+      int slot = -1;
+      const char* body = nullptr;
+      uint64_t n_body = 0;
+    } pre[2];
+    int n_pre = 0;
     uint32_t* d_counts = nullptr;
     uint64_t counts_cap = 0;
     uint64_t *d_base = nullptr, *d_super = nullptr, *d_total = nullptr, *d_nl = nullptr;
@@ -312,7 +319,16 @@ struct grp_ctx
     uint32_t* d_len = nullptr;
     uint64_t so_cap = 0, wo_cap = 0, len_cap = 0;
     hipEvent_t uploaded = nullptr; // the chunk's text has arrived (copied on the side stream, beside the fill of the chunk before)
-    hipEvent_t text_done[2] = { nullptr, nullptr }; // the main stream's last use of the slot's text (grp_fastq_free records it: the next upload into the slot waits for it, not the host)
+    // page-locked, device-mapped staging of a parse (grp_ingest.inc: ingest_stage): [0] newlines, [1] end of the last record
+    uint64_t* h_scal = nullptr;
+    uint64_t* dm_scal = nullptr;
+    uint8_t* h_front = nullptr; // the bytes in front of a prefetched body
+    uint8_t* dm_front = nullptr;
+    uint8_t* h_rec = nullptr; // the record table
+    uint8_t* dm_rec = nullptr;
+    uint64_t h_rec_bytes = 0;
+    hipEvent_t text_up[FQ_TEXT_SLOTS] = {};   // the slot's prefetched body has arrived (recorded on the copy stream)
+    hipEvent_t text_done[FQ_TEXT_SLOTS] = {}; // the main stream's last use of the slot's text (grp_fastq_free records it: the next upload into the slot waits for it, not the host)
   } ingest;
   const char* reg_text = nullptr; // the caller's text buffer, page-locked by grp_fastq_pin
   size_t reg_bytes = 0;
@@ -858,7 +874,7 @@ grp_create(const grp_params* p, grp_ctx** out)
   if (p->tile < p->k + p->h - 1) {
     return set_err(nullptr, GRP_ERR_INVALID, "tile length %u shorter than the longest seed span %u", p->tile, p->k + p->h - 1);
   }
-  if (p->tile > 65535u) {
+  if (p->tile > GRP_MAX_TILE) {
     return set_err(nullptr, GRP_ERR_INVALID, "tile length %u: a tile holds at most 65 535 frames (an ID's count per tile is 16 bits)", p->tile);
   }
   // m = 0: the size is not known yet (--ntcard estimates it from the reads);
@@ -940,6 +956,10 @@ grp_create(const grp_params* p, grp_ctx** out)
       (void)hipGetLastError();
     }
     CREATE_TRY(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi));
+    // the copy stream at the LOWEST priority: streams of one priority may share a hardware queue, and the barrier packets
+    // around a 5 ms DMA copy then hold back whatever else that queue carries (round 5: with both side streams at the
+    // highest priority the parse kernels of a chunk started exactly when the copy of the chunk after next ended)
+    CREATE_TRY(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, lo));
   }
   CREATE_TRY(hipMalloc(&c->d_seeds, sizeof(DevSeeds)));
   CREATE_TRY(hipMemcpyAsync(c->d_seeds, &c->h_seeds, sizeof(DevSeeds), hipMemcpyHostToDevice, c->stream));
@@ -994,6 +1014,9 @@ grp_destroy(grp_ctx* c)
   if (getenv("GRP_DEBUG_STATS")) {
     fprintf(stderr, "grp stats: direct windows %llu (fallbacks %llu), general windows %llu, redo launches %llu, flagged tiles %llu\n", (unsigned long long)c->n_direct_windows,
             (unsigned long long)c->n_direct_fallbacks, (unsigned long long)c->n_general_windows, (unsigned long long)c->n_redo_launches, (unsigned long long)c->n_flagged_tiles);
+  }
+  if (c->stream3) {
+    (void)hipStreamSynchronize(c->stream3);
   }
   if (c->stream2) {
     (void)hipStreamSynchronize(c->stream2);
@@ -1136,7 +1159,7 @@ grp_destroy(grp_ctx* c)
   (void)hipFree(c->ovl.d_n);
   (void)hipFree(c->ovl.d_tab);
   (void)hipFree(c->ovl.d_prev);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < FQ_TEXT_SLOTS; ++i) {
     (void)hipFree(c->ingest.text[i]);
   }
   (void)hipFree(c->ingest.d_counts);
@@ -1154,6 +1177,21 @@ grp_destroy(grp_ctx* c)
       e = nullptr;
     }
   }
+  if (c->ingest.h_scal) {
+    (void)hipHostFree(c->ingest.h_scal);
+  }
+  if (c->ingest.h_front) {
+    (void)hipHostFree(c->ingest.h_front);
+  }
+  if (c->ingest.h_rec) {
+    (void)hipHostFree(c->ingest.h_rec);
+  }
+  for (hipEvent_t& e : c->ingest.text_up) {
+    if (e) {
+      (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+  }
   if (c->ingest.uploaded) {
     (void)hipEventDestroy(c->ingest.uploaded);
   }
@@ -1163,6 +1201,9 @@ grp_destroy(grp_ctx* c)
   (void)hipFree(c->d_ir_locs);
   (void)hipFree(c->d_ir_slots);
   (void)hipFree(c->d_ir_counter);
+  if (c->stream3) {
+    (void)hipStreamDestroy(c->stream3);
+  }
   if (c->stream2) {
     (void)hipStreamDestroy(c->stream2);
   }
@@ -2807,6 +2848,7 @@ grp_sync(grp_ctx* c)
   if (!c) {
     return GRP_ERR_INVALID;
   }
+  HIP_TRY(c, hipStreamSynchronize(c->stream3));
   HIP_TRY(c, hipStreamSynchronize(c->stream2));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return GRP_OK;

@@ -203,7 +203,7 @@ private:
 // raw text chunks parsed, filtered and packed on the GPU (grpath_ingest.h).
 // A reader thread keeps the NEXT chunk of the file coming (InputFile: parallel pread of a plain
 // file, zlib for gzip data) while the caller works on the current one — upload, parse, pack, fill
-// or classify — so a pass costs max(read, GPU) per chunk instead of their sum.  Two slots in ONE
+// or classify — so a pass costs max(read, GPU) per chunk instead of their sum.  Four slots in ONE
 // page-locked buffer; every slot has room in front of the bytes read for the unconsumed tail of
 // the chunk before it (a partial record), which is copied there before the parse.
 class GpuSource : public RecordSource
@@ -236,7 +236,8 @@ public:
     }
     release();
     if (getenv("GRP_TRACE_INGEST")) {
-      std::cerr << "GRP_TRACE_INGEST source: " << n_pre_[0] << " chunks, next chunk not ready at " << n_pre_[1] << ", uploads started ahead " << n_pre_[2] << std::endl;
+      std::cerr << "GRP_TRACE_INGEST source: " << n_pre_[0] << " chunks, next chunk not ready at " << n_pre_[1] << ", uploads started ahead " << n_pre_[2] << "; seconds waiting for the reader " << t_tr_[0]
+                << ", in fastq_parse " << t_tr_[1] << ", in fastq_prefetch " << t_tr_[2] << ", copying tails " << t_tr_[3] << std::endl;
     }
     if (pinned_) {
       run_.vt.fastq_unpin(run_.ctx); // before the buffer goes away: the engine cannot know when the host frees memory
@@ -256,11 +257,14 @@ public:
       {
         std::unique_lock<std::mutex> g(mu_);
         if (held_ >= 0) {
+          slot_[held_].uploaded = false;
           slot_[held_].state = Slot::FREE;
           held_ = -1;
           cv_.notify_all();
         }
+        const double tw0 = now_s();
         cv_.wait(g, [&] { return slot_[take_].state == Slot::READY; });
+        t_tr_[0] += now_s() - tw0;
         sl = &slot_[take_];
         held_ = take_;
         take_ = (take_ + 1) % kSlots;
@@ -272,8 +276,10 @@ public:
       size_t fill = carry_.size() + sl->n;
       if (carry_.size() <= front_) {
         text = data - carry_.size();
-        if (!carry_.empty() && text != pre_text_) { // (a prefetched text has its carry in place: the copy is reading it)
+        if (!carry_.empty()) { // (a prefetch reads the slot's body only: the room in front of it is free to write)
+          const double tc0 = now_s();
           memcpy(text, carry_.data(), carry_.size());
+          t_tr_[3] += now_s() - tc0;
         }
       } else {
         // a record longer than a chunk: assembled in a buffer of its own (pageable; rare)
@@ -289,7 +295,10 @@ public:
       }
       uint64_t n_rec = 0, used = 0;
       int stopped = 0;
-      if (run_.vt.fastq_parse(run_.ctx, text, fill, eof ? 1 : 0, &fq_, &n_rec, &used, &stopped) != GRP_OK) {
+      const double tp0 = now_s();
+      const int prc = run_.vt.fastq_parse(run_.ctx, text, fill, eof ? 1 : 0, &fq_, &n_rec, &used, &stopped);
+      t_tr_[1] += now_s() - tp0;
+      if (prc != GRP_OK) {
         std::cerr << "goldrush-path: FASTQ ingest: " << (run_.vt.last_error ? run_.vt.last_error(run_.ctx) : "failed") << std::endl;
         failed_ = true;
         done_ = true;
@@ -324,35 +333,42 @@ public:
     }
     return false;
   }
-  // The next chunk's upload, started NOW if the reader has it: the caller is about to queue this chunk's fill, and a
-  // copy issued behind that launch only begins when it has ended (round 5, tools/dev/r5_ingest_timeline.sh: fill 7 ms,
-  // then copy 9 ms, then parse 4.5 ms — one after the other); in front of it, it runs beside it.
+  // The uploads of the next TWO chunks' bodies, started as soon as the reader has them (round 5).  A copy issued behind the
+  // fill of the current chunk only begins when that has ended (tools/dev/r5_ingest_timeline.sh: fill, then copy, then parse,
+  // one after the other); issued one chunk ahead — with the tail of the chunk before copied in front first — it still lay on
+  // the path of every chunk (copy 5.5 ms + parse + the host's share against a fill of 7 ms).  The body does not depend on
+  // that tail: it goes up two chunks ahead, the engine leaves room in front of it and the parse uploads the tail alone
+  // (grpath_ingest.h: grp_fastq_prefetch).
   void prefetch_next()
   {
-    pre_text_ = nullptr;
     ++n_pre_[0];
-    if (!run_.vt.fastq_prefetch || done_ || carry_.size() > front_) {
+    if (!run_.vt.fastq_prefetch || done_) {
       return;
     }
-    size_t n = 0;
-    {
-      std::lock_guard<std::mutex> g(mu_);
-      if (slot_[take_].state != Slot::READY) {
-        ++n_pre_[1];
-        return; // the reader is still at it: the parse uploads as before
+    for (int ahead = 0; ahead < 2; ++ahead) {
+      const int j = (take_ + ahead) % kSlots;
+      size_t n = 0;
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (slot_[j].state != Slot::READY) {
+          n_pre_[1] += ahead == 0;
+          return; // the reader is still at it (and the slots behind it are not ready either)
+        }
+        if (slot_[j].eof && slot_[j].n == 0) {
+          return;
+        }
+        n = slot_[j].n; // (a READY slot is the consumer's until it releases it)
       }
-      n = slot_[take_].n; // (a READY slot is the consumer's until it releases it)
-    }
-    const size_t fill = carry_.size() + n;
-    if (fill == 0) {
-      return;
-    }
-    char* text = slot_data(take_) - carry_.size();
-    if (!carry_.empty()) {
-      memcpy(text, carry_.data(), carry_.size());
-    }
-    if (run_.vt.fastq_prefetch(run_.ctx, text, fill) == GRP_OK) {
-      pre_text_ = text;
+      if (slot_[j].uploaded || n == 0) {
+        continue;
+      }
+      const double tq0 = now_s();
+      const int qrc = run_.vt.fastq_prefetch(run_.ctx, slot_data(j), n);
+      t_tr_[2] += now_s() - tq0;
+      if (qrc != GRP_OK) {
+        return; // no free buffer on the device: later
+      }
+      slot_[j].uploaded = true;
       ++n_pre_[2];
     }
   }
@@ -387,6 +403,7 @@ private:
     size_t n = 0;          // bytes read
     uint64_t file_off = 0; // stream offset of the first of them
     bool eof = false;      // the data ends with this chunk
+    bool uploaded = false; // consumer's: the engine has been handed the body ahead of its parse (prefetch_next)
   };
   char* slot_data(int i) { return buf_.data() + (size_t)i * (front_ + chunk_) + front_; }
   void read_loop()
@@ -434,7 +451,7 @@ private:
   InputFile in_;
   std::vector<char> buf_;  // kSlots x [front | chunk]
   uint64_t n_pre_[3] = { 0, 0, 0 }; // developer trace: chunks returned, next slot not ready, prefetches the engine took
-  const char* pre_text_ = nullptr; // the text whose upload prefetch_next has started (the next call's text, carry included)
+  double t_tr_[4] = { 0, 0, 0, 0 };  // developer trace: seconds waiting for the reader / in the parse call / in the prefetch calls / copying tails
   std::vector<char> carry_; // unconsumed tail of the chunk before
   std::vector<char> big_;
   size_t chunk_ = 0, front_ = 0;
@@ -442,10 +459,9 @@ private:
   std::thread reader_;
   std::mutex mu_;
   std::condition_variable cv_;
-  // three chunk buffers (round 5; two before): the caller's batch lives in one, the next one's upload has been started
-  // ahead (prefetch_next) and the reader fills the third — with two the reader could only begin when the caller came
-  // back for the next chunk, and was not done when the upload should have started
-  static constexpr int kSlots = 3;
+  // four chunk buffers (round 5; two before): the caller's batch lives in one, the bodies of the next two have been handed to
+  // the engine ahead (prefetch_next) and the reader fills the fourth
+  static constexpr int kSlots = 4;
   Slot slot_[kSlots];
   int take_ = 0;  // the slot the next chunk arrives in
   int held_ = -1; // the slot the caller's current batch lives in

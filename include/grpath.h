@@ -61,6 +61,7 @@ typedef struct grp_reads grp_reads; /* a batch of packed reads resident in HBM *
 /* limits of this implementation (checked by grp_create) */
 #define GRP_MAX_SEEDS 8  /* -h */
 #define GRP_MAX_SPAN 64  /* k + h - 1 <= 64 bases (round 4; up to 32: one 64-bit window of 2-bit bases, beyond: two) */
+#define GRP_MAX_TILE 65535 /* -t: an ID's count per tile is 16 bits (round 5: tile x h IDs need not fit the LDS any more) */
 
 typedef struct
 {

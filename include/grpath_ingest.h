@@ -51,12 +51,15 @@ typedef struct
  */
 int grp_fastq_parse(grp_ctx* ctx, const char* text, uint64_t n_bytes, int final_chunk, grp_fastq** out, uint64_t* n_records, uint64_t* bytes_consumed, int* stopped);
 /*
- * Optional (round 5): start the upload of the NEXT chunk now — the very (text, n_bytes) the next grp_fastq_parse will be
- * given; it then finds its text on the device.  The copy of a 256 MiB chunk takes ~9 ms and, issued from inside
- * grp_fastq_parse, only began when the fill of the chunk before had ended (the timeline: tools/dev/r5_ingest_timeline.sh);
- * issued in FRONT of that fill it runs beside it.  The text must stay unchanged until that parse returns.  A prefetch
- * that is not followed by the matching parse is simply dropped.  GRP_ERR_BUSY: no device buffer is free for it right
- * now (not an error: the parse uploads as before).
+ * Optional (round 5): start the upload of a COMING chunk now.  `text` is that chunk's body: the later grp_fastq_parse is
+ * given a text that ENDS with exactly these bytes at this address — the body itself, or the body with up to 1 MiB in front
+ * of it (the unconsumed tail of the chunk before, which is only known once that chunk has been parsed); it finds the body on
+ * the device and uploads what is in front of it alone.  Up to two prefetches may be pending, parsed in the order they were
+ * issued.  Why: the copy of a 256 MiB chunk takes ~5 ms and, issued from inside grp_fastq_parse, only began when the fill
+ * of the chunk before had ended (the timeline: tools/dev/r5_ingest_timeline.sh); two chunks ahead it is off the path of
+ * every chunk.  The body must stay unchanged until its parse returns.  A prefetch that is not followed by the matching
+ * parse is simply dropped (with every prefetch behind it).  GRP_ERR_BUSY: no device buffer is free for it right now (not
+ * an error: the parse uploads as before).
  */
 int grp_fastq_prefetch(grp_ctx* ctx, const char* text, uint64_t n_bytes);
 /* copy the record table (n_records entries) to the host */

@@ -3,6 +3,8 @@ grp_engine_vt) backed by the CPU oracle, so the product's order-exact
 classifier can be exercised without a GPU (CPU tests, gloo world_size-2)."""
 import ctypes as C
 
+import zlib
+
 import numpy as np
 
 from goldrush_amd import host, native
@@ -629,10 +631,34 @@ class OracleCliEngine:
                               ("qual_len", "<u4"), ("flags", "<u4"), ("phred_sum", "<f8"), ("phred_first", "<f8")])
         parsed = {}
 
+        # grp_fastq_prefetch restated as its CONTRACT (grpath_ingest.h): up to two bodies pending, parsed in order, each parse's
+        # text ends with the body at the body's address with at most 1 MiB in front, and the body's bytes are the ones that
+        # were there when it was handed over (the host must not touch a buffer whose upload may be running)
+        pending = []
+        self.prefetch_stats = {"issued": 0, "matched": 0, "dropped": 0, "busy": 0}
+
+        def fastq_prefetch(ctx, body_p, n):
+            if len(pending) >= 2:
+                self.prefetch_stats["busy"] += 1
+                return -6  # GRP_ERR_BUSY
+            pending.append((int(body_p), int(n), zlib.crc32(C.string_at(body_p, n))))
+            self.prefetch_stats["issued"] += 1
+            return 0
+
         def fastq_parse(ctx, text_p, n, final, out_pp, nrec_p, used_p, stopped_p):
             hl = host.load()
             self.n_parse += 1
             text = C.string_at(text_p, n) if n else b""
+            if pending:
+                body, nb, crc = pending[0]
+                front = n - nb
+                if 0 <= front <= (1 << 20) and int(text_p) + front == body:
+                    assert zlib.crc32(text[front:]) == crc, "a prefetched body changed before its parse"
+                    pending.pop(0)
+                    self.prefetch_stats["matched"] += 1
+                else:
+                    self.prefetch_stats["dropped"] += len(pending)
+                    pending.clear()
             lines, pos = [], 0
             while pos < len(text):
                 nl = text.find(b"\n", pos)
@@ -704,7 +730,7 @@ class OracleCliEngine:
                 "ntcard_begin": ntcard_begin, "ntcard_add": ntcard_add, "ntcard_finish": ntcard_finish, "set_filter_size": set_filter_size}
         if self.ingest:
             impl.update({"fastq_parse": fastq_parse, "fastq_records": fastq_records, "fastq_pack": fastq_pack, "fastq_free": fastq_free,
-                         "fastq_pin": fastq_pin, "fastq_unpin": fastq_unpin})
+                         "fastq_pin": fastq_pin, "fastq_unpin": fastq_unpin, "fastq_prefetch": fastq_prefetch})
         for name, ftype in host.VT_TYPES:
             if name in impl:
                 cb = ftype(impl[name])

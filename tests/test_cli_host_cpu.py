@@ -30,6 +30,10 @@ RUNNER = textwrap.dedent("""
         assert eng.n_parse > 0, "the host did not take its chunked source"
         if os.environ.get("EXPECT_PINS"):
             assert "pin" in ops
+            # the bodies of coming chunks were handed over ahead of their parse and every one of them was parsed with its
+            # bytes unchanged (the oracle engine checks the contract of grp_fastq_prefetch: tests/oracle_engine.py)
+            ps = eng.prefetch_stats
+            assert ps["matched"] > 0 and ps["matched"] + ps["dropped"] <= ps["issued"] <= ps["matched"] + ps["dropped"] + 2, ps
         assert ops.count("pin") <= ops.count("unpin") and all(a != b for a, b in zip(ops, ops[1:]) if a == "pin"), ops
     if os.environ.get("GRP_TEST_MARK"):  # what the engine was asked to do (the ranks other than 0 must stay silent)
         open(os.environ["GRP_TEST_MARK"] + "." + os.environ.get("GRP_RANK", "0"), "w").write(str(getattr(eng, "n_bv_exports", 0)))

@@ -312,6 +312,8 @@ def test_errors_are_loud(native):
         native.Engine(22, 3, 10, 1 << 20, default_seeds(3))  # tile shorter than the seeds
     with pytest.raises(native.GrpError):
         native.Engine(63, 3, 1000, 1 << 20, ["1" * 63, "1" * 64, "1" * 65])  # span k + h - 1 > 64
+    with pytest.raises(native.GrpError):
+        native.Engine(22, 3, 70000, 1 << 20, default_seeds(3))  # more than 65 535 frames per tile (16-bit counts)
     eng = native.Engine(22, 3, 1000, 1 << 20, default_seeds(3))
     b = eng.upload([b"ACGT" * 600])
     with pytest.raises(native.GrpError):

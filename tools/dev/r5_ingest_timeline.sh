@@ -25,7 +25,7 @@ if len(fills) > 12:
     t1 = fills[11][1] + 2_000_000
     print("events between the 9th and the 12th fill (ms from the window's start; only those >= 0.05 ms or fills / big copies):")
     for s, e, n, q in ev:
-        if s >= t0 and s <= t1 and (e - s) >= 50_000:
+        if s >= t0 and s <= t1 and ((e - s) >= 20_000 or n.startswith("C ")):
             print("%8.2f .. %8.2f  %6.2f ms  stream %s  %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, q, n))
 PY
 rm -rf $out/ingest_tl /tmp/ingest.fq
