@@ -220,6 +220,7 @@ struct grp_ctx
 
   // developer switches, read once at grp_create (not on every call of a latency path)
   bool env_no_direct = false, env_stream_resume_off = false, env_no_early_park = false, env_trace_abort = false;
+  uint32_t env_small_hist = 0; // GRP_SMALL_HIST (developer hook / tests): slots of the first-step count table
   // grp_window_overlap (grp_batch.inc): samples per tile, their table, the result per read
   struct OverlapBuf
   {
@@ -613,10 +614,7 @@ query_geom(const grp_ctx* c, bool full)
   const uint64_t max_ids = (uint64_t)tile * h;
   auto lds_of = [&](uint32_t cap) { return tab_bytes(c) + (size_t)cap * 6 + bases_bytes(tile + c->params.k + h); };
   const uint32_t cap_full = (uint32_t)((max_ids + (uint64_t)THREADS * h + 2 + 1023) / 1024 * 1024);
-  static const uint32_t forced_small = [] { // developer hook / tests: slots of the first-step table (forces the two-step scheme)
-    const char* e = getenv("GRP_SMALL_HIST");
-    return e ? (uint32_t)atoi(e) / 2u * 2u : 0u;
-  }();
+  const uint32_t forced_small = c->env_small_hist; // developer hook / tests (GRP_SMALL_HIST, read when the context is created): slots of the first-step table — forces the two-step scheme
   QueryGeom g;
   g.hist_cap = cap_full;
   if (!full) {
@@ -915,6 +913,9 @@ grp_create(const grp_params* p, grp_ctx** out)
       c->batch_epochs = (uint32_t)std::min<long>(std::max<long>(atol(e), 1), (long)GRP_EPOCH_MAX);
     }
     c->env_no_early_park = getenv("GRP_NO_EARLY_PARK") != nullptr;
+    if (const char* e = getenv("GRP_SMALL_HIST")) {
+      c->env_small_hist = (uint32_t)atoi(e) / 2u * 2u;
+    }
     c->env_trace_abort = getenv("GRP_TRACE_ABORT") != nullptr;
   }
   int rc = build_seed_tables(c);

@@ -87,7 +87,7 @@ def test_hip_classifier_on_a_repeat_rich_genome(oracle, native, mode, monkeypatc
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["auto", "batch", "stream"])
+@pytest.mark.parametrize("mode", ["auto", "batch", "stream", "batch_flagged", "stream_flagged"])
 def test_hip_classifier_with_tiles_of_12000_bases(oracle, native, mode, monkeypatch):
     """-t 12000 at h = 3: 36 000 possible IDs per tile do not fit the LDS (rounds 1-4: a loud error at grp_create; the
     reference has no such limit).  The product's windows, batches and streaming launches on that geometry against the
@@ -96,7 +96,12 @@ def test_hip_classifier_with_tiles_of_12000_bases(oracle, native, mode, monkeypa
     from goldrush_amd import host, synth
     from oracle_engine import cached_serial_reference
 
-    env = {"auto": {}, "batch": {"GRP_BATCH": "force"}, "stream": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "force"}}[mode]
+    # *_flagged: a first-step table of 840 slots (71 distinct IDs): most tiles are flagged and redone with the worst-case table,
+    # which at this geometry lives in global memory — the plain form, the form through a batch's log (the redo launch that
+    # reads the list's length on the device included) and the hand-back of a streaming window
+    env = {"auto": {}, "batch": {"GRP_BATCH": "force"}, "stream": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "force"},
+           "batch_flagged": {"GRP_BATCH": "force", "GRP_SMALL_HIST": "840"},
+           "stream_flagged": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "force", "GRP_SMALL_HIST": "840"}}[mode]
     for key, val in env.items():
         monkeypatch.setenv(key, val)
     tile, k, h, block = 12000, 22, 3, 2
@@ -117,6 +122,8 @@ def test_hip_classifier_with_tiles_of_12000_bases(oracle, native, mode, monkeypa
     assert np.array_equal(ids, ref_ids) and np.array_equal(counts, ref_counts)
     st = cls.state()
     assert st["inserts"] == sum(1 for e in exp if e[1] in (2, 4)) and st["inserts"] >= 3
+    if mode.endswith("_flagged"):
+        assert eng.verify_stats()["window_flagged"] > 0
 
 
 def test_golden_fixture_through_cli(native, tmp_path):
