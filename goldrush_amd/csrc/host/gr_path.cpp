@@ -235,6 +235,9 @@ public:
       reader_.join();
     }
     release();
+    if (run_.vt.fastq_prefetch) {
+      (void)run_.vt.fastq_prefetch(run_.ctx, nullptr, 0); // bodies handed over ahead of a parse that never came (an early end)
+    }
     if (getenv("GRP_TRACE_INGEST")) {
       std::cerr << "GRP_TRACE_INGEST source: " << n_pre_[0] << " chunks, next chunk not ready at " << n_pre_[1] << ", uploads started ahead " << n_pre_[2] << "; seconds waiting for the reader " << t_tr_[0]
                 << ", in fastq_parse " << t_tr_[1] << ", in fastq_prefetch " << t_tr_[2] << ", copying tails " << t_tr_[3] << std::endl;

@@ -59,7 +59,8 @@ int grp_fastq_parse(grp_ctx* ctx, const char* text, uint64_t n_bytes, int final_
  * of the chunk before had ended (the timeline: tools/dev/r5_ingest_timeline.sh); two chunks ahead it is off the path of
  * every chunk.  The body must stay unchanged until its parse returns.  A prefetch that is not followed by the matching
  * parse is simply dropped (with every prefetch behind it).  GRP_ERR_BUSY: no device buffer is free for it right now (not
- * an error: the parse uploads as before).
+ * an error: the parse uploads as before).  (NULL, 0): every pending prefetch is forgotten and its copy waited for — call it
+ * before the buffers the bodies live in are freed.
  */
 int grp_fastq_prefetch(grp_ctx* ctx, const char* text, uint64_t n_bytes);
 /* copy the record table (n_records entries) to the host */

@@ -638,6 +638,10 @@ class OracleCliEngine:
         self.prefetch_stats = {"issued": 0, "matched": 0, "dropped": 0, "busy": 0}
 
         def fastq_prefetch(ctx, body_p, n):
+            if not body_p and n == 0:  # the caller's buffers are going away
+                self.prefetch_stats["dropped"] += len(pending)
+                pending.clear()
+                return 0
             if len(pending) >= 2:
                 self.prefetch_stats["busy"] += 1
                 return -6  # GRP_ERR_BUSY
