@@ -2163,9 +2163,9 @@ grp_classify_reads_end(grp_ctx* c, uint32_t slot, grp_read_decision* out)
   HIP_TRY(c, hipSetDevice(c->device));
   c->q = &sl;
   HIP_TRY(c, hipEventSynchronize(sl.done));
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    if (sl.h_qctr[3] > sl.list_cap) { // list arena too small: grow and redo the window
-      sl.list_cap = sl.h_qctr[3] + sl.h_qctr[3] / 4 + 4096;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    if (sl.h_qctr[3] > sl.list_cap) { // list arena too small: grow (with room for the lists of tiles that are redone) and redo the window
+      sl.list_cap = 2 * sl.h_qctr[3] + 4096;
       int rc = classify_enqueue(c, sl, false);
       if (rc != GRP_OK) {
         return rc;

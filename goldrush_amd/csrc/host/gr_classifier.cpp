@@ -36,7 +36,7 @@ Classifier::Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, v
       env_.overlap_samples = 0;
     } else if (!t.empty()) {
       env_.overlap_samples = (uint32_t)std::max(1l, atol(t.c_str()));
-      env_.overlap_fixed = true;
+      env_.overlap_fixed = t.find('+') == std::string::npos; // "4+": the base threshold, still adapting (developer: with GRP_BATCH_OVERLAP_SHIFT)
     }
     const std::string pmin = env("GRP_BATCH_OVERLAP_P");
     if (!pmin.empty()) {
@@ -1120,10 +1120,10 @@ Classifier::batch_round(uint32_t& pos)
       ovl_lo_ = at;
       ovl_hi_ = at + nb;
       ++n_overlap_calls_;
-      // How many shared samples end a window: 8 tells every true overlap of a uniform genome (an error-free kilobase
-      // is ~60 samples, unrelated reads share ~0.01) — and, on a genome with repeats, nearly every read: the windows
+      // How many shared samples end a window: 4 (of the one frame in 32 the engine samples; rounds 4 - 5: 8 of one in 16)
+      // tells every true overlap of a uniform genome (an error-free kilobase is ~30 samples, unrelated reads share ~0.005) — and, on a genome with repeats, nearly every read: the windows
       // end after ~50 reads and the batches' fixed cost (worth ~70 reads) is what the run pays (bench.py --repeat-frac
-      // 0.4: 75 k reads/s at 8, 103 k at 64; uniform genome: 127 k at 8, 123 k at 64).  So the threshold climbs the
+      // 0.4, measured with one frame in 16: 75 k reads/s at 8, 103 k at 64; uniform genome: 127 k at 8, 123 k at 64).  So the threshold climbs the
       // block-by-block efficiency — reads committed per (70 x batches + reads queried), from the classifier's own
       // counters: deterministic — while the batches are short; where they are long already (>= 128 reads at the base
       // threshold) it stays.  A hint either way: every batch is still confirmed by its second decisions.
@@ -1142,8 +1142,8 @@ Classifier::batch_round(uint32_t& pos)
               if (next < env_.overlap_samples) {
                 next = env_.overlap_samples;
                 ovl_dir_ = 1;
-              } else if (next > 256u) {
-                next = 256u;
+              } else if (next > 32u * env_.overlap_samples) {
+                next = 32u * env_.overlap_samples;
                 ovl_dir_ = -1;
               }
               ovl_thr_ = next;

@@ -99,7 +99,7 @@ private:
     std::string pipeline, stream, loop, batch; // GRP_PIPELINE / GRP_STREAM / GRP_LOOP / GRP_BATCH as found when the classifier was created
     uint64_t max_window_tiles = 0;             // GRP_MAX_WINDOW_TILES (0: unset)
     bool overlap_fixed = false;                // GRP_BATCH_OVERLAP was given: the threshold stays what it says (else it adapts, batch_round)
-    uint32_t overlap_samples = 8;              // GRP_BATCH_OVERLAP=<n> / off: windows of batches end in front of a read sharing >= n sampled k-mers with a read in front of it (0: not asked)
+    uint32_t overlap_samples = 4;              // GRP_BATCH_OVERLAP=<n> / off: windows of batches end in front of a read sharing >= n sampled k-mers with a read in front of it (0: not asked)
     double overlap_min_insert = 0.3;           // GRP_BATCH_OVERLAP_P: ... where at least this share of the reads inserts
   } env_;
   gr_commit_fn commit_cb_ = nullptr;

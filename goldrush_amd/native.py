@@ -599,7 +599,7 @@ class Engine:
         self._check(self.lib.grp_batch_verify(self._h, batch._h, first, count, extra, C.byref(dp), _ptr(fl), _ptr(out)))
         return out
 
-    def window_overlap(self, batch: ReadBatch, first: int, count: int, threshold: int = 8) -> np.ndarray:
+    def window_overlap(self, batch: ReadBatch, first: int, count: int, threshold: int = 4) -> np.ndarray:
         """grp_window_overlap: per read of [first, first + count) the closest read in front of it (index relative to
         first) that owns >= threshold of its sampled k-mers; 0xFFFFFFFF: none."""
         out = np.full(max(count, 1), 0xFFFFFFFF, dtype=np.uint32)

@@ -579,12 +579,12 @@ int grp_batch_verify(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint3
  * Where windows should END (round 4).  A batch is taken back from the first read on that decides differently
  * behind the inserts of the reads in front of it — in practice a read that OVERLAPS an inserting read of its own
  * window (14 - 19 % of the batches).  This call hashes the reads [first, first + count) under seed 0 only, keeps one
- * frame in 16 (the canonical hash: either strand), attributes every sample to the first read of the range that holds
+ * frame in 32 (the canonical hash: either strand; one in 16 until the end of round 5), attributes every sample to the first read of the range that holds
  * it, and returns for every read j (index relative to first) in prev_out[j] the CLOSEST read in front of it that owns
  * at least `threshold` of j's samples, 0xFFFFFFFF if there is none (also for ranges of more than 2^19 tiles, which are
  * not examined).  One call covers many windows: a window [s, e) of the range ends best in front of the first j in
  * (s, e) with prev_out[j] >= s.  Reads nothing of the filter, changes nothing, synchronous; a hint — exactness never
- * depends on it.  An error-free overlap of 1 kb is ~60 samples; unrelated 25 kb reads of a 3 Gbp genome share ~0.01.
+ * depends on it.  An error-free overlap of 1 kb is ~30 samples; unrelated 25 kb reads of a 3 Gbp genome share ~0.005.
  */
 int grp_window_overlap(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, uint32_t threshold, uint32_t* prev_out);
 int grp_batch_undo(grp_ctx* ctx, uint32_t from_read, uint32_t id_floor);
