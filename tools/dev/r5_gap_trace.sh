@@ -52,6 +52,22 @@ for n, v in per.most_common(24):
 print("\nidle time by (previous event -> next event):")
 for kk, v in gaps.most_common(30):
     print("  %-40s -> %-40s %7d x  %8.2f ms  avg %7.1f us" % (kk[0], kk[1], gapn[kk], v / 1e6, v / 1e3 / gapn[kk]))
+# the context of the pair that idles most (three examples)
+top = gaps.most_common(2)
+for kk, _ in top:
+    if gapn[kk] < 50:
+        continue
+    shown = 0
+    print("\nexamples of the gap %s -> %s (us from the first event shown):" % kk)
+    for i in range(lo + 8, hi - 8):
+        if ev[i][2] == kk[1] and ev[i - 1][2] == kk[0] and ev[i][0] - ev[i - 1][1] > 500_000:
+            b0 = ev[i - 7][0]
+            for s2, e2, n2 in ev[i - 7:i + 6]:
+                print("  %9.1f .. %9.1f  %8.1f us  %s" % ((s2 - b0) / 1e3, (e2 - b0) / 1e3, (e2 - s2) / 1e3, n2))
+            print("  --")
+            shown += 1
+            if shown == 3:
+                break
 # one batch in the middle, event by event
 mid = col[len(col) // 2]
 nxt = col[len(col) // 2 + 2]
@@ -61,4 +77,4 @@ for s, e, n in ev[mid - 6:nxt + 1]:
     print("  %9.1f .. %9.1f  %8.1f us  %s" % ((s - b0) / 1e3, (e - b0) / 1e3, (e - s) / 1e3, n))
 PY
 rm -rf $out/gap_tl
-head -70 $out/${tag}_gap_trace.txt
+tail -60 $out/${tag}_gap_trace.txt
