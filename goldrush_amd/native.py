@@ -357,6 +357,15 @@ class Engine:
     def fastq_unpin(self):
         self._check(self.lib.grp_fastq_unpin(self._h))
 
+    def fastq_prefetch(self, body: "np.ndarray | None", n_bytes: int = 0) -> bool:
+        """grp_fastq_prefetch: the upload of a coming chunk's body (a uint8 view the caller keeps alive and unchanged until its
+        parse); False: no device buffer free right now (GRP_ERR_BUSY).  (None, 0): every pending prefetch is forgotten."""
+        rc = self.lib.grp_fastq_prefetch(self._h, _ptr(body) if body is not None else None, n_bytes)
+        if rc == -6:
+            return False
+        self._check(rc)
+        return True
+
     def fastq_parse_at(self, buf: np.ndarray, n_bytes: int, final_chunk: bool = True):
         """fastq_parse on the first n_bytes of a caller-owned uint8 array (no copy: what a pinned chunk buffer needs)."""
         out = C.c_void_p()

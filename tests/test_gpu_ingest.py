@@ -177,3 +177,66 @@ def test_pinned_chunk_buffer_over_several_passes(native):
         del buf
     with pytest.raises(native.GrpError):
         eng.fastq_pin(np.zeros(0, dtype=np.uint8))
+
+
+@pytest.mark.parametrize("shift", [0, 1, 5, 15, 16, 23])
+def test_bodies_uploaded_ahead_of_their_parse(native, shift):
+    """grp_fastq_prefetch (round 5): the bodies of the next two chunks are handed over before the chunk in front of them is
+    parsed; a parse then gets [the unconsumed tail of the chunk before | body] and uploads the tail alone - the text begins
+    wherever that leaves it inside a 16-byte group of the device buffer (`shift` moves the cuts, so the tail's length takes
+    different values mod 16).  Same records, same bytes consumed, same packed bases as the parse of the same text from
+    scratch; a third prefetch is refused; a parse of another text drops what is pending; (None, 0) forgets."""
+    eng = native.Engine(22, 3, 1000, 1 << 20, default_seeds(3))
+    text = _mk_text(31, n=1500)
+    n = len(text)
+    cuts = [0, n // 3 + shift, 2 * n // 3 + 3 * shift, n]
+    room = 1 << 20
+    bufs = []
+    for a, b in zip(cuts, cuts[1:]):
+        buf = np.zeros(room + (b - a), dtype=np.uint8)
+        buf[room:] = np.frombuffer(text[a:b], dtype=np.uint8)
+        bufs.append(buf)
+    body = lambda k: (bufs[k][room:], bufs[k].size - room)  # noqa: E731
+
+    # from scratch, chunk by chunk (no prefetch): the expectation
+    exp, carry = [], b""
+    for k in range(3):
+        chunk = carry + bytes(bufs[k][room:])
+        fq, rec, used, stopped = eng.fastq_parse(chunk, final_chunk=k == 2)
+        sel = [j for j, r in enumerate(rec) if not (r["flags"] & 1) and r["seq_len"] >= 1000][:6]
+        batch = eng.fastq_pack(fq, sel, rec["seq_len"][sel]) if sel else None
+        hashes = [eng.tile_hashes(batch, j, 0).copy() for j in range(len(sel))]
+        exp.append((rec.copy(), used, stopped, len(carry), sel, hashes))
+        eng.fastq_free(fq)
+        carry = chunk[used:]
+    assert sum(len(e[0]) for e in exp) == 1500 and carry == b""
+    assert shift == 0 or any(e[3] % 16 for e in exp[1:])
+
+    # the host's order: chunk 0 is parsed, THEN the next two bodies go up; a third one has no buffer to go to
+    fq, rec, used, stopped = eng.fastq_parse_at(bufs[0][room:], bufs[0].size - room, final_chunk=False)
+    assert (used, stopped) == exp[0][1:3] and np.array_equal(rec, exp[0][0])
+    assert eng.fastq_prefetch(*body(1)) and eng.fastq_prefetch(*body(2))
+    assert not eng.fastq_prefetch(*body(0))
+    eng.fastq_free(fq)
+    carry = bytes(bufs[0][room:])[used:]
+    for k in (1, 2):
+        assert len(carry) == exp[k][3]
+        bufs[k][room - len(carry): room] = np.frombuffer(carry, dtype=np.uint8)
+        view = bufs[k][room - len(carry):]
+        fq, rec, used, stopped = eng.fastq_parse_at(view, view.size, final_chunk=k == 2)
+        assert (used, stopped) == exp[k][1:3] and np.array_equal(rec, exp[k][0]), k
+        sel = exp[k][4]
+        if sel:
+            batch = eng.fastq_pack(fq, sel, rec["seq_len"][sel])
+            for j in range(len(sel)):
+                assert np.array_equal(eng.tile_hashes(batch, j, 0), exp[k][5][j]), (k, j)
+        eng.fastq_free(fq)
+        carry = bytes(view[used:])
+    # a parse of another text drops what is pending (the body of chunk 1 again, then something else is parsed)
+    assert eng.fastq_prefetch(*body(1))
+    fq, rec, used, stopped = eng.fastq_parse(text[: cuts[1]], final_chunk=False)
+    assert np.array_equal(rec, exp[0][0])
+    eng.fastq_free(fq)
+    assert eng.fastq_prefetch(*body(2)) and eng.fastq_prefetch(*body(1))  # two free buffers again: nothing was pending
+    assert eng.fastq_prefetch(None, 0)  # forgotten: the buffers may go
+    eng.close()
