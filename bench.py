@@ -2,8 +2,9 @@
 """bench.py — GoldRush-Path hot path (spaced-seed ntHash + miBF query / insert) on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the
-driver launches one rank per GPU with torch.distributed.run.  Rank 0 prints ONE
-JSON line.
+driver launches one rank per GPU with torch.distributed.run — and where nothing did
+(`WORLD_SIZE` unset), `--gpus N` starts its N ranks itself (launch_ranks).  A launcher
+whose WORLD_SIZE is not N is an error.  Rank 0 prints ONE JSON line.
 
 Workload (default): BASELINE.json configs[2] "C2" — 10 M synthetic ONT-like reads,
 mean 25 kb, G = 3e9, k=22 w=16 h=3 tile=1000, o=0.1 (m = 61 146 729 472 bits), golden
@@ -294,6 +295,28 @@ def warm_up(native, host, steps: int, device: int, h: int):
     dr.free()
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes through torch.distributed.run (one per GPU,
+    rendezvous on 127.0.0.1), this process only waits — it has not imported torch or touched HIP, and never does.
+    Rank 0's JSON line goes to our stdout as it is (the children inherit it); the exit code is non-zero if any rank fails."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver: dmabuf IPC only (RCCL between processes)
+    sys.stderr.write("bench: --gpus %d without a launcher: starting %d ranks (%s)\n" % (n, n, " ".join(cmd[1:9])))
+    sys.stderr.flush()
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        sys.stderr.write("bench: the %d-rank run failed (exit code %d)\n" % (n, rc))
+    return rc if rc >= 0 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,6 +342,17 @@ def main():
     ap.add_argument("--verify-ranks", action="store_true", help="developer: N > 1, compare the classifier state of all ranks after the run")
     ap.add_argument("--share-gpu", action="store_true", help="developer: all ranks use GPU 0 (plumbing test on a 1-GPU box, use with --backend gloo)")
     a = ap.parse_args()
+
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            # no launcher around us: start the N ranks ourselves (the single command that uses the whole
+            # node, like bin/goldrush:240-246's -j$t) — before anything in this process touches HIP
+            raise SystemExit(launch_ranks(a.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: the two must agree (the line's n_gpus is the number of ranks that ran)"
+                         % (a.gpus, os.environ["WORLD_SIZE"]))
 
     cfg = dict(CONFIGS[a.config])
     if a.reads:

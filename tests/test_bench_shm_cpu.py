@@ -135,3 +135,34 @@ def test_a_peer_that_left_is_reported_at_once():
         p.join(timeout=30)
     assert res == {0: -3, 1: 0}, res
     assert time.time() - t0 < 60
+
+
+def _bench(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_bench_refuses_a_world_that_is_not_its_gpus_flag():
+    """`--gpus N` is the number of ranks: a launcher that started another number is an error, not a silent N = WORLD_SIZE
+    (or N = 1) line (VERDICT r05 missing #2).  Decided before torch is imported: runs without a GPU."""
+    r = _bench(["--gpus", "2"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr and not r.stdout.strip()
+    r = _bench(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    r = _bench(["--gpus", "0"])
+    assert r.returncode != 0
+
+
+def test_bench_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE around it starts two rank processes itself (torch.distributed.run on
+    127.0.0.1) and hands their exit code on.  Here there is no GPU: both ranks must fail loudly ("no HIP device", no CPU
+    fallback) — and the parent with them."""
+    r = _bench(["--gpus", "2", "--config", "C1", "--reads", "2000", "--steps", "2", "--warmup", "0"])
+    assert "starting 2 ranks" in r.stderr, r.stderr[-1500:]
+    import torch
+
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "no HIP device visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

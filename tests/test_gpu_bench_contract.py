@@ -41,17 +41,13 @@ def test_two_ranks_on_the_one_gpu_end_where_one_rank_ends():
     windows, the shared-memory exchange.  The run's counters (tiles, hits, misses, inserted
     bases, IDs, inserts) and the filter's population must equal the single-rank run's — not
     just agree between the ranks."""
-    import socket
-
     common = ["--config", "C1", "--steps", "4", "--reads", "120000", "--no-cpu-baseline"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--verify-ranks"] + common,
-                         capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    # round 6: no launcher around it — `bench.py --gpus 2` starts its two ranks itself (bench.py launch_ranks)
+    env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--verify-ranks"] + common,
+                         capture_output=True, text=True, timeout=900, env=env)
     assert two.returncode == 0, two.stderr[-3000:]
     a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
