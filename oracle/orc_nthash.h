@@ -13,6 +13,17 @@
  * v1.4.x..1.7.x); anchors are the reference's call sites
  * goldrush_path/multiLensfrHashIterator.hpp:39-41,54,60.
  *
+ * HOW TO PIN IT (one command, for anyone with a real btllib install):
+ *   python3 tools/make_btllib_kat.py
+ * runs btllib.SeedNtHash exactly as multiLensfrHashIterator.hpp:39-41,54,60
+ * does (one object per seed, roll() / hashes()[0]) over tests/golden/tiny.fq
+ * with the pipeline's seeds at h = 3 and h = 5 and a family spanning 60..64
+ * bases, and writes tests/golden/btllib_seed_kat.json.  With that file in
+ * place tests/test_oracle.py::test_seed_hashes_match_a_real_btllib (this
+ * restatement) and tests/test_gpu_parity.py::test_seed_hashes_match_a_real_btllib
+ * (the HIP kernels) stop skipping and check every position against btllib's
+ * values.  Until then: unpinned, as said above.
+ *
  * Definition restated (closed form; btllib evaluates the same value
  * incrementally over "care blocks" and "monomers"):
  *   seed of span K with care set C = { q : seed[q] == '1' }

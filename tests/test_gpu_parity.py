@@ -47,6 +47,53 @@ def test_nthash_known_answers_btllib(native):
     eng.close()
 
 
+def _device_streams(native):
+    """per seed of a family, every position's hash of one read as the DEVICE computes it: the family's engine (seeds share
+    a frame's halves, grp_kernels.inc seed_halves) with one tile covering the whole read; seed j is stale in the tile's
+    last j frames (multiLensfrHashIterator.hpp:54-60), which SeedNtHash itself never emits — cut off"""
+    def hashes_of(seeds, seq):
+        k, h = len(seeds[0]), len(seeds)
+        tile = len(seq) - k + 1
+        eng = native.Engine(k, h, tile, 1 << 20, seeds)
+        b = eng.upload([seq])
+        got = eng.tile_hashes(b, 0, 0).reshape(tile, h)
+        eng.close()
+        return [got[: tile - j, j] for j in range(h)]
+    return hashes_of
+
+
+def test_seed_hashes_match_a_real_btllib(native):
+    """The device's side of the pin of rows a2 / a3 (tools/make_btllib_kat.py, tests/test_oracle.py): the HIP hashing,
+    through the C ABI, against values a real btllib produced.  Skips while tests/golden/btllib_seed_kat.json is absent
+    (btllib is neither in this image nor on the GPU box)."""
+    from helpers import check_against_btllib_kat, load_btllib_kat
+
+    kat = load_btllib_kat()
+    if kat is None:
+        pytest.skip("no tests/golden/btllib_seed_kat.json: run tools/make_btllib_kat.py where btllib is installed")
+    assert check_against_btllib_kat(kat, _device_streams(native)) > 0
+
+
+def test_device_side_of_the_btllib_pin_hook(oracle, native):
+    """The same checker over a file of the SAME shape whose values are the oracle's (a stand-in: pins nothing): the three
+    families of the tool — the pipeline's seeds at h = 3 and h = 5, spans 60..64 — over the reads of tiny.fq, every
+    position, device against oracle.  Shows the device-side hook is live."""
+    import importlib.util
+    import os
+
+    from helpers import check_against_btllib_kat
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_btllib_kat", os.path.join(root, "tools", "make_btllib_kat.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kat = {"stride": mod.STRIDE, "families": {}}
+    for name, seeds in mod.FAMILIES.items():
+        kat["families"][name] = {"seeds": seeds, "reads": {rid: [mod.summarise([int(v) for v in oracle.Seeds([sd]).multi_hash(seq.encode())]) for sd in seeds]
+                                                           for rid, seq in mod.tiny_reads(6)}}
+    assert check_against_btllib_kat(kat, _device_streams(native)) == (3 + 5 + 5) * 6
+
+
 def test_fill_bits_pop_rank(oracle, native):
     eng, oseeds, omf, m = _mk(oracle, native)
     reads = random_reads(12, 1500, 9000, seed=21) + [b"ACGT" * 6, b"A" * 25, b"ACGTTGCA" * 40]

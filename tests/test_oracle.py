@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from helpers import SEED22, default_seeds, random_reads
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -150,6 +151,72 @@ def test_nthash_known_answers_btllib(oracle):
     # canonical: the reverse complement walks the same values backwards
     rc = _revcomp(BTLLIB_KAT_SEQ)
     assert [int(x) for x in oracle.Seeds(["11111"]).multi_hash(rc)][::-1] == [int(x) for x in h]
+
+
+def _oracle_streams(oracle):
+    def hashes_of(seeds, seq):
+        return [oracle.Seeds([sd]).multi_hash(seq) for sd in seeds]  # one SeedNtHash per seed, like multiLensfrHashIterator.hpp:39-41
+    return hashes_of
+
+
+def test_seed_hashes_match_a_real_btllib(oracle):
+    """THE PIN of rows a2 / a3, ready for whoever has btllib: tools/make_btllib_kat.py writes
+    tests/golden/btllib_seed_kat.json from a real install (SeedNtHash over tiny.fq with the pipeline's seeds at
+    h = 3 and h = 5 and a family spanning 60..64 bases); this test holds the oracle's restatement against it.
+    btllib is absent from this image, so the file is not committed and the test skips."""
+    from helpers import check_against_btllib_kat, load_btllib_kat
+
+    kat = load_btllib_kat()
+    if kat is None:
+        pytest.skip("no tests/golden/btllib_seed_kat.json: run tools/make_btllib_kat.py where btllib is installed")
+    assert check_against_btllib_kat(kat, _oracle_streams(oracle)) > 0
+
+
+def test_the_btllib_pin_hook_is_live(oracle, tmp_path, monkeypatch):
+    """The hook itself, exercised end to end without btllib: a stand-in module whose SeedNtHash answers with the
+    oracle's values is put in front of tools/make_btllib_kat.py; the file it writes must be accepted by the checker, and
+    a file with one value changed must be refused — so a real btllib that disagrees with the restatement WOULD fail."""
+    import importlib.util
+    import json
+    import sys
+    import types
+
+    from helpers import check_against_btllib_kat, load_btllib_kat
+
+    class FakeSeedNtHash:
+        def __init__(self, seq, seeds, per_seed, k):
+            assert per_seed == 1 and len(seeds) == 1 and len(seeds[0]) == k
+            self.vals = [int(v) for v in oracle.Seeds(seeds).multi_hash(seq.encode())]
+            self.i = -1
+
+        def roll(self):
+            self.i += 1
+            return self.i < len(self.vals)
+
+        def hashes(self):
+            return (self.vals[self.i],)
+
+    fake = types.ModuleType("btllib")
+    fake.SeedNtHash = FakeSeedNtHash
+    fake.__version__ = "stand-in (oracle values): exercises the hook, pins nothing"
+    monkeypatch.setitem(sys.modules, "btllib", fake)
+    spec = importlib.util.spec_from_file_location("make_btllib_kat", os.path.join(ROOT, "tools", "make_btllib_kat.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dst = str(tmp_path / "kat.json")
+    monkeypatch.setattr(sys, "argv", ["make_btllib_kat.py", dst])
+    mod.main()
+    kat = load_btllib_kat(dst)
+    assert set(kat["families"]) == {"pipeline_h3", "pipeline_h5", "wide_span_60_to_64"}
+    assert [len(s) for s in kat["families"]["wide_span_60_to_64"]["seeds"]] == [60, 61, 62, 63, 64]
+    assert all(s == s[::-1] and s.count("1") == 32 for s in kat["families"]["wide_span_60_to_64"]["seeds"])
+    n = check_against_btllib_kat(kat, _oracle_streams(oracle))
+    assert n == (3 + 5 + 5) * 12
+    rid = next(iter(kat["families"]["pipeline_h3"]["reads"]))
+    kat["families"]["pipeline_h3"]["reads"][rid][1]["every_97"][3] ^= 1
+    with pytest.raises(AssertionError):
+        check_against_btllib_kat(kat, _oracle_streams(oracle))
+    assert not os.path.exists(os.path.join(ROOT, "tests", "golden", "btllib_seed_kat.json")) or json.load(open(os.path.join(ROOT, "tests", "golden", "btllib_seed_kat.json")))["btllib_version"].find("stand-in") < 0
 
 
 def test_mibf_semantics(oracle):
