@@ -746,7 +746,6 @@ def main():
                     "insert_kernel_s": ks["insert"]["ms"] * 1e-3, "insert_launches": ks["insert"]["launches"],
                     "query_latency": {"launches": ks["query_latency"]["launches"], "kernel_s": ks["query_latency"]["ms"] * 1e-3, "probes": ks["query_latency"]["units"],
                                       "what": "k_query<h,F,0,false> on windows of a few reads, summaries written straight to host memory"},
-                    "commit_loop": {"launches": ks["loop"]["launches"], "kernel_s": ks["loop"]["ms"] * 1e-3, "probes": ks["loop"]["units"]},
                     "kernel_stats": ks,  # every timed kernel family: launches, units, summed HIP-event ms (grpath.h GRP_K_*)
                     "batch_verify": eng.verify_stats(),  # tiles of the batches' second decisions: patched from records / queried again / redone / calls that fell back
                     "wall_s": dt},

@@ -156,41 +156,6 @@ struct BatchRun
   uint32_t first_read = 0;        // reads are numbered from here in the log
 };
 
-// buffers of the ordered commit loop (grp_commit_loop_*)
-struct LoopRun
-{
-  bool busy = false;
-  uint32_t first = 0, count = 0;
-  hipEvent_t done = nullptr;
-  uint32_t* d_ctl = nullptr;
-  uint32_t* h_ctl_stage = nullptr; // pinned: [0..) initial control block, [LC_WORDS..) the final one
-  uint32_t* h_ctl = nullptr;       // mapped, coherent: committed count / status / stop request
-  uint32_t* dmap_ctl = nullptr;
-  uint32_t* d_tiles_done = nullptr;
-  uint64_t tiles_done_cap = 0;
-  uint32_t* d_ready = nullptr;
-  uint64_t ready_cap = 0;
-  grp_read_decision* d_rec = nullptr;
-  uint64_t rec_cap = 0;
-  grp_read_decision* h_rec = nullptr; // mapped, coherent
-  grp_read_decision* dmap_rec = nullptr;
-  uint64_t h_rec_cap = 0;
-  grp_tile_summary* d_tiles = nullptr;
-  uint64_t tiles_cap = 0;
-  grp_id_count* d_lists = nullptr;
-  uint64_t lists_cap = 0;
-  unsigned long long* d_unit_buf = nullptr;
-  uint64_t unit_buf_cap = 0;
-  uint32_t* d_tile_parts = nullptr;
-  uint64_t tile_parts_cap = 0;
-  unsigned long long* d_trace = nullptr;
-  uint64_t trace_cap = 0;
-  unsigned long long* d_tile_trace = nullptr;
-  uint64_t tile_trace_cap = 0;
-  uint64_t t0 = 0, nt = 0;
-  const grp_reads* reads_for_trace = nullptr;
-};
-
 constexpr int FQ_TEXT_SLOTS = 3; // device text buffers of the FASTQ ingest (grp_ingest.inc)
 
 struct grp_ctx
@@ -198,7 +163,6 @@ struct grp_ctx
   int device = 0;
   std::string arch;
   bool coherent_arch = false; // gfx942 / gfx950: agent-scope accesses are served by the memory side
-  LoopRun loop;
   BatchRun batch;
   hipStream_t stream = nullptr;
   // decision kernel + copy-back of a pipelined window run here, next to the following
@@ -333,7 +297,7 @@ struct grp_ctx
   } ingest;
   const char* reg_text = nullptr; // the caller's text buffer, page-locked by grp_fastq_pin
   size_t reg_bytes = 0;
-  uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_LOOP) | (1u << GRP_K_QUERY_LAT) | (1u << GRP_K_VERIFY) | (1u << GRP_K_BATCH);
+  uint32_t timing_mask = (1u << GRP_K_FILL) | (1u << GRP_K_RANK) | (1u << GRP_K_QUERY) | (1u << GRP_K_DECIDE) | (1u << GRP_K_QUERY_LAT) | (1u << GRP_K_VERIFY) | (1u << GRP_K_BATCH);
   // timing
   bool timing = true;
   std::vector<EventPair> pending;
@@ -425,9 +389,6 @@ const uint64_t BASE_SEED[4] = { 0x3c8bfbb395c60474ULL, 0x3193c18562a02b4cULL, 0x
 } // namespace
 
 #include "grp_kernels.inc"
-#ifdef GRP_DEV_HOOKS // the frozen commit loop is a developer build: make DEV=1
-#include "grp_loop.inc"
-#endif
 
 // ---------------------------------------------------------------------------
 // host side
@@ -1076,31 +1037,6 @@ grp_destroy(grp_ctx* c)
     if (sl.h_ack) {
       (void)hipHostFree(sl.h_ack);
     }
-  }
-  {
-    LoopRun& lp = c->loop;
-    (void)hipFree(lp.d_ctl);
-    if (lp.h_ctl_stage) {
-      (void)hipHostFree(lp.h_ctl_stage);
-    }
-    if (lp.h_ctl) {
-      (void)hipHostFree(lp.h_ctl);
-    }
-    if (lp.h_rec) {
-      (void)hipHostFree(lp.h_rec);
-    }
-    if (lp.done) {
-      (void)hipEventDestroy(lp.done);
-    }
-    (void)hipFree(lp.d_tiles_done);
-    (void)hipFree(lp.d_ready);
-    (void)hipFree(lp.d_rec);
-    (void)hipFree(lp.d_tiles);
-    (void)hipFree(lp.d_lists);
-    (void)hipFree(lp.d_trace);
-    (void)hipFree(lp.d_tile_trace);
-    (void)hipFree(lp.d_unit_buf);
-    (void)hipFree(lp.d_tile_parts);
   }
   {
     BatchRun& b = c->batch;
@@ -3173,36 +3109,6 @@ grp_stream(grp_ctx* c)
 
 } // extern "C"
 
-#ifdef GRP_DEV_HOOKS
-#include "grp_loop_host.inc"
-#else
-// The ordered commit loop on the device (grp_commit_loop_*) is frozen: measured slower than the batches
-// of grp_batch_* on every configuration, it is only compiled into developer builds (make DEV=1 -> -DGRP_DEV_HOOKS).
-// The entry points stay (include/grpath.h) and say so; grp_dev_hooks() tells a host which build it has.
-extern "C" {
-int
-grp_commit_loop_begin(grp_ctx* c, const grp_reads*, uint32_t, uint32_t, const grp_loop_params*, const grp_read_decision**, const volatile uint32_t**)
-{
-  return set_err(c, GRP_ERR_STATE, "grp_commit_loop_begin: this library was built without GRP_DEV_HOOKS (make DEV=1)");
-}
-int
-grp_commit_loop_stop(grp_ctx* c)
-{
-  return set_err(c, GRP_ERR_STATE, "grp_commit_loop_stop: this library was built without GRP_DEV_HOOKS (make DEV=1)");
-}
-int
-grp_commit_loop_poll(grp_ctx* c)
-{
-  return set_err(c, GRP_ERR_STATE, "grp_commit_loop_poll: this library was built without GRP_DEV_HOOKS (make DEV=1)");
-}
-int
-grp_commit_loop_end(grp_ctx* c, grp_loop_result*)
-{
-  return set_err(c, GRP_ERR_STATE, "grp_commit_loop_end: this library was built without GRP_DEV_HOOKS (make DEV=1)");
-}
-}
-#endif
-
 extern "C" int
 grp_dev_hooks(void)
 {
@@ -3217,4 +3123,6 @@ grp_dev_hooks(void)
 #include "grp_ingest.inc"
 #include "grp_ntcard.inc"
 #include "grp_comm.inc"
+#ifdef GRP_DEV_HOOKS // priced-and-rejected prototypes, measurement only (make DEV=1; include/grpath_dev.h)
 #include "grp_pshard.inc"
+#endif

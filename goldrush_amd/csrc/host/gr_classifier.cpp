@@ -24,7 +24,6 @@ Classifier::Classifier(const gr_classifier_params& p, const grp_engine_vt& vt, v
   auto env = [](const char* name) { const char* e = getenv(name); return std::string(e ? e : ""); };
   env_.pipeline = env("GRP_PIPELINE");
   env_.stream = env("GRP_STREAM");
-  env_.loop = env("GRP_LOOP");
   env_.batch = env("GRP_BATCH");
   {
     const std::string t = env("GRP_MAX_WINDOW_TILES");
@@ -703,10 +702,10 @@ Classifier::commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_
   // rolls over behind it, :156-187 — the ID array is reset there, a parked window has nothing to carry on with)
   auto insert_read = [&](uint32_t ts, uint32_t te_excl, uint32_t id_offset, uint64_t bases) {
     if (engine_inserted) {
-      // the commit loop on the device allocated the same ID from the same counter
+      // the batch applied the insert ahead of this commit, with the ID this counter allocates now
       if (engine_first_id != ids_inserted_) {
         rc = GRP_ERR_STATE;
-        err_ = "commit loop: the device allocated block ID " + std::to_string(engine_first_id) + ", the host " + std::to_string(ids_inserted_);
+        err_ = "batch: the engine inserted block ID " + std::to_string(engine_first_id) + ", the host allocates " + std::to_string(ids_inserted_);
       }
       return;
     }
@@ -945,41 +944,6 @@ Classifier::stream_decision(uint32_t j, gr_read_decision& d)
   const uint32_t g = j - group_base_;
   d = stripe_recv_[(size_t)(g / C) * CB + 1 + g % C];
   return GRP_OK;
-}
-
-bool
-Classifier::can_loop() const
-{
-  // opt-in (GRP_LOOP=on / force): over a whole C2 stream the loop did not beat the host-driven
-  // windows (head 27.2 s against 25.0 s, profiles/README.md), see want_loop
-  const bool built = p_.hash_num == 1 || p_.hash_num == 3 || p_.hash_num == 5; // the frozen path is compiled for these seed counts (round 3)
-  return vt_.loop_begin && vt_.loop_stop && vt_.loop_poll && vt_.loop_end && !loop_disabled_ && built && (env_.loop == "on" || env_.loop == "force");
-}
-
-// Measured on MI355X (tools/loop_matrix.sh, profiles/r02_loop_matrix.txt): the device-side
-// commit loop costs ~75-80 us per inserting read (a chain of ~60 dependent memory-side steps
-// of 0.3-2 us each), the host-driven latency windows ~83 us per insert but they query
-// several reads per round, so the loop only wins where nearly every read inserts (the
-// start of a path on a genome-scale filter).  Enter above 80 % inserting reads, leave
-// below 60 %.
-bool
-Classifier::want_loop() const
-{
-  if (!can_loop() || p_.debug) {
-    return false;
-  }
-  if (env_.loop == "force") {
-    return true;
-  }
-  static const double p_in = [] {
-    const char* v = getenv("GRP_LOOP_ENTER");
-    return v ? atof(v) : 0.8;
-  }();
-  static const double p_out = [] {
-    const char* v = getenv("GRP_LOOP_LEAVE");
-    return v ? atof(v) : 0.6;
-  }();
-  return p_insert_mid_ >= (in_loop_ ? p_out : p_in);
 }
 
 // ---- windows committed as batches ------------------------------------------------------
@@ -1445,135 +1409,6 @@ Classifier::batch_round(uint32_t& pos)
   return rc;
 }
 
-// ---- commit loop on the device: the host only replays the records ---------------------
-int
-Classifier::loop_round(uint32_t& pos)
-{
-  const uint32_t n = rg_.n;
-  static const uint32_t max_range = [] { // reads per launch (developer hook)
-    const char* e = getenv("GRP_LOOP_RANGE");
-    return e ? (uint32_t)atol(e) : 65536u;
-  }();
-  const uint32_t S = std::min<uint32_t>(n - pos, std::max<uint32_t>(max_range, 1u));
-  grp_loop_params lp{};
-  lp.struct_size = sizeof(lp);
-  lp.decide = grp_decide_params{ p_.threshold, p_.unassigned_min, p_.assigned_max, 0 };
-  lp.block_tiles = p_.block_size;
-  lp.silver_path = p_.silver_path ? 1u : 0u;
-  lp.ids_inserted = ids_inserted_;
-  lp.max_depth = 0;
-  // one workgroup per tile (the form that cuts tiles into units was not faster, measured)
-  lp.whole_tiles = 1u;
-  lp.target_bases = p_.target_bases;
-  lp.inserted_bases = inserted_bases_;
-  const gr_read_decision* rec = nullptr;
-  const volatile uint32_t* com = nullptr;
-  int rc = vt_.loop_begin(ctx_, rg_.reads, base_ + pos, S, &lp, &rec, &com);
-  if (rc != GRP_OK) {
-    err_ = std::string("loop_begin: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
-    return rc;
-  }
-  ++n_windows_;
-  ++n_loops_;
-  in_loop_ = true;
-  const bool forced = env_.loop == "force";
-  uint32_t consumed = 0, spins = 0;
-  bool stop_sent = false, ended = false, rolled = false;
-  while (rc == GRP_OK) {
-    const uint32_t status = __atomic_load_n(const_cast<const uint32_t*>(com) + 1, __ATOMIC_ACQUIRE);
-    const uint32_t c = __atomic_load_n(const_cast<const uint32_t*>(com), __ATOMIC_ACQUIRE);
-    while (consumed < c && rc == GRP_OK && !finished_) {
-      gr_read_decision d = rec[consumed];
-      const uint32_t first_id = d.pad;
-      d.pad = 0;
-      const uint64_t path_before = curr_path_;
-      commit_one(pos + consumed, d, rc, true, first_id);
-      ++consumed;
-      rolled = rolled || curr_path_ != path_before;
-      if (!stop_sent && !forced && !rolled && !want_loop()) {
-        (void)vt_.loop_stop(ctx_); // the insert-heavy stretch is over: the windows are faster from here
-        stop_sent = true;
-      }
-    }
-    if (rc != GRP_OK || finished_ || rolled) {
-      break; // a rollover ends the launch on the device as well (status ROLLOVER)
-    }
-    if (status != 0 && consumed == c) {
-      // the count is written before the status: nothing more will come
-      if (__atomic_load_n(const_cast<const uint32_t*>(com), __ATOMIC_ACQUIRE) == consumed) {
-        break;
-      }
-      continue;
-    }
-    if (consumed == c) {
-      __builtin_ia32_pause();
-      if ((++spins & 0xFFFFu) == 0) {
-        const int st = vt_.loop_poll(ctx_);
-        if (st < 0) {
-          rc = st;
-          err_ = std::string("loop_poll: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
-        } else if (st == 1) {
-          if (ended) { // the launch is over and a full round of spinning brought nothing new
-            break;
-          }
-          ended = true;
-        }
-      }
-    }
-  }
-  grp_loop_result res{};
-  const int erc = vt_.loop_end(ctx_, &res);
-  if (rc == GRP_OK && erc != GRP_OK) {
-    rc = erc;
-    err_ = std::string("loop_end: ") + (vt_.last_error ? vt_.last_error(ctx_) : "failed");
-  }
-  n_loop_reads_ += consumed;
-  if (avg_probes_per_read_ > 0) {
-    n_queried_ += (uint64_t)((double)res.probes / avg_probes_per_read_ + 0.5);
-  }
-  if (rc == GRP_OK && !finished_ && !rolled) {
-    // records that arrived between the last look and the end of the launch
-    while (consumed < res.reads_committed && rc == GRP_OK && !finished_ && !rolled) {
-      gr_read_decision d = rec[consumed];
-      const uint32_t first_id = d.pad;
-      d.pad = 0;
-      const uint64_t path_before = curr_path_;
-      commit_one(pos + consumed, d, rc, true, first_id);
-      ++consumed;
-      rolled = curr_path_ != path_before;
-    }
-  }
-  if (rc == GRP_OK && consumed != res.reads_committed) {
-    rc = GRP_ERR_STATE;
-    err_ = "commit loop: the device committed " + std::to_string(res.reads_committed) + " reads, the host replayed " + std::to_string(consumed);
-  }
-  if (rc == GRP_OK && !rolled && !finished_ && res.status != GRP_LOOP_TIMEOUT && (res.ids_inserted != ids_inserted_ || res.inserted_bases != inserted_bases_)) {
-    rc = GRP_ERR_STATE;
-    err_ = "commit loop: device and host disagree on the ID / base counters";
-  }
-  if (rc == GRP_OK && (rolled || finished_) && res.status != GRP_LOOP_ROLLOVER) {
-    rc = GRP_ERR_STATE;
-    err_ = "commit loop: the host rolled the silver path over, the device did not";
-  }
-  pos += consumed;
-  if (rc != GRP_OK) {
-    return rc;
-  }
-  if (res.status == GRP_LOOP_TIMEOUT) {
-    loop_disabled_ = true; // the device is shared with another persistent launch: windows from here on
-    in_loop_ = false;
-  } else if (res.status == GRP_LOOP_HANDBACK && !finished_ && pos < n) {
-    // one read through the synchronous path (more tiles than the device decision holds, or
-    // the list arena was too small)
-    rc = query_window(rg_.reads, rg_.lens, pos, 1);
-    if (rc == GRP_OK) {
-      commit_one(pos, dec_all_[0], rc);
-      ++pos;
-    }
-  }
-  return rc;
-}
-
 // ---- streaming window: consume the decisions while the launch is running ----------
 int
 Classifier::stream_round(uint32_t& pos)
@@ -1858,13 +1693,6 @@ Classifier::run(void* reads, const uint32_t* lens, uint32_t first, uint32_t n, c
   uint32_t pos = 0;
   int rc = GRP_OK;
   while (rc == GRP_OK && pos < n && !finished_) {
-    if (!next_.active && !snext_.active && want_loop()) {
-      const auto t0 = std::chrono::steady_clock::now();
-      rc = loop_round(pos);
-      t_windows_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      continue;
-    }
-    in_loop_ = false;
     if (!next_.active && !snext_.active && want_batch()) {
       const auto t0 = std::chrono::steady_clock::now();
       rc = batch_round(pos);

@@ -40,7 +40,7 @@ public:
 
 private:
   int query_window(void* reads, const uint32_t* lens, uint32_t first, uint32_t count);
-  // engine_inserted: the engine has applied the read's ID blocks already (commit loop on the device)
+  // engine_inserted: the engine has applied the read's ID blocks already (a window committed as a batch: grp_batch_insert_reads)
   bool commit(void* reads, const uint32_t* lens, uint32_t r, const gr_read_decision& d, int& rc, bool engine_inserted = false, uint32_t engine_first_id = 0);
   void silver_path_check(int& rc);
   void skip_reads(uint32_t n);
@@ -78,9 +78,6 @@ private:
   bool can_stream() const;
   bool can_resume() const;
   bool commit_one(uint32_t r, const gr_read_decision& d, int& rc, bool engine_inserted = false, uint32_t engine_first_id = 0);
-  bool can_loop() const;
-  bool want_loop() const; // the insert rate calls for the device-side commit loop
-  int loop_round(uint32_t& pos);
   bool can_batch() const;
   bool want_batch() const; // the insert rate calls for windows committed as batches
   int batch_round(uint32_t& pos);
@@ -96,7 +93,7 @@ private:
   void* ctx_;
   struct
   {
-    std::string pipeline, stream, loop, batch; // GRP_PIPELINE / GRP_STREAM / GRP_LOOP / GRP_BATCH as found when the classifier was created
+    std::string pipeline, stream, batch; // GRP_PIPELINE / GRP_STREAM / GRP_BATCH as found when the classifier was created
     uint64_t max_window_tiles = 0;             // GRP_MAX_WINDOW_TILES (0: unset)
     bool overlap_fixed = false;                // GRP_BATCH_OVERLAP was given: the threshold stays what it says (else it adapts, batch_round)
     uint32_t overlap_samples = 4;              // GRP_BATCH_OVERLAP=<n> / off: windows of batches end in front of a read sharing >= n sampled k-mers with a read in front of it (0: not asked)
@@ -127,10 +124,7 @@ private:
   // speculation control / statistics
   double p_insert_ = 1.0;        // EMA over ~32 reads
   double p_insert_slow_ = 0.0;   // EMA over ~8192 reads
-  double p_insert_mid_ = 1.0;    // EMA over ~256 reads: chooses between the device-side commit loop and the windows
-  bool in_loop_ = false;         // the last round ran as a commit loop (hysteresis of the choice)
-  bool loop_disabled_ = false;   // a loop launch could not become resident (shared device): windows only
-  uint64_t n_loops_ = 0, n_loop_reads_ = 0;
+  double p_insert_mid_ = 1.0;    // EMA over ~256 reads: chooses between the batches and the windows
   bool last_insert_shares_id_ = false; // the last insert was a trimmed read whose last ID block carries the next insert's first ID
   bool in_batch_ = false;        // the last round was a batch (hysteresis)
   bool batch_bypass_ = false;    // the read in front cannot be part of a batch: one classic round

@@ -64,10 +64,6 @@ VT_TYPES = [
     ("stream_abort", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("stream_poll", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("stream_end", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, _vp)),
-    ("loop_begin", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp)),
-    ("loop_stop", C.CFUNCTYPE(C.c_int, _vp)),
-    ("loop_poll", C.CFUNCTYPE(C.c_int, _vp)),
-    ("loop_end", C.CFUNCTYPE(C.c_int, _vp, _vp)),
     ("batch_insert", C.CFUNCTYPE(C.c_int, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32)),
     ("batch_classify", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp)),
     ("batch_undo", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32, C.c_uint32)),
@@ -258,12 +254,8 @@ def hip_engine_vt() -> grp_engine_vt:
     vt = grp_engine_vt()
     alias = {"classify_begin": "classify_reads_begin", "classify_end": "classify_reads_end", "stream_begin": "classify_stream_begin_striped",
              "stream_abort": "classify_stream_abort", "stream_insert": "classify_stream_insert", "stream_begin_resumable": "classify_stream_begin_resumable", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end",
-             "loop_begin": "commit_loop_begin", "loop_stop": "commit_loop_stop", "loop_poll": "commit_loop_poll", "loop_end": "commit_loop_end",
              "batch_insert": "batch_insert_reads", "stream_begin_striped_resumable": "classify_stream_begin_striped_resumable", "stream_resumable": "classify_stream_resumable", "stream_insert_done": "classify_stream_insert_done"}
-    dev = bool(lib.grp_dev_hooks())
     for name, ftype in VT_TYPES:
-        if name.startswith("loop_") and not dev:
-            continue  # the frozen commit loop is only in developer builds (make DEV=1): a product build's classifier is not offered it
         sym = getattr(lib, "grp_" + alias.get(name, name))
         setattr(vt, name, C.cast(sym, ftype))
     return vt

@@ -21,9 +21,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libgrpath_hip.so")
 
 GRP_OK = 0
 GRP_ERR_INVALID, GRP_ERR_NO_DEVICE, GRP_ERR_HIP, GRP_ERR_STATE, GRP_ERR_NOMEM, GRP_ERR_BUSY = -1, -2, -3, -4, -5, -6
-GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_LOOP, GRP_K_QUERY_LAT, GRP_K_VERIFY, GRP_K_BATCH, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard", "loop", "query_latency", "verify", "batch_insert")
-GRP_LOOP_RUNNING, GRP_LOOP_DONE, GRP_LOOP_ROLLOVER, GRP_LOOP_HANDBACK, GRP_LOOP_STOPPED, GRP_LOOP_TIMEOUT = 0, 1, 2, 3, 4, 5
+GRP_K_FILL, GRP_K_RANK, GRP_K_QUERY, GRP_K_INSERT, GRP_K_DECIDE, GRP_K_NTCARD, GRP_K_QUERY_LAT, GRP_K_VERIFY, GRP_K_BATCH, GRP_K_COUNT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+KERNEL_NAMES = ("fill", "rank", "query", "insert", "decide", "ntcard", "query_latency", "verify", "batch_insert")
 
 
 class GrpError(RuntimeError):
@@ -55,16 +54,6 @@ class grp_decide_params(C.Structure):
 
 decision_dtype = np.dtype([("kind", "<u4"), ("num_tiles", "<u4"), ("num_assigned", "<u4"), ("trim_start", "<u4"), ("trim_end", "<u4"),
                            ("hits", "<u4"), ("misses", "<u4"), ("pad", "<u4")])
-
-
-class grp_loop_params(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32), ("decide", grp_decide_params), ("block_tiles", C.c_uint32), ("silver_path", C.c_uint32), ("ids_inserted", C.c_uint32),
-                ("max_depth", C.c_uint32), ("whole_tiles", C.c_uint32), ("target_bases", C.c_uint64), ("inserted_bases", C.c_uint64)]
-
-
-class grp_loop_result(C.Structure):
-    _fields_ = [("status", C.c_uint32), ("reads_committed", C.c_uint32), ("inserts", C.c_uint32), ("ids_inserted", C.c_uint32), ("inserted_bases", C.c_uint64),
-                ("tiles_queried", C.c_uint64), ("probes", C.c_uint64)]
 
 
 class grp_query_stats(C.Structure):
@@ -113,16 +102,10 @@ SIGNATURES = {
     "grp_debug_decide": (C.c_int, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint64, C.POINTER(grp_decide_params), _vp, _vp, _vp]),
     "grp_classify_stream_begin_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.POINTER(C.c_void_p)]),
     "grp_classify_stream_insert": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
-    "grp_debug_touch_filter": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "grp_pshard_query": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
     "grp_comm_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_uint32)]),
     "grp_classify_stream_begin_striped_resumable": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]),
     "grp_classify_stream_resumable": (C.c_int, [_vp, C.c_uint32]),
     "grp_classify_stream_insert_done": (C.c_int, [_vp, C.c_uint32]),
-    "grp_commit_loop_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_loop_params), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
-    "grp_commit_loop_stop": (C.c_int, [_vp]),
-    "grp_commit_loop_poll": (C.c_int, [_vp]),
-    "grp_commit_loop_end": (C.c_int, [_vp, C.POINTER(grp_loop_result)]),
     "grp_batch_insert_reads": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "grp_batch_classify": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp, _vp]),
     "grp_batch_verify": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp, _vp]),
@@ -192,6 +175,13 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+# developer builds only (make -C goldrush_amd/csrc DEV=1, include/grpath_dev.h): measurement prototypes, not exported by the product library
+DEV_SIGNATURES = {
+    "grp_debug_touch_filter": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "grp_pshard_query": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
+}
+
+
 def load():
     """dlopen libgrpath_hip.so and type every exported symbol."""
     global _lib
@@ -211,6 +201,11 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.grp_dev_hooks():
+        for name, (res, args) in DEV_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 
@@ -461,7 +456,9 @@ class Engine:
 
     def pshard_query(self, batch: ReadBatch, first: int, count: int, n_owners: int = 8):
         """Measurement: query_tiles' result through the position-sharded form with `n_owners` virtual owners on this one
-        device (grp_pshard_query).  Returns (tiles, lists, {"partition_ms", "gather_ms", "vote_ms"})."""
+        device (grp_pshard_query, developer builds only).  Returns (tiles, lists, {"partition_ms", "gather_ms", "vote_ms"})."""
+        if not self.lib.grp_dev_hooks():
+            raise GrpError(GRP_ERR_STATE, "pshard_query: libgrpath_hip.so is the product build; the prototype needs make -C goldrush_amd/csrc DEV=1")
         nt = int(batch.tile0[first + count] - batch.tile0[first])
         tiles = np.zeros(nt, dtype=tile_summary_dtype)
         cap = max(8 * nt, 1024)
@@ -570,21 +567,6 @@ class Engine:
         if rc < 0:
             self._check(rc)
         return rc
-
-    def commit_loop(self, batch: ReadBatch, first: int, count: int, block: int = 10, threshold=10, unassigned_min=5, assigned_max=1, silver=False,
-                    target_bases: int = 0, ids_inserted: int = 0, inserted_bases: int = 0, max_depth: int = 0, whole_tiles: bool = False):
-        """Run the ordered commit loop over reads [first, first+count) to its end.
-        Returns (records[decision_dtype] of the committed reads, result dict)."""
-        p = grp_loop_params(C.sizeof(grp_loop_params), grp_decide_params(threshold, unassigned_min, assigned_max, 0), block, 1 if silver else 0, ids_inserted, max_depth,
-                            1 if whole_tiles else 0, target_bases, inserted_bases)
-        rec_p, com_p = C.c_void_p(), C.c_void_p()
-        self._check(self.lib.grp_commit_loop_begin(self._h, batch._h, first, count, C.byref(p), C.byref(rec_p), C.byref(com_p)))
-        res = grp_loop_result()
-        self._check(self.lib.grp_commit_loop_end(self._h, C.byref(res)))
-        n = res.reads_committed
-        buf = (C.c_uint8 * (max(n, 1) * decision_dtype.itemsize)).from_address(rec_p.value)
-        rec = np.frombuffer(buf, dtype=decision_dtype)[:n].copy()
-        return rec, {k: getattr(res, k) for k, _ in grp_loop_result._fields_}
 
     def batch_insert_reads(self, batch: ReadBatch, inserts, block: int, first_read: int):
         """inserts: list of (read, tile_start, tile_end, first_id, id_offset), ascending reads"""

@@ -398,76 +398,6 @@ int grp_classify_stream_abort(grp_ctx* ctx, uint32_t slot);
 int grp_classify_stream_poll(grp_ctx* ctx, uint32_t slot);
 int grp_classify_stream_end(grp_ctx* ctx, uint32_t slot, uint32_t* reads_decided);
 
-/* ---- phase 2: the ordered commit loop on the device ------------------------------ */
-/*
- * Replaces, for reads [first, first+count) of the batch, the reference's serial loop
- *     for (record : reader) process_read(record)         (goldrush_path.cpp:1229-1256)
- * up to a silver-path rollover: per read the hashing producer + loop 1 of
- * calc_num_assigned_tiles (:544-626), the threshold / smoothing passes / decision
- * (:628-1040), the ID allocation (:982-986, :1040-1047) and the inserts
- * (insertMIBF, :988-990, :1048-1049 -> MIBFConstructSupport.hpp:247-283) — in file order,
- * read N queried after the inserts of every accepted read < N, without a host round trip
- * per read.  ONE persistent launch: workgroups draw the tiles of the next reads (a few reads
- * ahead of the commit cursor, speculatively); the workgroup that completes a read decides it;
- * decisions are committed strictly in order; a committed insert stops the speculation, all
- * workgroups apply the read's ID blocks (exactly grp_insert_read's result) and the query
- * resumes behind it.  The host only replays the 32-byte records (output files, counters).
- *
- *   _begin  enqueues the launch and returns at once.  (*records)[j] is final for every
- *           j < **committed (the host spins on *committed; records of inserting reads
- *           carry the first block ID in .pad).  The arrays stay valid until the next _begin.
- *   _stop   asks the loop to end at the next commit (status GRP_LOOP_STOPPED).
- *   _poll   1 when the launch has finished, 0 while it runs.
- *   _end    waits for the launch and reports how it ended.
- * The launch ends by itself (status) when every read is committed (DONE), right after an
- * insert that makes the silver path roll over (ROLLOVER: target_bases < inserted_bases,
- * goldrush_path.cpp:156-187 — the caller resets the IDs and starts the next range), or in
- * front of a read it cannot take (HANDBACK: more tiles than the device decision holds, or
- * a list arena overflow; the caller takes read `reads_committed` through
- * grp_classify_reads / grp_insert_read and continues behind it).
- * Stream-ordered like every other call.  One loop per context at a time; no other call
- * that queries or inserts may be issued between _begin and _end.
- */
-typedef struct
-{
-  uint32_t struct_size;     /* = sizeof(grp_loop_params) */
-  grp_decide_params decide; /* -x -u -a */
-  uint32_t block_tiles;     /* -b */
-  uint32_t silver_path;     /* --silver_path: stop after the insert that passes target_bases */
-  uint32_t ids_inserted;    /* state in front of the first read (goldrush_path.cpp:1226) */
-  uint32_t max_depth;       /* reads the query may run ahead of the commit cursor; 0 = default */
-  uint32_t whole_tiles;     /* 0: a tile is queried by several workgroups (lowest latency per read: insert-heavy
-                               stretches); 1: one workgroup per tile (highest rate when inserts are rare) */
-  uint64_t target_bases;    /* uint64(r * G) (:1223) */
-  uint64_t inserted_bases;  /* state in front of the first read (:1222) */
-} grp_loop_params;
-
-enum
-{
-  GRP_LOOP_RUNNING = 0,
-  GRP_LOOP_DONE = 1,
-  GRP_LOOP_ROLLOVER = 2,
-  GRP_LOOP_HANDBACK = 3,
-  GRP_LOOP_STOPPED = 4,
-  GRP_LOOP_TIMEOUT = 5 /* a grid-wide wait did not complete (device shared with another persistent launch): nothing after reads_committed was applied */
-};
-
-typedef struct
-{
-  uint32_t status;          /* GRP_LOOP_* */
-  uint32_t reads_committed;
-  uint32_t inserts;         /* reads whose ID blocks were inserted */
-  uint32_t ids_inserted;    /* state behind the last committed read */
-  uint64_t inserted_bases;
-  uint64_t tiles_queried;   /* tiles processed, speculative work included */
-  uint64_t probes;          /* frames x seeds of those tiles */
-} grp_loop_result;
-
-int grp_commit_loop_begin(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, const grp_loop_params* params, const grp_read_decision** records, const volatile uint32_t** committed);
-int grp_commit_loop_stop(grp_ctx* ctx);
-int grp_commit_loop_poll(grp_ctx* ctx);
-int grp_commit_loop_end(grp_ctx* ctx, grp_loop_result* result);
-
 /* ---- phase 2: ID insert ---------------------------------------------------- */
 /*
  * Replaces: miBFCS.insertMIBF(*miBF, hashed_values, tile_start, tile_end, id)
@@ -655,9 +585,8 @@ int grp_debug_decide(grp_ctx* ctx, uint32_t n_reads, const uint64_t* tile0, cons
  * (ranks beyond their bucket's 8th set bit, csrc/grp_device.h) */
 int grp_debug_verify_stats(const grp_ctx* ctx, uint64_t out[12]);
 
-/* 1: the library was built with GRP_DEV_HOOKS (make DEV=1): the frozen commit loop (grp_commit_loop_*) and the
- * developer kernels / switches (GRP_BATCH_COLLECT3 ...) are compiled in; 0: the product build — grp_commit_loop_*
- * return GRP_ERR_STATE and a host must not offer them to its classifier */
+/* 1: the library was built with GRP_DEV_HOOKS (make DEV=1): the measurement-only prototypes of include/grpath_dev.h are
+ * compiled in; 0: the product build (they are not exported) */
 int grp_dev_hooks(void);
 
 /* ---- measurement ------------------------------------------------------------ */
@@ -669,13 +598,12 @@ enum
   GRP_K_INSERT = 3,   /* ID insert kernel */
   GRP_K_DECIDE = 4,   /* read decision kernel */
   GRP_K_NTCARD = 5,   /* --ntcard sampling kernel (units = hashes) */
-  GRP_K_LOOP = 6,     /* ordered commit loop (query + decision + insert; units = probes queried) */
-  GRP_K_QUERY_LAT = 7, /* the query kernel in its latency form: windows of a few reads written straight to
+  GRP_K_QUERY_LAT = 6, /* the query kernel in its latency form: windows of a few reads written straight to
                           host memory (insert-heavy stretches); GRP_K_QUERY holds the throughput forms */
-  GRP_K_VERIFY = 8,   /* grp_batch_verify: inserted tiles patched from the batch's records (units = their probes) */
-  GRP_K_BATCH = 9,    /* grp_batch_insert_reads: collect + apply of a whole batch (units = (frame, seed) records); large launches,
+  GRP_K_VERIFY = 7,   /* grp_batch_verify: inserted tiles patched from the batch's records (units = their probes) */
+  GRP_K_BATCH = 8,    /* grp_batch_insert_reads: collect + apply of a whole batch (units = (frame, seed) records); large launches,
                          timed by default — GRP_K_INSERT holds the latency-critical single-read inserts */
-  GRP_K_COUNT = 10
+  GRP_K_COUNT = 9
 };
 
 typedef struct
@@ -695,21 +623,6 @@ int grp_reset_kernel_stats(grp_ctx* ctx);
 
 /* HIP stream the context launches on (hipStream_t as void*) */
 void* grp_stream(grp_ctx* ctx);
-
-/*
- * Measurement (round 5): grp_query_tiles' result through the POSITION-SHARDED form of the query — the filter cut into
- * `n_owners` ranges of buckets, every probe a record in its owner's bin (partition), the bins gathered in owner order,
- * the IDs handed back and voted on per tile (csrc/grp_pshard.inc) — with the owners on ONE device: what the
- * partition and return passes cost beside the gather, before any xGMI traffic.  Same tile summaries as
- * grp_query_tiles (lists in any order); times_ms[3] = partition, gather, vote (HIP events).  Not on the product's
- * path (DESIGN.md 7 has the decision it feeds).
- */
-/* Measurement (round 5): the hash-and-test pass of a hashed filter of the ranks a batch touched —
- * `table_mib` MiB (a power of two), a share `fill` of its bits set, `n_hash` (1 or 2) bits tested per probe — over the
- * tiles of reads [first, first + count): *ms (best of three), *dirty_frames (frames with a probe that hits: what the
- * second decisions would still evaluate through the log), *frames.  csrc/grp_pshard.inc; tools/touch_filter_bench.py. */
-int grp_debug_touch_filter(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, uint32_t table_mib, double fill, uint32_t n_hash, float* ms, uint64_t* dirty_frames, uint64_t* frames);
-int grp_pshard_query(grp_ctx* ctx, const grp_reads* reads, uint32_t first, uint32_t count, uint32_t n_owners, grp_tile_summary* tiles, grp_id_count* lists, uint64_t list_cap, uint64_t* list_used, float* times_ms);
 
 #ifdef __cplusplus
 }

@@ -43,11 +43,6 @@ typedef struct
   int (*stream_abort)(void* ctx, uint32_t slot);
   int (*stream_poll)(void* ctx, uint32_t slot);
   int (*stream_end)(void* ctx, uint32_t slot, uint32_t* reads_decided);
-  /* optional (all four or none): the ordered commit loop on the device, grp_commit_loop_* */
-  int (*loop_begin)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_loop_params* params, const grp_read_decision** records, const volatile uint32_t** committed);
-  int (*loop_stop)(void* ctx);
-  int (*loop_poll)(void* ctx);
-  int (*loop_end)(void* ctx, grp_loop_result* result);
   /* optional (all four or none): a window of reads committed as one batch, grp_batch_* */
   int (*batch_insert)(void* ctx, const void* reads, const grp_batch_insert* inserts, uint32_t n_inserts, uint32_t block_tiles, uint32_t first_read);
   int (*batch_classify)(void* ctx, const void* reads, uint32_t first, uint32_t count, const grp_decide_params* params, const uint32_t* id_floor, grp_read_decision* out);

@@ -30,6 +30,14 @@ def test_engine_library_exports_every_declared_symbol(native):
     lib = native.load()
     for name in decl:
         assert getattr(lib, name) is not None
+    # ... and nothing else (round 6): the product library exports exactly what the headers declare — the measurement-only
+    # prototypes of include/grpath_dev.h exist in developer builds alone (make DEV=1), the frozen commit loop is gone
+    extra = {e for e in exp if e.startswith("grp_")} - set(decl)
+    if lib.grp_dev_hooks():
+        assert extra == set(_declared("grpath_dev.h", "grp_")), extra
+    else:
+        assert not extra, extra
+        assert not any("commit_loop" in e or "pshard" in e for e in exp)
 
 
 def test_host_library_exports_every_declared_symbol(native):
@@ -50,7 +58,7 @@ def test_struct_layouts_match_headers(native):
     assert native.tile_summary_dtype.itemsize == 24 and native.id_count_dtype.itemsize == 8
     assert ctypes.sizeof(host.gr_read_decision) == 32 == host.decision_dtype.itemsize
     assert ctypes.sizeof(host.gr_commit) == 48
-    assert ctypes.sizeof(host.grp_engine_vt) == 51 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(host.grp_engine_vt) == 47 * ctypes.sizeof(ctypes.c_void_p)
 
 
 def test_no_gpu_means_loud_failure_not_fallback(native):

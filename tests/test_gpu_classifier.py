@@ -14,19 +14,16 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("max_window,mode", [(1, "auto"), (5, "auto"), (4096, "auto"), (4096, "loop"), (4096, "stream"), (48, "stream"), (4096, "pipeline"), (4096, "sync"),
+@pytest.mark.parametrize("max_window,mode", [(1, "auto"), (5, "auto"), (4096, "auto"), (4096, "stream"), (48, "stream"), (4096, "pipeline"), (4096, "sync"),
                                              (1, "windows"), (4096, "windows"), (4096, "batch"), (6, "batch"), (4096, "batch_refused")])
 def test_hip_classifier_matches_serial_loop(oracle, native, max_window, mode, monkeypatch):
-    if mode == "loop" and not native.load().grp_dev_hooks():
-        pytest.skip("the commit loop is only in developer builds (make DEV=1)")
     from goldrush_amd import host, synth
     from oracle_engine import cached_serial_reference
 
-    # auto: the product's own choice (device-side commit loop while inserts are frequent, windows after);
-    # loop: commit loop only; the others: windows only, one form forced
-    env = {"auto": {}, "loop": {"GRP_LOOP": "force"}, "windows": {"GRP_LOOP": "off", "GRP_BATCH": "off"}, "stream": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "force"},
-           "pipeline": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "force"},
-           "sync": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "off"},
+    # auto: the product's own choice (batches while inserts are frequent, streaming windows after); the others: one form forced
+    env = {"auto": {}, "windows": {"GRP_BATCH": "off"}, "stream": {"GRP_BATCH": "off", "GRP_STREAM": "force"},
+           "pipeline": {"GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "force"},
+           "sync": {"GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "off"},
            "batch": {"GRP_BATCH": "force"},
            # a chain store of 8 entries: every batch whose reads share more than 8 ranks is refused ON THE DEVICE (the owners'
            # touches are taken back from the records), the classifier falls back to the classic commit and halves the batch
@@ -99,9 +96,9 @@ def test_hip_classifier_with_tiles_of_12000_bases(oracle, native, mode, monkeypa
     # *_flagged: a first-step table of 840 slots (71 distinct IDs): most tiles are flagged and redone with the worst-case table,
     # which at this geometry lives in global memory — the plain form, the form through a batch's log (the redo launch that
     # reads the list's length on the device included) and the hand-back of a streaming window
-    env = {"auto": {}, "batch": {"GRP_BATCH": "force"}, "stream": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "force"},
+    env = {"auto": {}, "batch": {"GRP_BATCH": "force"}, "stream": {"GRP_BATCH": "off", "GRP_STREAM": "force"},
            "batch_flagged": {"GRP_BATCH": "force", "GRP_SMALL_HIST": "840"},
-           "stream_flagged": {"GRP_LOOP": "off", "GRP_BATCH": "off", "GRP_STREAM": "force", "GRP_SMALL_HIST": "840"}}[mode]
+           "stream_flagged": {"GRP_BATCH": "off", "GRP_STREAM": "force", "GRP_SMALL_HIST": "840"}}[mode]
     for key, val in env.items():
         monkeypatch.setenv(key, val)
     tile, k, h, block = 12000, 22, 3, 2
@@ -446,7 +443,7 @@ def test_c1_stream_streaming_equals_synchronous_windows(native, monkeypatch):
     results = []
     # batches + streaming windows (the product's default) against classic synchronous windows
     for mode in ({"GRP_STREAM": "force"}, {"GRP_BATCH": "off", "GRP_STREAM": "off", "GRP_PIPELINE": "off"}):
-        for key in ("GRP_STREAM", "GRP_PIPELINE", "GRP_LOOP", "GRP_BATCH"):
+        for key in ("GRP_STREAM", "GRP_PIPELINE", "GRP_BATCH"):
             monkeypatch.delenv(key, raising=False)
         for key, val in mode.items():
             monkeypatch.setenv(key, val)

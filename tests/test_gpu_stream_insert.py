@@ -129,7 +129,6 @@ def test_classifier_golden_mode_streams_through_inserts(oracle, native, max_wind
 
     monkeypatch.setenv("GRP_STREAM", "force")
     monkeypatch.setenv("GRP_BATCH", "off")
-    monkeypatch.setenv("GRP_LOOP", "off")
     k, h, tile, block = 22, 3, 500, 4
     seeds = default_seeds(h)
     g = synth.random_genome(150_000, 21)
@@ -175,7 +174,6 @@ def test_classifier_silver_mode_streams_through_inserts(oracle, native, monkeypa
 
     monkeypatch.setenv("GRP_STREAM", "force")
     monkeypatch.setenv("GRP_BATCH", "off")
-    monkeypatch.setenv("GRP_LOOP", "off")
     k, h, tile, block = 22, 3, 500, 4
     seeds = default_seeds(h)
     g = synth.random_genome(150_000, 23)
