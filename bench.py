@@ -421,6 +421,9 @@ def main():
     stream_batch = a.stream_batch if a.stream_batch >= 0 else (2_000_000 if n_reads * 6400 > 100e9 else 0)
     rs = ReadStream(native, n_reads, G, stream_batch, sigma=a.len_sigma, repeat_frac=a.repeat_frac)
     eng = native.Engine(k, h, tile, m, seeds, device=local_rank)
+    # the -o the filter size was computed for: the engine allocates the phase-2 tables beside the fill (grp_set_occupancy_hint;
+    # a hint — grp_finalize measures the occupancy as ever), what the goldrush-path binary does with its own -o
+    eng.set_occupancy_hint(0.1)
     rs.eng = eng
     rs.get(0)
     t_synth = time.time() - t0
@@ -513,6 +516,7 @@ def main():
     t0 = time.time()
     pop = eng.finalize()
     t_finalize = time.time() - t0
+    finalize_parts = eng.finalize_times()
     if world > 1 and shm and hl.gr_ranks_same_u64(shm, world, pop) != 1:
         raise SystemExit("bench: the ranks' filters differ after the merge (rank %d: %d set bits)" % (rank, pop))
 
@@ -618,6 +622,8 @@ def main():
     # Every read of the stream went into the bit vector, so every probe of every frame meets a set
     # bit and is counted as a hit or a miss (goldrush_path.cpp:567-594): anything else means the
     # filter lost bits on the way (a sharded fill merged wrongly, a fill that did not cover the reads).
+    if eng.verify_stats()["impossible_deltas"]:
+        raise SystemExit("bench: grp_batch_verify met %d tiles with an impossible delta (a logic error of the patch: the results stay exact, the run is refused)" % eng.verify_stats()["impossible_deltas"])
     if st1["hits"] + st1["misses"] != h * st1["queries"]:
         raise SystemExit("bench: hits + misses = %d, expected h x queries = %d: the filter does not hold every read of the stream"
                          % (st1["hits"] + st1["misses"], h * st1["queries"]))
@@ -649,7 +655,7 @@ def main():
         # Only a summary taken on a build of exactly these engine sources counts (the summary stores
         # the sha256 of goldrush_amd/csrc, tools/pmc_summary.py): a kernel change without a new PMC
         # pass reports traffic: null instead of silently keeping the old bytes per probe.
-        traffic = bytes_per_probe_moved = None
+        traffic = bytes_per_probe_moved = fill_bytes_moved = None
         pmc_file = _newest_profile("r*_pmc_summary.json")
         pmc_note = "no PMC summary under profiles/"
         try:
@@ -660,6 +666,7 @@ def main():
             spec.loader.exec_module(mod)
             pmc = json.load(open(pmc_file))
             if pmc.get("csrc_tree_sha256") == mod.csrc_tree_hash():
+                fill_bytes_moved = (pmc.get("k_fill") or {}).get("hbm_bytes_per_probe")
                 key = "k_query_all_variants" if "k_query_all_variants" in pmc else "k_query<3, 2, 0>"
                 bytes_per_probe_moved = pmc[key]["hbm_bytes_per_probe"]
                 traffic = bytes_per_probe_moved * probes_per_launch
@@ -728,6 +735,17 @@ def main():
                                  "frac": ks["batch_insert"]["units"] * 256 / ks["batch_insert"]["ms"] / 1e6 / HBM_PEAK_GBPS,
                                  "note": "the pass pays per memory request, not per byte (DESIGN 4): a record is a 64-B quad read of the query line, one compare-and-swap on the insert line of the same 128-B unit and a 4-B store"}
                                 if ks["batch_insert"]["ms"] > 0 else None),
+            # phase 1 (round 6; SURVEY 8(d): bit-vector fill = 128 B per probe, a 64-B sector read-modify-write): k_fill over every position
+            # of every read, HIP events around its launches; untimed setup of the headline, but 40 % of a real run (aux.end_to_end)
+            "roofline_fill": ({"bound": "hbm", "kernel": "k_fill<h> (grp_bv_insert: hash every read position, test-then-atomicOr of bit hash % m)", "probes": int(fill_stats["units"]),
+                               "launches": int(fill_stats["launches"]), "kernel_ms": fill_stats["ms"], "avg_launch_ms": fill_stats["ms"] / max(fill_stats["launches"], 1),
+                               "bytes_per_probe": 128, "achieved": fill_stats["units"] * 128 / fill_stats["ms"] / 1e6, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": fill_stats["units"] * 128 / fill_stats["ms"] / 1e6 / HBM_PEAK_GBPS, "G_probes_per_s": fill_stats["units"] / fill_stats["ms"] / 1e6,
+                               "traffic": (fill_bytes_moved * fill_stats["units"] / max(fill_stats["launches"], 1) if fill_bytes_moved else None),
+                               "traffic_unit": "HBM bytes per launch (read + write): " + pmc_note, "moved_bytes_per_probe": fill_bytes_moved,
+                               "line_rate_ceiling_Gps": ceiling, "line_rate_frac": (fill_stats["units"] / fill_stats["ms"] / 1e6 / ceiling if ceiling else None),
+                               "note": "rank %d's share of the reads%s; a probe is one random 64-B line: the same request-rate wall as the query" % (rank, "" if world == 1 else " (1 / %d of the stream)" % world)}
+                              if fill_stats["ms"] > 0 else None),
             "phases": {"slice_reads": PHASE_SLICE,
                        "head": {"reads": head_reads, "seconds": head_s, "reads_per_s": head_reads / head_s if head_s > 0 else None, "inserts": head_ins,
                                 "definition": "slices before the first %d-read slice with an insert rate < 1 %%" % PHASE_SLICE},
@@ -736,6 +754,11 @@ def main():
                                                              "ids_inserted", "reads_committed", "inserts")},  # the run's result: the same for every N, mode and switch
                     "pop": int(pop),
                     "comm": comm_aux,  # N > 1: which path merged the ranks' fills (rccl: grp_comm_* / grp_bv_merge_ranks inside the engine), the communicator's size, RCCL's version
+                    # the whole goldrush-path run the reference times (goldrush_path.cpp:244,337,1208,1273): fill + setup + classification
+                    "end_to_end": {"fill_s": t_fill, "finalize_s": t_finalize, "classify_s": dt, "total_s": t_fill + t_finalize + dt, "reads_per_s": reads_done / (t_fill + t_finalize + dt),
+                                   "finalize_parts": finalize_parts,
+                                   "what": "phase 1 (bit-vector fill of every read + rank build) + phase 2 (the timed region) over the same resident reads; FASTQ ingest excluded (tools/cli_end_to_end.py has the binary's)"},
+                    "fill_probes": int(fill_stats["units"]),
                     "fill_reads_per_s": n_reads / t_fill, "fill_Gprobes_per_s": fill_stats["units"] * world / t_fill / 1e9, "fill_s": t_fill, "finalize_s": t_finalize,
                     "fill_mode": "single GPU" if world == 1 else "reads sharded over %d GPUs, bit vectors OR-merged as reduce-scatter (all-to-all + OR) + all-gather" % world, "synth_s": t_synth,
                     "read_batches": rs.n_batches, "synth_in_timed_region_s": rs.synth_s - synth_before,

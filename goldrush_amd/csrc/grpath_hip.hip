@@ -23,8 +23,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <cmath>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ---------------------------------------------------------------------------
@@ -207,6 +210,18 @@ struct grp_ctx
   uint64_t n_direct_windows = 0, n_direct_fallbacks = 0, n_general_windows = 0, n_redo_launches = 0; // GRP_DEBUG_STATS
   uint64_t n_chunks = 0; // rank-build chunks
   uint64_t* d_super = nullptr;
+  // grp_set_occupancy_hint: the phase-2 tables allocated by a helper thread while the fill runs (grp_finalize joins it)
+  struct Prealloc
+  {
+    double occupancy = 0.0;
+    bool started = false;
+    std::thread worker;
+    uint4* units = nullptr;
+    uint64_t units_buckets = 0; // capacity in 128-byte units
+    ulonglong2* far = nullptr;
+    uint64_t far_cap = 0;       // slots (a power of two)
+  } pre;
+  double finalize_times[6] = { 0, 0, 0, 0, 0, 0 };
   bool finalized = false;
   int n_cus = 0;
   std::mutex fill_mutex; // grp_bv_insert may be called from several host threads (the reference calls insertBV under `omp parallel`)
@@ -274,6 +289,7 @@ struct grp_ctx
       uint64_t n_body = 0;
     } pre[2];
     int n_pre = 0;
+    uint64_t n_dropped = 0; // prefetched bodies that were not followed by their parse (uploaded for nothing)
     uint32_t* d_counts = nullptr;
     uint64_t counts_cap = 0;
     uint64_t *d_base = nullptr, *d_super = nullptr, *d_total = nullptr, *d_nl = nullptr;
@@ -974,8 +990,8 @@ grp_destroy(grp_ctx* c)
     return;
   }
   if (getenv("GRP_DEBUG_STATS")) {
-    fprintf(stderr, "grp stats: direct windows %llu (fallbacks %llu), general windows %llu, redo launches %llu, flagged tiles %llu\n", (unsigned long long)c->n_direct_windows,
-            (unsigned long long)c->n_direct_fallbacks, (unsigned long long)c->n_general_windows, (unsigned long long)c->n_redo_launches, (unsigned long long)c->n_flagged_tiles);
+    fprintf(stderr, "grp stats: direct windows %llu (fallbacks %llu), general windows %llu, redo launches %llu, flagged tiles %llu, FASTQ prefetches dropped %llu\n", (unsigned long long)c->n_direct_windows,
+            (unsigned long long)c->n_direct_fallbacks, (unsigned long long)c->n_general_windows, (unsigned long long)c->n_redo_launches, (unsigned long long)c->n_flagged_tiles, (unsigned long long)c->ingest.n_dropped);
   }
   if (c->stream3) {
     (void)hipStreamSynchronize(c->stream3);
@@ -986,6 +1002,11 @@ grp_destroy(grp_ctx* c)
   if (c->stream) {
     (void)hipStreamSynchronize(c->stream);
   }
+  if (c->pre.worker.joinable()) {
+    c->pre.worker.join();
+  }
+  (void)hipFree(c->pre.units);
+  (void)hipFree(c->pre.far);
   comm_release(c);
   if (c->reg_text) {
     (void)hipHostUnregister(const_cast<char*>(c->reg_text));
@@ -1344,6 +1365,85 @@ grp_reads_tile0(const grp_reads* r)
 
 // ---- fill ---------------------------------------------------------------------------
 
+// buckets (128-byte units) and far-table slots a filter of m bits at occupancy `occ` needs: W as grp_finalize picks it
+// from the measured occupancy, the far entries from the binomial bucket population (E[max(c - 8, 0)] per bucket)
+static void
+prealloc_sizes(uint64_t m, double occ, uint64_t& n_buckets, uint64_t& far_cap)
+{
+  // a W slightly below what the hinted occupancy gives: a measured occupancy a few percent above the hint still fits
+  const double w = 6.0 / (occ * 1.04);
+  const uint32_t W = std::max<uint32_t>(GRP_BUCKET_IDS, std::min<uint32_t>(w >= 64.0 ? 64u : (uint32_t)w, 64u));
+  n_buckets = (m + W - 1) / W;
+  double pk = std::pow(1.0 - occ, (double)W), tail = 0.0; // P(c = 0)
+  for (uint32_t k = 0; k <= W; ++k) {
+    if (k > GRP_NEAR_CW) {
+      tail += pk * (double)(k - GRP_NEAR_CW);
+    }
+    pk = pk * (double)(W - k) / (double)(k + 1) * occ / (1.0 - occ);
+  }
+  const uint64_t expect_far = (uint64_t)(tail * (double)n_buckets * 1.10) + 1024;
+  far_cap = 1024;
+  while (far_cap < 2 * expect_far) {
+    far_cap <<= 1;
+  }
+}
+
+// called with the first fill launches enqueued: the allocations run beside them
+static void
+prealloc_start(grp_ctx* c)
+{
+  if (c->pre.started || c->pre.occupancy <= 0.0 || c->f.m == 0 || c->finalized) {
+    return;
+  }
+  c->pre.started = true;
+  uint64_t nb = 0, fc = 0;
+  prealloc_sizes(c->f.m, c->pre.occupancy, nb, fc);
+  const int device = c->device;
+  grp_ctx::Prealloc* p = &c->pre;
+  c->pre.worker = std::thread([p, nb, fc, device] {
+    if (hipSetDevice(device) != hipSuccess) {
+      return;
+    }
+    uint4* u = nullptr;
+    if (hipMalloc(&u, nb * (uint64_t)GRP_UNIT_U4 * 16) != hipSuccess) {
+      (void)hipGetLastError();
+      return; // grp_finalize allocates what it needs (and reports the failure if there is one)
+    }
+    ulonglong2* f = nullptr;
+    if (hipMalloc(&f, fc * sizeof(ulonglong2)) != hipSuccess) {
+      (void)hipGetLastError();
+      f = nullptr;
+    }
+    p->units = u;
+    p->units_buckets = nb;
+    p->far = f;
+    p->far_cap = f ? fc : 0;
+  });
+}
+
+int
+grp_set_occupancy_hint(grp_ctx* c, double occupancy)
+{
+  if (!c || !(occupancy > 0.0 && occupancy < 1.0)) {
+    return set_err(c, GRP_ERR_INVALID, "grp_set_occupancy_hint: occupancy must lie in (0, 1)");
+  }
+  if (c->finalized || c->pre.started) {
+    return set_err(c, GRP_ERR_STATE, "grp_set_occupancy_hint: the tables are being prepared already (call it before the first grp_bv_insert)");
+  }
+  c->pre.occupancy = occupancy;
+  return GRP_OK;
+}
+
+int
+grp_debug_finalize_times(const grp_ctx* c, double out[6])
+{
+  if (!c || !out) {
+    return GRP_ERR_INVALID;
+  }
+  memcpy(out, c->finalize_times, sizeof(c->finalize_times));
+  return GRP_OK;
+}
+
 int
 grp_set_filter_size(grp_ctx* c, uint64_t m)
 {
@@ -1402,6 +1502,7 @@ grp_bv_insert(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count)
     HIP_TRY(c, hipGetLastError());
     b += nb;
   }
+  prealloc_start(c); // (the first call with work: the phase-2 tables are allocated beside the fill, grp_set_occupancy_hint)
   return GRP_OK;
 }
 
@@ -1500,6 +1601,12 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
     return set_err(c, GRP_ERR_STATE, "grp_finalize: the filter size is not set (grp_set_filter_size)");
   }
   HIP_TRY(c, hipSetDevice(c->device));
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const auto t_begin = now();
+  for (double& v : c->finalize_times) {
+    v = 0.0;
+  }
   unsigned long long* d_scalars = nullptr; // [0] pop (popcount), [1] pop (scan), [2] overflow entries (IDs), [3] far entries (count words)
   HIP_TRY(c, hipMalloc(&d_scalars, 4 * sizeof(unsigned long long)));
   HIP_TRY(c, hipMemsetAsync(d_scalars, 0, 4 * sizeof(unsigned long long), c->stream));
@@ -1508,6 +1615,8 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
   unsigned long long h_scalars[4] = { 0, 0, 0, 0 };
   HIP_TRY(c, hipMemcpyAsync(h_scalars, d_scalars, sizeof(h_scalars), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const auto t_pop = now();
+  c->finalize_times[0] = secs(t_begin, t_pop);
   const uint64_t h_pop = h_scalars[0];
   // bucket width: ~6 set bits per bucket on average at the measured occupancy;
   // with W <= 13 a bucket can never overflow its 13 ID slots
@@ -1541,16 +1650,35 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
   // a bucket is a 128-byte unit since round 5: its query line {rel, bitmap, 13 IDs} and its insert line (8 count words);
   // the count words of the ranks beyond a bucket's 8th set bit come on top (the far table below, ~5 % of the ranks x 32 B)
   const uint64_t unit_bytes = (uint64_t)GRP_UNIT_U4 * 16;
-  hipError_t e = hipMalloc(&c->f.buckets, c->f.n_buckets * unit_bytes);
-  if (e != hipSuccess) {
-    delete t;
-    return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu bucket units (%.1f GB: 128 B per %u filter bits, IDs and insert counts included) failed: %s", (unsigned long long)c->f.n_buckets, c->f.n_buckets * unit_bytes / 1e9, W,
-                   hipGetErrorString(e));
+  // Round 6: the tables prepared beside the fill (grp_set_occupancy_hint) are taken where they are large enough — the
+  // measured occupancy picks W and the bucket count as ever, a prepared table only has to hold them.  hipMalloc of
+  // 130 GB + 8 GB took ~4 s of host time here, with the device idle.
+  if (c->pre.worker.joinable()) {
+    c->pre.worker.join();
+  }
+  bool used_prepared = false;
+  if (c->pre.units && c->pre.units_buckets >= c->f.n_buckets) {
+    c->f.buckets = c->pre.units;
+    c->pre.units = nullptr;
+    used_prepared = true;
+  } else {
+    if (c->pre.units) { // prepared for another geometry (the occupancy came out far above the hint): released first
+      (void)hipFree(c->pre.units);
+      c->pre.units = nullptr;
+    }
+    const hipError_t e = hipMalloc(&c->f.buckets, c->f.n_buckets * unit_bytes);
+    if (e != hipSuccess) {
+      delete t;
+      return set_err(c, GRP_ERR_NOMEM, "hipMalloc of %llu bucket units (%.1f GB: 128 B per %u filter bits, IDs and insert counts included) failed: %s", (unsigned long long)c->f.n_buckets, c->f.n_buckets * unit_bytes / 1e9, W,
+                     hipGetErrorString(e));
+    }
   }
   HIP_TRY(c, hipMalloc(&c->d_super, c->nsb * sizeof(uint64_t)));
   c->f.super = c->d_super;
   HIP_TRY(c, hipMalloc(&d_chunk_sum, c->n_chunks * 4));
   HIP_TRY(c, hipMalloc(&d_chunk_base, c->n_chunks * 8));
+  const auto t_alloc = now();
+  c->finalize_times[1] = secs(t_pop, t_alloc);
   k_bucket_chunk_sums<<<dim3((uint32_t)c->n_chunks), dim3(THREADS), 0, c->stream>>>(c->f.bv, c->f.m, W, c->f.n_buckets, d_chunk_sum);
   k_scan_chunks<<<dim3(1), dim3(1024), 0, c->stream>>>(d_chunk_sum, c->n_chunks, d_chunk_base, c->d_super, reinterpret_cast<uint64_t*>(d_scalars + 1));
   k_bucket_write<<<dim3((uint32_t)c->n_chunks), dim3(THREADS), 0, c->stream>>>(c->f.bv, c->f.m, W, c->f.n_buckets, c->f.buckets, d_chunk_base, c->d_super, d_scalars + 2);
@@ -1558,24 +1686,46 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(h_scalars, d_scalars, sizeof(h_scalars), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_chunk_sum);
-  (void)hipFree(d_chunk_base);
-  (void)hipFree(d_scalars);
   if (h_scalars[1] != h_pop) {
     return set_err(c, GRP_ERR_HIP, "internal: bucket scan counted %llu set bits, popcount %llu", h_scalars[1], (unsigned long long)h_pop);
   }
-  (void)hipFree(c->f.bv); // the bits now live in the buckets
-  c->f.bv = nullptr;
+  {
+    // the bits now live in the buckets.  (Measured in round 6 before deciding where this belongs: hipFree waits for the
+    // device — idle here — and unmaps 7.6 GB at C2; finalize_times[5] has what it takes.  A helper thread would free it
+    // behind the caller's back, but hipFree synchronises with EVERY later launch too: a parked streaming window that waits
+    // for the host while the host's next HIP call waits for the free is a deadlock this engine has met before)
+    const auto t_free = now();
+    (void)hipFree(c->f.bv);
+    c->f.bv = nullptr;
+    (void)hipFree(d_chunk_sum);
+    (void)hipFree(d_chunk_base);
+    (void)hipFree(d_scalars);
+    c->finalize_times[5] = secs(t_free, now());
+  }
   c->f.pop = h_pop;
+  const auto t_rank = now();
+  c->finalize_times[2] = secs(t_alloc, t_rank);
   {
     // the count words beyond a bucket's 8th set bit: {rank + 1, word}, open addressing at load <= 1/2, keys written now
     const uint64_t far_cap = next_pow2_64(std::max<uint64_t>(2 * h_scalars[3], 1024));
-    e = hipMalloc(&c->f.far, far_cap * sizeof(ulonglong2));
-    if (e != hipSuccess) {
-      return set_err(c, GRP_ERR_NOMEM, "hipMalloc of the far count table (%llu ranks beyond their bucket's 8th set bit, %.1f GB) failed: %s", h_scalars[3], far_cap * sizeof(ulonglong2) / 1e9, hipGetErrorString(e));
+    if (c->pre.far && c->pre.far_cap >= far_cap) {
+      // (a prepared table larger than needed keeps its size: the load only drops)
+      c->f.far = c->pre.far;
+      c->f.far_mask = c->pre.far_cap - 1;
+      c->pre.far = nullptr;
+    } else {
+      used_prepared = false;
+      if (c->pre.far) {
+        (void)hipFree(c->pre.far);
+        c->pre.far = nullptr;
+      }
+      const hipError_t e = hipMalloc(&c->f.far, far_cap * sizeof(ulonglong2));
+      if (e != hipSuccess) {
+        return set_err(c, GRP_ERR_NOMEM, "hipMalloc of the far count table (%llu ranks beyond their bucket's 8th set bit, %.1f GB) failed: %s", h_scalars[3], far_cap * sizeof(ulonglong2) / 1e9, hipGetErrorString(e));
+      }
+      c->f.far_mask = far_cap - 1;
     }
-    HIP_TRY(c, hipMemsetAsync(c->f.far, 0, far_cap * sizeof(ulonglong2), c->stream));
-    c->f.far_mask = far_cap - 1;
+    HIP_TRY(c, hipMemsetAsync(c->f.far, 0, (c->f.far_mask + 1) * sizeof(ulonglong2), c->stream));
     c->n_far = h_scalars[3];
     if (h_scalars[3]) {
       k_far_build<<<dim3((uint32_t)std::min<uint64_t>((c->f.n_buckets + THREADS - 1) / THREADS, 65536)), dim3(THREADS), 0, c->stream>>>(c->f);
@@ -1590,6 +1740,8 @@ grp_finalize(grp_ctx* c, uint64_t* pop)
   c->f.ovf_mask = ovf_cap - 1;
   c->n_ovf = h_scalars[2];
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->finalize_times[3] = secs(t_rank, now());
+  c->finalize_times[4] = used_prepared ? 1.0 : 0.0;
   c->finalized = true;
   if (pop) {
     *pop = h_pop;

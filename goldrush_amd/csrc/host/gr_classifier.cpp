@@ -1094,6 +1094,9 @@ Classifier::batch_round(uint32_t& pos)
       if (!env_.overlap_fixed) {
         if (ovl_thr_ == 0) {
           ovl_thr_ = env_.overlap_samples;
+          ovl_s_batches_ = n_batches_;
+          ovl_s_reads_ = n_batch_reads_;
+          ovl_s_queried_ = n_queried_;
         } else {
           const uint64_t db = n_batches_ - ovl_s_batches_, dr = n_batch_reads_ - ovl_s_reads_, dq = n_queried_ - ovl_s_queried_;
           if (db >= 8) {
@@ -1113,11 +1116,13 @@ Classifier::batch_round(uint32_t& pos)
               ovl_thr_ = next;
             }
             ovl_last_eff_ = eff;
+            // (the snapshots move only when a block of >= 8 batches has been judged — short hint windows
+            // accumulate until there are 8, instead of never adapting)
+            ovl_s_batches_ = n_batches_;
+            ovl_s_reads_ = n_batch_reads_;
+            ovl_s_queried_ = n_queried_;
           }
         }
-        ovl_s_batches_ = n_batches_;
-        ovl_s_reads_ = n_batch_reads_;
-        ovl_s_queried_ = n_queried_;
       }
       const uint32_t threshold = env_.overlap_fixed || ovl_thr_ == 0 ? env_.overlap_samples : ovl_thr_;
       if (nb >= 3 && vt_.window_overlap(ctx_, rg_.reads, base_ + at, nb, threshold, ovl_prev_.data()) != GRP_OK) {

@@ -88,6 +88,7 @@ hip_engine()
   vt.stream_resumable = [](void* c, uint32_t slot) { return grp_classify_stream_resumable(static_cast<grp_ctx*>(c), slot); };
   vt.stream_insert_done = [](void* c, uint32_t slot) { return grp_classify_stream_insert_done(static_cast<grp_ctx*>(c), slot); };
   vt.fastq_prefetch = [](void* c, const char* text, uint64_t n) { return grp_fastq_prefetch(static_cast<grp_ctx*>(c), text, n); };
+  vt.occupancy_hint = [](void* c, double o) { return grp_set_occupancy_hint(static_cast<grp_ctx*>(c), o); };
   return vt;
 }
 

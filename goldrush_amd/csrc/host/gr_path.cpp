@@ -217,7 +217,7 @@ public:
     if (in_.plain_size() != 0) { // a small file: one slot holds it all, no 2 x 256 MiB to allocate and page-lock
       chunk_ = std::min<size_t>(chunk_, std::max<size_t>((size_t)in_.plain_size() + 1, size_t(1) << 16));
     }
-    front_ = std::min<size_t>(std::max<size_t>(chunk_ / 16, 4096), size_t(16) << 20);
+    front_ = std::min<size_t>(std::max<size_t>(chunk_ / 16, 4096), (size_t)GRP_FASTQ_PREFETCH_FRONT); // (what a prefetched body may have in front of it, grpath_ingest.h)
     buf_.resize((size_t)kSlots * (front_ + chunk_));
     const char* pin_min = getenv("GRP_PIN_MIN_BYTES"); // tests: page-lock small buffers too
     if (run_.vt.fastq_pin && run_.vt.fastq_unpin && buf_.size() >= (pin_min ? (size_t)atoll(pin_min) : (size_t(8) << 20))) {
@@ -1131,6 +1131,11 @@ gr_path_main(int argc, char** argv, const grp_engine_vt* vt)
     if (run.vt.set_filter_size(run.ctx, filter_size) != GRP_OK) {
       return run.fail_engine("allocating the bit vector");
     }
+  }
+  if (run.vt.occupancy_hint && opt.occupancy > 0.0 && opt.occupancy < 1.0) {
+    // the ID / count tables of phase 2 are sized by the occupancy the fill will reach: -o, by construction of the filter
+    // size (:1183-1184) — the engine allocates them beside the fill instead of between the passes (a hint: ignored where wrong)
+    (void)run.vt.occupancy_hint(run.ctx, opt.occupancy);
   }
   if (run.world > 1 && shm.h && gr_ranks_share_device(shm.h, run.world, run.device) == 1) {
     // ranks on one device (a test box): their windows' launches must all fit it at once — the in-launch inserts of

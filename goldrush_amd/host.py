@@ -92,6 +92,7 @@ VT_TYPES = [
     ("stream_resumable", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("stream_insert_done", C.CFUNCTYPE(C.c_int, _vp, C.c_uint32)),
     ("fastq_prefetch", C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64)),
+    ("occupancy_hint", C.CFUNCTYPE(C.c_int, _vp, C.c_double)),
 ]
 
 
@@ -254,7 +255,7 @@ def hip_engine_vt() -> grp_engine_vt:
     vt = grp_engine_vt()
     alias = {"classify_begin": "classify_reads_begin", "classify_end": "classify_reads_end", "stream_begin": "classify_stream_begin_striped",
              "stream_abort": "classify_stream_abort", "stream_insert": "classify_stream_insert", "stream_begin_resumable": "classify_stream_begin_resumable", "stream_poll": "classify_stream_poll", "stream_end": "classify_stream_end",
-             "batch_insert": "batch_insert_reads", "stream_begin_striped_resumable": "classify_stream_begin_striped_resumable", "stream_resumable": "classify_stream_resumable", "stream_insert_done": "classify_stream_insert_done"}
+             "batch_insert": "batch_insert_reads", "stream_begin_striped_resumable": "classify_stream_begin_striped_resumable", "stream_resumable": "classify_stream_resumable", "stream_insert_done": "classify_stream_insert_done", "occupancy_hint": "set_occupancy_hint"}
     for name, ftype in VT_TYPES:
         sym = getattr(lib, "grp_" + alias.get(name, name))
         setattr(vt, name, C.cast(sym, ftype))

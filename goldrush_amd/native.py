@@ -85,6 +85,8 @@ SIGNATURES = {
     "grp_words_or_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "grp_bv_import_device": (C.c_int, [_vp, _vp]),
     "grp_finalize": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "grp_set_occupancy_hint": (C.c_int, [_vp, C.c_double]),
+    "grp_debug_finalize_times": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "grp_query_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(grp_query_stats)]),
     "grp_classify_reads": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp]),
     "grp_classify_reads_begin": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), C.c_uint32]),
@@ -428,11 +430,21 @@ class Engine:
     def bv_merge_ranks(self):
         self._check(self.lib.grp_bv_merge_ranks(self._h))
 
+    def set_occupancy_hint(self, occupancy: float):
+        """the -o the filter was sized for: the phase-2 tables are allocated beside the fill (grp_set_occupancy_hint)"""
+        self._check(self.lib.grp_set_occupancy_hint(self._h, float(occupancy)))
+
     def finalize(self) -> int:
         pop = C.c_uint64()
         self._check(self.lib.grp_finalize(self._h, C.byref(pop)))
         self.pop = pop.value
         return self.pop
+
+    def finalize_times(self) -> dict:
+        t = (C.c_double * 6)()
+        self._check(self.lib.grp_debug_finalize_times(self._h, t))
+        return {"popcount_and_wait_for_fill_s": t[0], "table_allocation_s": t[1], "rank_build_s": t[2], "far_and_overflow_tables_s": t[3],
+                "prepared_tables_used": bool(t[4]), "release_plain_vector_s": t[5]}
 
     # -- phase 2
     def query_tiles(self, batch: ReadBatch, first: int = 0, count: int | None = None, list_cap: int | None = None):

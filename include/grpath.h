@@ -214,6 +214,20 @@ int grp_bv_or_words(grp_ctx* ctx, uint64_t first, uint64_t n_words32, const uint
  * arrays (pop entries each).  After this call the bit vector is immutable.
  */
 int grp_finalize(grp_ctx* ctx, uint64_t* pop);
+/*
+ * Optional, before the fill (round 6): the occupancy the filter was sized for — the `-o` of
+ * calcOptimalSize (MIBloomFilter.hpp:94-101, goldrush_path.cpp:1183-1184).  The phase-2 tables
+ * (128 bytes per ~6 / occupancy filter bits: 130 GB at C2) are then allocated by a helper thread
+ * while the fill kernels run — hipMalloc of that size takes seconds of host time, which
+ * grp_finalize used to spend with the device idle (the reference's own setup / allocation timers:
+ * goldrush_path.cpp:1180-1208).  A hint only: grp_finalize measures the occupancy as before and
+ * allocates again where the tables prepared for the hint are too small; the filter is the same
+ * bit for bit either way.  0 < occupancy < 1.
+ */
+int grp_set_occupancy_hint(grp_ctx* ctx, double occupancy);
+/* seconds grp_finalize spent by part (diagnostics of the line above): [0] popcount + wait for the fill, [1] waiting for /
+ * doing the table allocations, [2] rank build kernels, [3] far / overflow tables, [4] 1.0 if the prepared tables were used, [5] (part of [2]) releasing the plain bit vector */
+int grp_debug_finalize_times(const grp_ctx* ctx, double out[6]);
 
 /* ---- phase 2: tile query -------------------------------------------------- */
 typedef struct

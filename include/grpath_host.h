@@ -90,6 +90,8 @@ typedef struct
   int (*stream_insert_done)(void* ctx, uint32_t slot); /* grp_classify_stream_insert_done */
   /* optional (with the fastq_* members; round 5): the next chunk's upload started ahead of its parse, grp_fastq_prefetch */
   int (*fastq_prefetch)(void* ctx, const char* text, uint64_t n_bytes);
+  /* optional (round 6): the occupancy the filter was sized for (-o): the phase-2 tables are allocated beside the fill, grp_set_occupancy_hint */
+  int (*occupancy_hint)(void* ctx, double occupancy);
 } grp_engine_vt;
 
 /* ---- pure functions --------------------------------------------------------- */

@@ -52,7 +52,7 @@ typedef struct
 int grp_fastq_parse(grp_ctx* ctx, const char* text, uint64_t n_bytes, int final_chunk, grp_fastq** out, uint64_t* n_records, uint64_t* bytes_consumed, int* stopped);
 /*
  * Optional (round 5): start the upload of a COMING chunk now.  `text` is that chunk's body: the later grp_fastq_parse is
- * given a text that ENDS with exactly these bytes at this address — the body itself, or the body with up to 1 MiB in front
+ * given a text that ENDS with exactly these bytes at this address — the body itself, or the body with up to GRP_FASTQ_PREFETCH_FRONT bytes (16 MiB) in front
  * of it (the unconsumed tail of the chunk before, which is only known once that chunk has been parsed); it finds the body on
  * the device and uploads what is in front of it alone.  Up to two prefetches may be pending, parsed in the order they were
  * issued.  Why: the copy of a 256 MiB chunk takes ~5 ms and, issued from inside grp_fastq_parse, only began when the fill
@@ -62,6 +62,7 @@ int grp_fastq_parse(grp_ctx* ctx, const char* text, uint64_t n_bytes, int final_
  * an error: the parse uploads as before).  (NULL, 0): every pending prefetch is forgotten and its copy waited for — call it
  * before the buffers the bodies live in are freed.
  */
+#define GRP_FASTQ_PREFETCH_FRONT (16ull << 20) /* bytes a later parse may put in front of a prefetched body (the engine leaves this much room) */
 int grp_fastq_prefetch(grp_ctx* ctx, const char* text, uint64_t n_bytes);
 /* copy the record table (n_records entries) to the host */
 int grp_fastq_records(grp_fastq* fq, grp_fastq_record* out);

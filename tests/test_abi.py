@@ -58,7 +58,7 @@ def test_struct_layouts_match_headers(native):
     assert native.tile_summary_dtype.itemsize == 24 and native.id_count_dtype.itemsize == 8
     assert ctypes.sizeof(host.gr_read_decision) == 32 == host.decision_dtype.itemsize
     assert ctypes.sizeof(host.gr_commit) == 48
-    assert ctypes.sizeof(host.grp_engine_vt) == 47 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(host.grp_engine_vt) == 48 * ctypes.sizeof(ctypes.c_void_p)
 
 
 def test_no_gpu_means_loud_failure_not_fallback(native):

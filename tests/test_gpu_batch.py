@@ -139,6 +139,9 @@ def _run(oracle, native, reads, tile, k, h, m, block, window, key, verify=None):
     if verify is not None:
         stats["verify"] = eng.verify_stats()
         assert stats["verify"]["fallbacks"] == 0 and stats["verify"]["patched"] > 0, stats
+        # the patch's self-check never fired (an older ID gained a frame / a count below zero would be a logic error of
+        # k_batch_delta: the run would stay exact — the tile is queried again — but it must not go unnoticed)
+        assert stats["verify"]["impossible_deltas"] == 0, stats
     eng.close()
     return stats, exp
 

@@ -37,7 +37,7 @@ for bp, cp in zip(bench_paths, csv_paths):
             sums.setdefault(k, {}).setdefault(c, 0.0)
             sums[k][c] += float(row["Counter_Value"])
             launches.setdefault(k, set()).add(row["Dispatch_Id"])
-    summary["passes"].append({"bench": bp, "counters": cp, "timed_probes": probes})
+    summary["passes"].append({"bench": bp, "counters": cp, "timed_probes": probes, "fill_probes": (b.get("aux") or {}).get("fill_probes")})
     for k, cs in sums.items():
         if not k.startswith(("k_query", "k_fill", "void k_query", "void k_fill")):
             continue
@@ -60,7 +60,24 @@ tot_f = sum(e.get("hbm_read_bytes_from_FETCH_SIZE", 0.0) for k, e in per_kernel.
 summary["k_query_all_variants"] = {
     "hbm_read_bytes_from_RDREQ": tot, "hbm_read_bytes_from_FETCH_SIZE": tot_f,
     "hbm_bytes_per_probe": tot / summary["passes"][0]["timed_probes"] if tot else None,
-    "hbm_bytes_per_probe_FETCH_SIZE": tot_f / summary["passes"][-1]["timed_probes"] if tot_f else None,
+    "hbm_bytes_per_probe_FETCH_SIZE": tot_f / summary["passes"][min(1, len(summary["passes"]) - 1)]["timed_probes"] if tot_f else None,
 }
+# the fill (round 6, bench.py roofline_fill): read requests + write requests of k_fill per probe of the pass's fill
+fill = {}
+for k, e in per_kernel.items():
+    if "k_fill" in k:
+        for c, v in e.items():
+            if isinstance(v, float):
+                fill[c] = fill.get(c, 0.0) + v
+fp = next((p["fill_probes"] for p in summary["passes"] if p.get("fill_probes")), None)
+if fill and fp:
+    rd = fill.get("TCC_EA0_RDREQ_sum", 0.0) * 64.0 - fill.get("TCC_EA0_RDREQ_32B_sum", 0.0) * 32.0
+    wr = None
+    if "TCC_EA0_WRREQ_sum" in fill:
+        w64 = fill.get("TCC_EA0_WRREQ_64B_sum", 0.0)
+        wr = w64 * 64.0 + (fill["TCC_EA0_WRREQ_sum"] - w64) * 32.0
+    summary["k_fill"] = {"fill_probes": fp, "hbm_read_bytes_per_probe": rd / fp if rd else None, "hbm_write_bytes_per_probe": wr / fp if wr is not None else None,
+                         "hbm_bytes_per_probe": ((rd + (wr or 0.0)) / fp) if rd else None, "atomics_at_memory_per_probe": fill.get("TCC_EA0_ATOMIC_sum", 0.0) / fp if "TCC_EA0_ATOMIC_sum" in fill else None,
+                         "note": "TCC_EA0_RDREQ x 64 B (+ TCC_EA0_WRREQ: 64-B and 32-B write requests) summed over the k_fill dispatches of the pass, per probe of that pass's fill (aux.fill_probes)"}
 json.dump(summary, open(out_path, "w"), indent=1)
 print(json.dumps(summary["kernels"], indent=1)[:3000])
