@@ -770,9 +770,25 @@ def main():
                     "query_latency": {"launches": ks["query_latency"]["launches"], "kernel_s": ks["query_latency"]["ms"] * 1e-3, "probes": ks["query_latency"]["units"],
                                       "what": "k_query<h,F,0,false> on windows of a few reads, summaries written straight to host memory"},
                     "kernel_stats": ks,  # every timed kernel family: launches, units, summed HIP-event ms (grpath.h GRP_K_*)
+                    "stream_keep": eng.stream_stats(),  # round 6: what the in-launch inserts kept / redid of the tiles queried behind the inserting read
                     "batch_verify": eng.verify_stats(),  # tiles of the batches' second decisions: patched from records / queried again / redone / calls that fell back
                     "wall_s": dt},
         }
+        # where the probes beyond the useful ones went: every frame of every read is useful once (h x queries);
+        # the rest is speculation that was thrown away or confirmation that exactness asks for
+        vs_, sk_ = out["aux"]["batch_verify"], out["aux"]["stream_keep"]
+        per_tile = tile * h
+        useful = h * int(st1["queries"] - st0["queries"])
+        executed = int(ks["query"]["units"] + ks["query_latency"]["units"])
+        acc = {
+            "batches_second_query_of_tiles_without_records": vs_["queried"] * per_tile,       # the confirmation of the reads / tiles a batch did not insert
+            "tiles_redone_with_the_worst_case_table_or_given_up_by_a_patch": (vs_["window_flagged"] + vs_["flagged"]) * per_tile,
+            "streaming_tiles_queried_again_behind_an_insert": (sk_["tiles_redone_dirty"] + sk_["tiles_redone_lost"]) * per_tile + sk_["in_progress_restarted"] * per_tile // 2,
+        }
+        acc["first_queries_thrown_away_and_windows_abandoned"] = max(executed - useful - sum(acc.values()), 0)  # batches taken back, the reads queried ahead of a batch that ended early, pipelined windows abandoned at an insert
+        out["aux"]["probe_accounting"] = {"useful": useful, "executed": executed, "executed_over_useful": executed / useful if useful else None, "beyond_useful": acc,
+                                          "share_of_useful": {k_: v_ / useful for k_, v_ in acc.items()} if useful else None,
+                                          "note": "tile counts x tile x h (a read's clipped last tile counted whole); streaming: grp_debug_stream_stats — tiles finished in front of an in-launch insert whose probes met a changed slot or whose fingerprints were gone, half a tile per tile in progress that started over"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rs, eng, cls, out["phases"], silver, n_reads, m, pop, seeds, k, tile, G, kept=cls.kept_commits() if witness else None)
             check = out["cpu_baseline"].pop("oracle_check", None)

@@ -93,6 +93,10 @@ struct QuerySlot
   unsigned long long* h_executed = nullptr; // pinned
   bool streaming = false;
   // a streaming window that applies inserts itself (grp_classify_stream_insert)
+  uint32_t* d_tile_ver = nullptr; // round 6: per tile of a resumable window, the generation its summary belongs to (DevStreamCtl::tile_ver)
+  uint64_t tile_ver_cap = 0;
+  uint32_t* d_rel = nullptr;    // release words of a resumable window's grid-wide waits: a 128-byte line per workgroup (STREAM_REL_WGS of them)
+  uint32_t* d_dbg = nullptr;    // developer (GRP_STREAM_DEBUG): a state word per workgroup of the streaming launch
   uint32_t* d_sctl = nullptr;   // SCT_* control block
   uint32_t* h_cmd = nullptr;    // mapped, coherent: [0] sequence number, [1..10] the command
   uint32_t* dmap_cmd = nullptr;
@@ -203,6 +207,7 @@ struct grp_ctx
   uint64_t n_overlap_calls = 0;
   uint32_t batch_epochs = GRP_EPOCH_MAX; // batches between two sweeps of the claims (GRP_BATCH_EPOCHS: tests)
   uint64_t n_batch_sweeps = 0; // times the batch epochs wrapped and the claims were swept out of the count words
+  uint64_t n_stream_keep[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // grp_debug_stream_stats
   uint64_t n_stream_idle_exits = 0, n_stream_coop_refused = 0; // parked windows that left by themselves (idle limit); resumable windows whose cooperative launch was refused
   uint64_t n_flagged_tiles = 0, n_flagged_distinct = 0, n_flagged_list = 0; // statistics: tiles redone with the worst-case table; why (distinct IDs / list length)
   uint64_t n_verify_impossible = 0;
@@ -266,6 +271,7 @@ struct grp_ctx
   unsigned long long* d_ir_locs = nullptr;
   uint32_t* d_ir_slots = nullptr;
   uint32_t* d_ir_counter = nullptr;
+  uint32_t* d_fp_tab[2] = { nullptr, nullptr }; // changed-slot sets of a streaming window's last two in-launch inserts (ir_cap words each)
   uint64_t ir_cap = 0;
   uint32_t ir_parity = 0;
   // RCCL communicator of a multi-GPU fill (grp_comm.inc), NULL on one GPU
@@ -628,8 +634,9 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     out_tiles = c->q->d_tiles;
     out_lists = c->q->d_lists;
   }
+  size_t launch_lds = g.lds; // dynamic LDS of the launch (the streaming form adds its fingerprint buffers)
   auto go = [&](auto kern) -> int {
-    int rc = ensure_lds(c, kern, g.lds);
+    int rc = ensure_lds(c, kern, launch_lds);
     if (rc != GRP_OK) {
       return rc;
     }
@@ -660,7 +667,7 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
         DevBatchView a_bv{};
         uint32_t* a_gtab = nullptr;
         void* args[] = { &a_f, &a_rd, &a_sd, &a_tile, &a_t0, &a_idx, &a_cap, &a_lim, &a_tiles, &a_lists, &a_lcap, &a_ctr, &a_flag, &a_fcap, &a_ds, &a_blk0, &a_sc, &a_bv, &a_gtab };
-        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3((uint32_t)n_launch), dim3(THREADS), args, (unsigned int)g.lds, c->stream);
+        const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(kern), dim3((uint32_t)n_launch), dim3(THREADS), args, (unsigned int)launch_lds, c->stream);
         if (e == hipSuccess) {
           return GRP_OK;
         }
@@ -668,7 +675,7 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
         return set_err(c, GRP_ERR_BUSY, "cooperative launch of a resumable window refused: %s", hipGetErrorString(e));
       }
     }
-    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), g.lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, blk0, stream_ctl ? *stream_ctl : DevStreamCtl{}, (c->view && !plain) ? *c->view : DevBatchView{}, nullptr);
+    kern<<<dim3((uint32_t)n_launch), dim3(THREADS), launch_lds, c->stream>>>(c->f, r->dev, c->d_seeds, c->params.tile, t0, d_tile_idx, g.hist_cap, g.distinct_limit, out_tiles, out_lists, list_cap, reinterpret_cast<unsigned long long*>(c->q->d_qctr), (d_tile_idx && !list_flags) ? nullptr : c->q->d_flag_idx, (uint32_t)c->q->d_flag_cap, direct_stride, blk0, stream_ctl ? *stream_ctl : DevStreamCtl{}, (c->view && !plain) ? *c->view : DevBatchView{}, nullptr);
     return GRP_OK;
   };
   // The synchronous forms (large windows, the two queries of a batch): two frames per lane and pass
@@ -719,12 +726,43 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     // one frame per lane and pass: fewer registers, more resident workgroups — measured
     // better than two for the persistent form (h = 3: +3 %, h = 5: +19 %)
     auto kern = k_query<HH, 1, 0, true>;
-    int rc = ensure_lds(c, kern, g.lds);
+    int per_cu = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, THREADS, g.lds));
+    // Round 6: a window that applies inserts itself keeps the probes' fingerprints of the tile in progress and of the
+    // tile before it in LDS (DevStreamCtl::n_fp) — as many of the two buffers as fit WITHOUT costing a resident workgroup
+    // (three per CU is what the launch runs at, below): C2's geometry 27.9 + 2 x 12.3 KB, three of them in the CU's 160 KB;
+    // h = 5 with tiles of 1000 (48 KB of count table) has no room: such a window hands everything behind an insert out again.
+    DevStreamCtl sc_fit = *stream_ctl;
+    QueryGeom g_fit = g;
+    sc_fit.n_fp = 0;
+    if (stream_ctl->ctl && stream_ctl->n_fp) {
+      static const int keep_env = [] { // developer switch / tests: fingerprint buffers per workgroup (0: rounds 3 - 5's form)
+        const char* e = getenv("GRP_STREAM_KEEP");
+        return e ? std::max(0, std::min(2, atoi(e))) : 2;
+      }();
+      const uint32_t fb = 3u * (64u - ((uint32_t)HH - 1u)) + 64u; // frames per pass at least (k_query: the helper-lane layout)
+      const uint32_t passes = (c->params.tile + fb - 1u) / fb;
+      const uint32_t words = passes * (uint32_t)THREADS * (uint32_t)HH;
+      const int want_cu = std::min(per_cu, 3);
+      for (int nf = std::min<int>(keep_env, (int)stream_ctl->n_fp); nf >= 1; --nf) {
+        const size_t lds = g.lds + (size_t)nf * words * 4u;
+        int fit = 0;
+        if (lds <= LDS_PER_WORKGROUP && ensure_lds(c, kern, lds) == GRP_OK && hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kern, THREADS, lds) == hipSuccess && fit >= want_cu) {
+          sc_fit.n_fp = (uint32_t)nf;
+          sc_fit.fp_off = (uint32_t)g.lds;
+          sc_fit.fp_words = words;
+          g_fit.lds = lds;
+          break;
+        }
+        (void)hipGetLastError();
+      }
+    }
+    stream_ctl = &sc_fit;
+    launch_lds = g_fit.lds; // (the launch takes the geometry with the fingerprint buffers)
+    int rc = ensure_lds(c, kern, launch_lds);
     if (rc != GRP_OK) {
       return rc;
     }
-    int per_cu = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, THREADS, g.lds));
     static const int cap_per_cu = [] { // developer hook
       const char* e = getenv("GRP_STREAM_WGS_PER_CU");
       return e ? atoi(e) : 0;
@@ -741,7 +779,7 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     // cooperative launch), profiles/r04_c1_workgroups_per_cu.txt.  Rounds 1 - 3 ran three (the 43.6 KB table allowed
     // no more); three leave a wave slot per SIMD free, and are as fast (C1 559 k reads/s in the steady state, two: 500 k).
     per_cu = std::min(per_cu, cap_per_cu > 0 ? cap_per_cu : 3);
-    const uint64_t resident = (uint64_t)std::max(per_cu, 1) * (uint64_t)std::max(c->n_cus, 1);
+    const uint64_t resident = std::min<uint64_t>((uint64_t)std::max(per_cu, 1) * (uint64_t)std::max(c->n_cus, 1), STREAM_REL_WGS);
     n_launch = std::min<uint64_t>(n_launch, resident);
     return go(kern);
   }
@@ -963,14 +1001,15 @@ grp_create(const grp_params* p, grp_ctx** out)
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_abort), sl.h_abort, 0));
     *sl.h_abort = 0;
     CREATE_TRY(hipMalloc(&sl.d_sctl, SCT_WORDS * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc(&sl.d_rel, (size_t)STREAM_REL_WGS * 32u * sizeof(uint32_t)));
     CREATE_TRY(hipHostMalloc(&sl.h_cmd, 64, hipHostMallocMapped | hipHostMallocCoherent));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_cmd), sl.h_cmd, 0));
     CREATE_TRY(hipHostMalloc(&sl.h_ack, 64, hipHostMallocMapped | hipHostMallocCoherent));
     CREATE_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.dmap_ack), sl.h_ack, 0));
     memset(sl.h_cmd, 0, 64);
     memset(sl.h_ack, 0, 64);
-    CREATE_TRY(hipMalloc(&sl.d_executed, sizeof(unsigned long long)));
-    CREATE_TRY(hipHostMalloc(&sl.h_executed, sizeof(unsigned long long), hipHostMallocDefault));
+    CREATE_TRY(hipMalloc(&sl.d_executed, 8 * sizeof(unsigned long long)));
+    CREATE_TRY(hipHostMalloc(&sl.h_executed, 8 * sizeof(unsigned long long), hipHostMallocDefault));
   }
   CREATE_TRY(hipHostMalloc(&c->h_lists, LIST_PREFIX * sizeof(grp_id_count), hipHostMallocDefault));
   CREATE_TRY(hipHostMalloc(&c->h_small_tiles, SMALL_TILES * sizeof(grp_tile_summary), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1052,6 +1091,9 @@ grp_destroy(grp_ctx* c)
     (void)hipFree(sl.d_tiles_done);
     (void)hipFree(sl.d_executed);
     (void)hipFree(sl.d_sctl);
+    (void)hipFree(sl.d_tile_ver);
+    (void)hipFree(sl.d_dbg);
+    (void)hipFree(sl.d_rel);
     if (sl.h_cmd) {
       (void)hipHostFree(sl.h_cmd);
     }
@@ -1159,6 +1201,8 @@ grp_destroy(grp_ctx* c)
   (void)hipFree(c->d_ir_locs);
   (void)hipFree(c->d_ir_slots);
   (void)hipFree(c->d_ir_counter);
+  (void)hipFree(c->d_fp_tab[0]);
+  (void)hipFree(c->d_fp_tab[1]);
   if (c->stream3) {
     (void)hipStreamDestroy(c->stream3);
   }
@@ -2329,9 +2373,14 @@ ensure_insert_table(grp_ctx* c, uint64_t max_ranks)
   (void)hipFree(c->d_ir_masks);
   (void)hipFree(c->d_ir_locs);
   (void)hipFree(c->d_ir_slots);
+  (void)hipFree(c->d_fp_tab[0]);
+  (void)hipFree(c->d_fp_tab[1]);
   c->d_ir_keys = c->d_ir_masks = c->d_ir_locs = nullptr;
   c->d_ir_slots = nullptr;
+  c->d_fp_tab[0] = c->d_fp_tab[1] = nullptr;
   c->ir_cap = 0;
+  HIP_TRY(c, hipMalloc(&c->d_fp_tab[0], want * 4));
+  HIP_TRY(c, hipMalloc(&c->d_fp_tab[1], want * 4));
   HIP_TRY(c, hipMalloc(&c->d_ir_keys, want * 8));
   HIP_TRY(c, hipMalloc(&c->d_ir_masks, want * 8));
   HIP_TRY(c, hipMalloc(&c->d_ir_locs, want * 8));
@@ -2441,7 +2490,8 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
     // Not now, then: the caller begins this window once the other one has ended.
     const QuerySlot& other = c->slot[slot ^ 1u];
     const bool grows = count > sl.sdec_cap || std::max<uint64_t>(count, 1) > sl.tiles_done_cap || nt + 1 > sl.d_dec_cap || std::max<uint64_t>(nt, 1) > sl.d_tiles_cap ||
-                       std::max<uint64_t>(sl.d_lists_cap, 4 * nt + 4096) > sl.d_lists_cap || std::max<uint64_t>(nt, 1) > sl.d_flag_cap;
+                       std::max<uint64_t>(sl.d_lists_cap, (want_resumable ? 8 : 4) * nt + 4096) > sl.d_lists_cap || std::max<uint64_t>(nt, 1) > sl.d_flag_cap ||
+                       (want_resumable && std::max<uint64_t>(nt, 1) > sl.tile_ver_cap);
     if (grows && other.busy && other.streaming && other.resumable) {
       return set_err(c, GRP_ERR_BUSY, "grp_classify_stream_begin: the slot's buffers must grow while a resumable window is in flight in the other slot: begin this window when that one has ended");
     }
@@ -2476,13 +2526,17 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
     HIP_TRY(c, hipMalloc(&sl.d_dec_scratch, cap * 8));
     sl.d_dec_cap = cap;
   }
-  sl.list_cap = std::max<uint64_t>(sl.d_lists_cap, 4 * nt + 4096);
+  // (a window that keeps tiles across its inserts does not start its list arena over at each of them: twice the room)
+  sl.list_cap = std::max<uint64_t>(sl.d_lists_cap, (want_resumable ? 8 : 4) * nt + 4096);
   rc = ensure_dev(c, sl.d_tiles, sl.d_tiles_cap, std::max<uint64_t>(nt, 1));
   if (rc == GRP_OK) {
     rc = ensure_dev(c, sl.d_lists, sl.d_lists_cap, sl.list_cap);
   }
   if (rc == GRP_OK) {
     rc = ensure_dev(c, sl.d_flag_idx, sl.d_flag_cap, std::max<uint64_t>(nt, 1));
+  }
+  if (rc == GRP_OK && want_resumable) { // (round 6) what a window keeps across an in-launch insert: a mark per tile (DevStreamCtl::tile_ver)
+    rc = ensure_dev(c, sl.d_tile_ver, sl.tile_ver_cap, std::max<uint64_t>(nt, 1));
   }
   if (rc != GRP_OK) {
     return rc;
@@ -2579,10 +2633,15 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
     HIP_TRY(c, hipMemsetAsync(sl.d_abort, 0, 256, c->stream));
     HIP_TRY(c, hipMemsetAsync(sl.d_abort + 48, 0xFF, sizeof(uint32_t), c->stream)); // park: nothing stale yet
     HIP_TRY(c, hipMemsetAsync(sl.d_tiles_done, 0, (size_t)count * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(sl.d_executed, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(sl.d_executed, 0, 8 * sizeof(unsigned long long), c->stream));
     if (sl.resumable) {
       HIP_TRY(c, hipMemsetAsync(sl.d_sctl, 0, SCT_WORDS * sizeof(uint32_t), c->stream));
       HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sl.d_sctl + SCT_GEN), 1, 1, c->stream));
+      HIP_TRY(c, hipMemsetAsync(sl.d_tile_ver, 0, std::max<uint64_t>(nt, 1) * sizeof(uint32_t), c->stream));
+      HIP_TRY(c, hipMemsetAsync(sl.d_rel, 0, (size_t)STREAM_REL_WGS * 32u * sizeof(uint32_t), c->stream));
+      // the changed-slot sets of the window's inserts start empty (the sets of the window before may hold its last two)
+      HIP_TRY(c, hipMemsetAsync(c->d_fp_tab[0], 0, c->ir_cap * sizeof(uint32_t), c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_fp_tab[1], 0, c->ir_cap * sizeof(uint32_t), c->stream));
       __atomic_store_n(&sl.h_cmd[0], 0u, __ATOMIC_RELEASE);
       sl.h_ack[0] = 0;
       sl.h_ack[1] = 0;
@@ -2610,6 +2669,24 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
       sc.cmd_host = sl.dmap_cmd;
       sc.ack_host = sl.dmap_ack;
       sc.tb = InsertTable{ c->d_ir_keys, c->d_ir_masks, c->d_ir_locs, c->d_ir_slots, c->d_ir_counter, c->ir_cap - 1 };
+      static const bool dbg_on = getenv("GRP_STREAM_DEBUG") != nullptr;
+      if (dbg_on) {
+        if (!sl.d_dbg) {
+          HIP_TRY(c, hipMalloc(&sl.d_dbg, 4096 * sizeof(uint32_t)));
+        }
+        HIP_TRY(c, hipMemsetAsync(sl.d_dbg, 0, 4096 * sizeof(uint32_t), c->stream));
+        sc.dbg = sl.d_dbg;
+      }
+      sc.rel = sl.d_rel;
+      sc.tile_ver = sl.d_tile_ver;
+      sc.fp_tab[0] = c->d_fp_tab[0];
+      sc.fp_tab[1] = c->d_fp_tab[1];
+      sc.fp_mask = (uint32_t)(c->ir_cap - 1);
+      // (the relay workgroups look for the host's words between tiles — one of the 32 every ~2 us; between passes as well cost
+      // those workgroups a quarter of their rate for nothing measurable: GRP_STREAM_PASS_RELAY=on, developer switch)
+      static const bool pass_relay = getenv("GRP_STREAM_PASS_RELAY") && !strcmp(getenv("GRP_STREAM_PASS_RELAY"), "on");
+      sc.pass_relay = pass_relay ? 1u : 0u;
+      sc.n_fp = 2; // asked for; launch_query gives what this geometry's LDS has room for beside three workgroups per CU (0: nothing is kept)
       static const double wait_s = [] { // developer hook: time limit of a grid-wide wait (seconds)
         const char* e = getenv("GRP_STREAM_WAIT_S");
         return e ? atof(e) : 2.0;
@@ -2636,10 +2713,10 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
       }
       HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipMemcpyAsync(sl.h_executed, sl.d_executed, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(sl.h_executed, sl.d_executed, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemsetAsync(sl.d_qctr, 0, 8 * sizeof(uint64_t), c->stream));
   } else {
-    *sl.h_executed = 0;
+    memset(sl.h_executed, 0, 8 * sizeof(unsigned long long));
   }
   HIP_TRY(c, hipEventRecord(sl.done, c->stream));
   return GRP_OK;
@@ -2683,6 +2760,9 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
   sl.busy = false;
   sl.streaming = false;
   c->kstat[GRP_K_QUERY].units += *sl.h_executed;
+  for (int i = 1; i < 8; ++i) { // what the window's in-launch inserts kept and redid (grp_debug_stream_stats)
+    c->n_stream_keep[i] += sl.h_executed[i];
+  }
   if (reads_decided) {
     uint32_t n = 0;
     for (uint32_t j = 0; j < sl.count; ++j) {
@@ -2697,8 +2777,46 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
     sl.resumable = false;
     const uint32_t code = __atomic_load_n(&sl.h_ack[1], __ATOMIC_ACQUIRE);
     const uint32_t applied = __atomic_load_n(&sl.h_ack[0], __ATOMIC_ACQUIRE);
+    if ((code == 2 || code == 1) && sl.d_dbg) { // developer: where every workgroup was
+      std::vector<uint32_t> st(4096);
+      if (hipMemcpy(st.data(), sl.d_dbg, st.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+        std::string line;
+        for (size_t i = 0; i < st.size(); ++i) {
+          if (i < 2048 && st[i] != 0 && ((st[i] >> 28) != 5u || (st[i] & 0xFFFFu) != ((sl.cmd_seq << 1) & 0xFFFFu))) {
+            char b[64];
+            snprintf(b, sizeof(b), " %zu:%08x", i, st[i]);
+            line += b;
+          }
+        }
+        {
+          // when the workgroups came to the event and reached the first wait (100 MHz ticks, relative to the earliest)
+          const uint32_t grid = std::min<uint32_t>(st[4095], 1000u);
+          uint32_t t_min = 0xFFFFFFFFu;
+          for (uint32_t i = 0; i < grid; ++i) {
+            t_min = std::min(t_min, st[2048 + i]);
+          }
+          std::vector<std::pair<uint32_t, uint32_t>> late;
+          for (uint32_t i = 0; i < grid; ++i) {
+            late.push_back({ st[2048 + i] - t_min, i });
+          }
+          std::sort(late.begin(), late.end());
+          char b[200];
+          snprintf(b, sizeof(b), " | grid %u; reached the first wait (us behind the earliest): median %.1f", st[4095], late[grid / 2].first * 1e-2);
+          line += b;
+          for (uint32_t q = grid >= 6 ? grid - 6 : 0; q < grid; ++q) {
+            const uint32_t w = late[q].second;
+            snprintf(b, sizeof(b), "; wg %u %.1f us (came to the event %.1f us earlier, %s)", w, late[q].first * 1e-2, (st[2048 + w] - st[1024 + w]) * 1e-2, st[3072 + w] == 2 ? "tile suspended" : "idle");
+            line += b;
+          }
+        }
+        fprintf(stderr, "  window: reads [%u, %u), %llu tiles; command: read %u tiles [%u, %u) block %u first id %u offset %u resume read %u tile %u decided base %u gen %u\n", sl.first, sl.first + sl.count, (unsigned long long)sl.nt,
+                sl.h_cmd[1], sl.h_cmd[2], sl.h_cmd[3], sl.h_cmd[4], sl.h_cmd[5], sl.h_cmd[6], sl.h_cmd[7], sl.h_cmd[8], sl.h_cmd[9], sl.h_cmd[10]);
+        fprintf(stderr, "grp_classify_stream_end: code %u, first to give up: wait %u, workgroup %u, %u groups had arrived; workgroups not inside insert %u (index:state):%s\n", code, sl.h_ack[14], sl.h_ack[15] >> 16, sl.h_ack[15] & 0xFFFFu, sl.cmd_seq, line.c_str());
+      }
+    }
     if (code == 2) {
-      return set_err(c, GRP_ERR_STATE, "grp_classify_stream_end: a grid-wide wait timed out in the middle of an insert (the ID array may be inconsistent)");
+      return set_err(c, GRP_ERR_STATE, "grp_classify_stream_end: a grid-wide wait timed out in the middle of an insert (the ID array may be inconsistent); first to give up: wait %u, workgroup %u, %u groups had arrived",
+                     sl.h_ack[14], sl.h_ack[15] >> 16, sl.h_ack[15] & 0xFFFFu);
     }
     if (code == 3) {
       // The parked window was told nothing for its idle limit (16 x GRP_STREAM_WAIT_S: a host stopped by a
@@ -2717,6 +2835,9 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
                     "grp_classify_stream_end: the parked window was never told how to go on (idle time limit) and left; launch: park %u decided %u next tile %u / %llu event %u command seen %u "
                     "generation %u; host: %u reads, generation %u, commands posted %u applied %u, first open record %u",
                     sl.h_ack[8], sl.h_ack[9], sl.h_ack[10], (unsigned long long)sl.nt, sl.h_ack[11], sl.h_ack[12], sl.h_ack[13], sl.count, sl.gen, sl.cmd_seq, applied, first_open);
+      if (c->env_trace_abort) {
+        fprintf(stderr, "%s\n", c->err.c_str());
+      }
     }
     if (applied != sl.cmd_seq) {
       // The launch ended without the insert posted last (an abort overtook it or the launch had left already: 1; the
@@ -2759,6 +2880,9 @@ grp_classify_stream_insert(grp_ctx* c, uint32_t slot, uint32_t read_idx, uint32_
     static uint64_t n_tr = 0;
     for (int i = 0; i < 4; ++i) {
       t_ph[i] += sl.h_ack[4 + i] * 1e-2;
+    }
+    if (getenv("GRP_TRACE_ABORT")[0] == '2') {
+      fprintf(stderr, "  previous in-launch insert, workgroup 0: collect %.1f us, first wait %.1f us, apply %.1f us, second wait %.1f us\n", sl.h_ack[4] * 1e-2, sl.h_ack[5] * 1e-2, sl.h_ack[6] * 1e-2, sl.h_ack[7] * 1e-2);
     }
     if ((++n_tr & 511u) == 0) {
       fprintf(stderr, "in-launch inserts %llu: workgroup 0 spent %.1f us collecting, %.1f us in the first wait, %.1f us applying, %.1f us in the second wait\n", (unsigned long long)n_tr, t_ph[0] / n_tr,
@@ -3211,6 +3335,17 @@ grp_debug_decide(grp_ctx* c, uint32_t n_reads, const uint64_t* tile0, const grp_
   }
 #undef DBG_TRY
   cleanup();
+  return GRP_OK;
+}
+
+int
+grp_debug_stream_stats(const grp_ctx* c, uint64_t out[8])
+{
+  if (!c || !out) {
+    return GRP_ERR_INVALID;
+  }
+  memcpy(out, c->n_stream_keep, sizeof(c->n_stream_keep));
+  out[0] = c->n_stream_coop_refused;
   return GRP_OK;
 }
 

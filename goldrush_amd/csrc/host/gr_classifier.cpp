@@ -1486,6 +1486,10 @@ Classifier::stream_round(uint32_t& pos)
     if (trace_abort && tr_resume_pending) { // the first record behind an insert the launch applied itself
       tr_resume_pending = false;
       t_resume += secs(tr_resume0, now());
+      static const bool each = getenv("GRP_TRACE_ABORT") && getenv("GRP_TRACE_ABORT")[0] == '2';
+      if (each) {
+        fprintf(stderr, "insert behind read %u of a window of %u (launched %.1f us ago): %.1f us to the first record behind it\n", j - 1, S, 1e6 * secs(tr_after_launch, tr_resume0), 1e6 * secs(tr_resume0, now()));
+      }
       if ((++n_resumed & 511u) == 0) {
         fprintf(stderr, "in-launch inserts %llu: %.1f us from the insert record to the first record behind it\n", (unsigned long long)n_resumed, 1e6 * t_resume / n_resumed);
       }

@@ -113,6 +113,7 @@ SIGNATURES = {
     "grp_batch_verify": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(grp_decide_params), _vp, _vp]),
     "grp_window_overlap": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "grp_debug_verify_stats": (C.c_int, [_vp, _vp]),
+    "grp_debug_stream_stats": (C.c_int, [_vp, _vp]),
     "grp_batch_undo": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "grp_batch_end": (C.c_int, [_vp]),
     "grp_insert_tiles": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -613,6 +614,12 @@ class Engine:
         out = np.zeros(12, dtype=np.uint64)
         self._check(self.lib.grp_debug_verify_stats(self._h, _ptr(out)))
         return dict(zip(("patched", "queried", "flagged", "fallbacks", "uncertified", "unpatched", "window_flagged", "flagged_distinct", "flagged_list", "claim_sweeps", "impossible_deltas", "far_count_words"), (int(x) for x in out)))
+
+    def stream_stats(self) -> dict:
+        """what the in-launch inserts of the streaming windows did with the tiles queried behind the inserting read"""
+        out = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.grp_debug_stream_stats(self._h, _ptr(out)))
+        return dict(zip(("coop_refused", "tiles_kept", "tiles_redone_dirty", "tiles_redone_lost", "in_progress_went_on", "in_progress_restarted", "inserts_kept_nothing", "inserts_kept"), (int(x) for x in out)))
 
     def batch_undo(self, from_read: int, id_floor: int):
         """takes back the inserts of reads >= from_read (batch index); id_floor = the first ID read from_read could allocate"""
