@@ -271,6 +271,7 @@ struct grp_ctx
   unsigned long long* d_ir_locs = nullptr;
   uint32_t* d_ir_slots = nullptr;
   uint32_t* d_ir_counter = nullptr;
+  uint32_t dbg_stream_lds = 0, dbg_stream_grid = 0; // developer (GRP_STREAM_DEBUG): the last streaming launch
   uint32_t* d_fp_tab[2] = { nullptr, nullptr }; // changed-slot sets of a streaming window's last two in-launch inserts (ir_cap words each)
   uint64_t ir_cap = 0;
   uint32_t ir_parity = 0;
@@ -781,6 +782,8 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
     per_cu = std::min(per_cu, cap_per_cu > 0 ? cap_per_cu : 3);
     const uint64_t resident = std::min<uint64_t>((uint64_t)std::max(per_cu, 1) * (uint64_t)std::max(c->n_cus, 1), STREAM_REL_WGS);
     n_launch = std::min<uint64_t>(n_launch, resident);
+    c->dbg_stream_lds = (uint32_t)launch_lds;
+    c->dbg_stream_grid = (uint32_t)n_launch;
     return go(kern);
   }
   // (round 2 had a second form for windows of a few reads, the care loop unrolled for weight-16
@@ -2672,9 +2675,9 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
       static const bool dbg_on = getenv("GRP_STREAM_DEBUG") != nullptr;
       if (dbg_on) {
         if (!sl.d_dbg) {
-          HIP_TRY(c, hipMalloc(&sl.d_dbg, 4096 * sizeof(uint32_t)));
+          HIP_TRY(c, hipMalloc(&sl.d_dbg, 8192 * sizeof(uint32_t)));
         }
-        HIP_TRY(c, hipMemsetAsync(sl.d_dbg, 0, 4096 * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(sl.d_dbg, 0, 8192 * sizeof(uint32_t), c->stream));
         sc.dbg = sl.d_dbg;
       }
       sc.rel = sl.d_rel;
@@ -2682,10 +2685,6 @@ stream_begin_impl(grp_ctx* c, const grp_reads* r, uint32_t first, uint32_t count
       sc.fp_tab[0] = c->d_fp_tab[0];
       sc.fp_tab[1] = c->d_fp_tab[1];
       sc.fp_mask = (uint32_t)(c->ir_cap - 1);
-      // (the relay workgroups look for the host's words between tiles — one of the 32 every ~2 us; between passes as well cost
-      // those workgroups a quarter of their rate for nothing measurable: GRP_STREAM_PASS_RELAY=on, developer switch)
-      static const bool pass_relay = getenv("GRP_STREAM_PASS_RELAY") && !strcmp(getenv("GRP_STREAM_PASS_RELAY"), "on");
-      sc.pass_relay = pass_relay ? 1u : 0u;
       sc.n_fp = 2; // asked for; launch_query gives what this geometry's LDS has room for beside three workgroups per CU (0: nothing is kept)
       static const double wait_s = [] { // developer hook: time limit of a grid-wide wait (seconds)
         const char* e = getenv("GRP_STREAM_WAIT_S");
@@ -2778,11 +2777,11 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
     const uint32_t code = __atomic_load_n(&sl.h_ack[1], __ATOMIC_ACQUIRE);
     const uint32_t applied = __atomic_load_n(&sl.h_ack[0], __ATOMIC_ACQUIRE);
     if ((code == 2 || code == 1) && sl.d_dbg) { // developer: where every workgroup was
-      std::vector<uint32_t> st(4096);
+      std::vector<uint32_t> st(8192);
       if (hipMemcpy(st.data(), sl.d_dbg, st.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
         std::string line;
         for (size_t i = 0; i < st.size(); ++i) {
-          if (i < 2048 && st[i] != 0 && ((st[i] >> 28) != 5u || (st[i] & 0xFFFFu) != ((sl.cmd_seq << 1) & 0xFFFFu))) {
+          if (i < 1024 && st[i] != 0 && ((st[i] >> 28) != 5u || (st[i] & 0xFFFFu) != ((sl.cmd_seq << 1) & 0xFFFFu))) {
             char b[64];
             snprintf(b, sizeof(b), " %zu:%08x", i, st[i]);
             line += b;
@@ -2805,18 +2804,31 @@ grp_classify_stream_end(grp_ctx* c, uint32_t slot, uint32_t* reads_decided)
           line += b;
           for (uint32_t q = grid >= 6 ? grid - 6 : 0; q < grid; ++q) {
             const uint32_t w = late[q].second;
-            snprintf(b, sizeof(b), "; wg %u %.1f us (came to the event %.1f us earlier, %s)", w, late[q].first * 1e-2, (st[2048 + w] - st[1024 + w]) * 1e-2, st[3072 + w] == 2 ? "tile suspended" : "idle");
+            snprintf(b, sizeof(b), "; wg %u %.1f us (came to the event %.1f us earlier; began %.1f us before that; xcc %u se %u cu %u)", w, late[q].first * 1e-2, (st[2048 + w] - st[1024 + w]) * 1e-2,
+                     (st[1024 + w] - st[4096 + w]) * 1e-2, st[5120 + w] >> 16, (st[5120 + w] >> 13) & 7u, (st[5120 + w] >> 8) & 15u);
             line += b;
           }
+          uint32_t t_start = 0xFFFFFFFFu, t_last = 0;
+          for (uint32_t i = 0; i < grid; ++i) {
+            t_start = std::min(t_start, st[4096 + i]);
+          }
+          uint32_t n_late = 0;
+          for (uint32_t i = 0; i < grid; ++i) {
+            t_last = std::max(t_last, st[4096 + i] - t_start);
+            n_late += (st[4096 + i] - t_start) > 100000u ? 1u : 0u; // more than a millisecond behind the first
+          }
+          snprintf(b, sizeof(b), " | the last workgroup began %.1f us behind the first, %u of them more than 1 ms behind", t_last * 1e-2, n_late);
+          line += b;
         }
+        fprintf(stderr, "  last streaming launch: %u workgroups, %u bytes of LDS each\n", c->dbg_stream_grid, c->dbg_stream_lds);
         fprintf(stderr, "  window: reads [%u, %u), %llu tiles; command: read %u tiles [%u, %u) block %u first id %u offset %u resume read %u tile %u decided base %u gen %u\n", sl.first, sl.first + sl.count, (unsigned long long)sl.nt,
                 sl.h_cmd[1], sl.h_cmd[2], sl.h_cmd[3], sl.h_cmd[4], sl.h_cmd[5], sl.h_cmd[6], sl.h_cmd[7], sl.h_cmd[8], sl.h_cmd[9], sl.h_cmd[10]);
-        fprintf(stderr, "grp_classify_stream_end: code %u, first to give up: wait %u, workgroup %u, %u groups had arrived; workgroups not inside insert %u (index:state):%s\n", code, sl.h_ack[14], sl.h_ack[15] >> 16, sl.h_ack[15] & 0xFFFFu, sl.cmd_seq, line.c_str());
+        fprintf(stderr, "grp_classify_stream_end: code %u, first to give up: wait %u, workgroup %u, %u of the insert's %u workgroups had arrived; workgroups not inside insert %u (index:state):%s\n", code, sl.h_ack[14] & 0xFFFFu, sl.h_ack[14] >> 16, sl.h_ack[15] & 0xFFFFu, sl.h_ack[15] >> 16, sl.cmd_seq, line.c_str());
       }
     }
     if (code == 2) {
-      return set_err(c, GRP_ERR_STATE, "grp_classify_stream_end: a grid-wide wait timed out in the middle of an insert (the ID array may be inconsistent); first to give up: wait %u, workgroup %u, %u groups had arrived",
-                     sl.h_ack[14], sl.h_ack[15] >> 16, sl.h_ack[15] & 0xFFFFu);
+      return set_err(c, GRP_ERR_STATE, "grp_classify_stream_end: a grid-wide wait timed out in the middle of an insert (the ID array may be inconsistent); first to give up: wait %u, workgroup %u, %u of the insert's %u workgroups had arrived",
+                     sl.h_ack[14] & 0xFFFFu, sl.h_ack[14] >> 16, sl.h_ack[15] & 0xFFFFu, sl.h_ack[15] >> 16);
     }
     if (code == 3) {
       // The parked window was told nothing for its idle limit (16 x GRP_STREAM_WAIT_S: a host stopped by a
