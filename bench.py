@@ -695,6 +695,15 @@ def main():
         tail_reads = sum(s[0] for s in slices[head_n:])
         tail_s = sum(s[1] for s in slices[head_n:])
         tail_ins = sum(s[2] for s in slices[head_n:])
+        # what an insert costs the steady state: least squares of the slices' seconds on (reads, inserts) — the device
+        # time the stream loses per insert, not the host's wait for the first record behind one (tools/scale_model.py)
+        steady_fit = None
+        if len(slices) - head_n >= 8 and tail_ins > 0:
+            a_ = np.array([[s_[0], s_[2]] for s_ in slices[head_n:]], dtype=np.float64)
+            b_ = np.array([s_[1] for s_ in slices[head_n:]], dtype=np.float64)
+            sol_ = np.linalg.lstsq(a_, b_, rcond=None)[0]
+            steady_fit = {"s_per_read": float(sol_[0]), "s_per_insert": float(sol_[1]), "slices": int(len(b_)),
+                          "what": "least squares of the steady-state slices' seconds on their reads and inserts"}
         out = {
             "metric": "reads/s through GoldRush-Path (hash + miBF query)",
             "value": reads_done / dt,
@@ -749,7 +758,7 @@ def main():
             "phases": {"slice_reads": PHASE_SLICE,
                        "head": {"reads": head_reads, "seconds": head_s, "reads_per_s": head_reads / head_s if head_s > 0 else None, "inserts": head_ins,
                                 "definition": "slices before the first %d-read slice with an insert rate < 1 %%" % PHASE_SLICE},
-                       "steady": {"reads": tail_reads, "seconds": tail_s, "reads_per_s": tail_reads / tail_s if tail_s > 0 else None, "inserts": tail_ins}},
+                       "steady": {"reads": tail_reads, "seconds": tail_s, "reads_per_s": tail_reads / tail_s if tail_s > 0 else None, "inserts": tail_ins, "fit": steady_fit}},
             "aux": {"counters": {k_: int(st1[k_]) for k_ in ("valid_reads", "total_tiles", "assigned_tiles", "unassigned_tiles", "queries", "hits", "misses", "inserted_bases",
                                                              "ids_inserted", "reads_committed", "inserts")},  # the run's result: the same for every N, mode and switch
                     "pop": int(pop),
@@ -783,12 +792,12 @@ def main():
         acc = {
             "batches_second_query_of_tiles_without_records": vs_["queried"] * per_tile,       # the confirmation of the reads / tiles a batch did not insert
             "tiles_redone_with_the_worst_case_table_or_given_up_by_a_patch": (vs_["window_flagged"] + vs_["flagged"]) * per_tile,
-            "streaming_tiles_queried_again_behind_an_insert": (sk_["tiles_redone_dirty"] + sk_["tiles_redone_lost"]) * per_tile + sk_["in_progress_restarted"] * per_tile // 2,
+            "streaming_tiles_queried_again_behind_an_insert": (sk_["tiles_redone_dirty"] + sk_["tiles_redone_lost"]) * per_tile,
         }
         acc["first_queries_thrown_away_and_windows_abandoned"] = max(executed - useful - sum(acc.values()), 0)  # batches taken back, the reads queried ahead of a batch that ended early, pipelined windows abandoned at an insert
         out["aux"]["probe_accounting"] = {"useful": useful, "executed": executed, "executed_over_useful": executed / useful if useful else None, "beyond_useful": acc,
                                           "share_of_useful": {k_: v_ / useful for k_, v_ in acc.items()} if useful else None,
-                                          "note": "tile counts x tile x h (a read's clipped last tile counted whole); streaming: grp_debug_stream_stats — tiles finished in front of an in-launch insert whose probes met a changed slot or whose fingerprints were gone, half a tile per tile in progress that started over"}
+                                          "note": "tile counts x tile x h (a read's clipped last tile counted whole); streaming: grp_debug_stream_stats — tiles finished in front of an in-launch insert whose probes met a changed slot or whose fingerprints were gone"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(rs, eng, cls, out["phases"], silver, n_reads, m, pop, seeds, k, tile, G, kept=cls.kept_commits() if witness else None)
             check = out["cpu_baseline"].pop("oracle_check", None)

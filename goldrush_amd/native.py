@@ -619,7 +619,8 @@ class Engine:
         """what the in-launch inserts of the streaming windows did with the tiles queried behind the inserting read"""
         out = np.zeros(8, dtype=np.uint64)
         self._check(self.lib.grp_debug_stream_stats(self._h, _ptr(out)))
-        return dict(zip(("coop_refused", "tiles_kept", "tiles_redone_dirty", "tiles_redone_lost", "in_progress_went_on", "in_progress_restarted", "inserts_kept_nothing", "inserts_kept"), (int(x) for x in out)))
+        names = ("coop_refused", "tiles_kept", "tiles_redone_dirty", "tiles_redone_lost", None, None, "inserts_kept_nothing", "inserts_kept")
+        return {k: int(x) for k, x in zip(names, out) if k}
 
     def batch_undo(self, from_read: int, id_floor: int):
         """takes back the inserts of reads >= from_read (batch index); id_floor = the first ID read from_read could allocate"""

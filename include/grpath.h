@@ -602,8 +602,9 @@ int grp_debug_verify_stats(const grp_ctx* ctx, uint64_t out[12]);
 /* What the in-launch inserts of the streaming windows ended so far (since grp_create) did with the tiles the launches had
  * queried behind the inserting read (round 6): [1] finished tiles kept (no probe of theirs read a slot the insert changed),
  * [2] finished tiles queried again because one did, [3] finished tiles queried again because their fingerprints were
- * gone, [4] tiles in progress that went on, [5] that started over, [6] inserts that kept nothing (no LDS room for
- * fingerprints, or a parked window), [7] inserts that kept; [0] resumable windows whose cooperative launch was refused */
+ * gone (it keeps the last two tiles of every workgroup), [4], [5] unused (0: tiles are not suspended between passes),
+ * [6] inserts that kept nothing (no LDS room for fingerprints in the window's geometry, or the list arena three quarters
+ * full), [7] inserts that kept; [0] resumable windows whose cooperative launch was refused */
 int grp_debug_stream_stats(const grp_ctx* ctx, uint64_t out[8]);
 
 /* 1: the library was built with GRP_DEV_HOOKS (make DEV=1): the measurement-only prototypes of include/grpath_dev.h are

@@ -31,7 +31,10 @@ import sys
 
 SPEC = 0.11                # speculative stripes thrown away per insert, share of the query work (2 ranks on one GPU)
 T_INSERT_STRIPED = 0.45e-3  # s per insert when the launch ends and the insert kernels run between launches (r03: 424 us + restart)
-T_INSERT_PARKED = 0.238e-3  # s per insert applied inside a parked launch (r03 measurement, one rank)
+T_INSERT_PARKED = 0.238e-3  # s per insert applied inside a parked launch when the line carries no fit (lines older than round 6; r03 measurement, one rank)
+# Round 6: the line says what an insert costs its steady state (phases.steady.fit.s_per_insert: least squares of the slices'
+# seconds on reads and inserts) — the device time lost per insert, which is what the model's term is; the 238 us above is the
+# host's wait for the first record behind an insert, the larger number (tools/stream_insert_cost.py reports both).
 T_EXCHANGE = 30e-6         # s per /dev/shm all-gather of decision records
 T_WINDOW_END = 100e-6      # s the GPUs idle at the end of a window of several ranks that applies inserts itself: it leaves on the host's word (host lag: one exchange + the commits of a group)
 WINDOW_READS = 8192        # reads per streaming window and rank count unit (Classifier::window_plan: max_window x min(N, 8) when the ranks' windows take inserts)
@@ -58,7 +61,8 @@ def model(d, park=True, pair=None):
     head_ins, steady_ins = ph["head"]["inserts"], ph["steady"]["inserts"]
     batches = max(t["batches"], 1)
     # steady state: everything but the inserts is query work of persistent launches
-    t_ins1 = T_INSERT_PARKED
+    fit = ph["steady"].get("fit") or {}
+    t_ins1 = fit.get("s_per_insert") if fit.get("s_per_insert") and fit["s_per_insert"] > 0 else T_INSERT_PARKED
     steady_query = max(steady_s - steady_ins * t_ins1, 0.0)
     # head: what every rank repeats on its replica is timed per kernel family (HIP events); the rest of the head's
     # wall time is the batches' query work (first query, tiles queried again) — the part that is shared
@@ -78,7 +82,7 @@ def model(d, park=True, pair=None):
             if park:
                 # an insert the launches apply themselves: the parked launch's own cost, one exchange round for the record
                 # to reach the other ranks and their command to reach their launches; the rest ends the launches as before
-                t_ins = share * (T_INSERT_PARKED + 2 * T_EXCHANGE) + (1 - share) * T_INSERT_STRIPED
+                t_ins = share * (t_ins1 + 2 * T_EXCHANGE) + (1 - share) * T_INSERT_STRIPED
                 windows = reads_steady / (WINDOW_READS * min(n, 8))
                 steady_n = steady_query * (1 + spec) / n + steady_ins * t_ins + windows * T_WINDOW_END
             else:
@@ -93,8 +97,9 @@ def model(d, park=True, pair=None):
         r["efficiency"] = r["speedup"] / r["gpus"]
     terms = {"steady_query_s": steady_query, "steady_inserts": steady_ins, "head_query_s": head_query, "head_verify_s": head_verify, "head_decide_s": head_decide,
              "head_replicated_rest_s": head_rest, "batches": batches, "speculative_share_of_query_work": spec, "inserts_taken_by_the_launches_share": share if park else 0.0,
-             "insert_cost_s": (share * (T_INSERT_PARKED + 2 * T_EXCHANGE) + (1 - share) * T_INSERT_STRIPED) if park else T_INSERT_STRIPED,
-             "amdahl_replicated_s_at_any_n": head_verify + head_decide + head_rest + steady_ins * ((share * (T_INSERT_PARKED + 2 * T_EXCHANGE) + (1 - share) * T_INSERT_STRIPED) if park else T_INSERT_STRIPED),
+             "insert_cost_s": (share * (t_ins1 + 2 * T_EXCHANGE) + (1 - share) * T_INSERT_STRIPED) if park else T_INSERT_STRIPED,
+             "amdahl_replicated_s_at_any_n": head_verify + head_decide + head_rest + steady_ins * ((share * (t_ins1 + 2 * T_EXCHANGE) + (1 - share) * T_INSERT_STRIPED) if park else T_INSERT_STRIPED),
+             "in_launch_insert_s": t_ins1, "in_launch_insert_from": "the line's steady-state fit" if t_ins1 != T_INSERT_PARKED else "named constant",
              "constants_from": pair["from"] if pair else "named constants (no --ranks pair given)"}
     fill = {"fill_s_n1": a["fill_s"], "rank_build_s": a.get("finalize_s"), "note": "hashing sharded by reads (/ N), merge 2 x (N-1)/N bit vectors over xGMI, rank build replicated; not in the metric"}
     return {"model": "replicated miBF, query work sharded (DESIGN.md 7)", "inserts_inside_the_ranks_launches": park, "terms": terms, "rows": rows, "fill": fill}

@@ -9,8 +9,7 @@ rounds 3 - 5's form, everything behind the read queried again) — with the clas
 (GRP_TRACE_ABORT=2) and reports, per form:
   latency_us        from the insert record to the first record behind it, on the host's clock (median / mean / p90)
   phases_us         workgroup 0 inside the launch: collect, first grid-wide wait, apply, second wait
-  per insert        tiles kept / queried again (a probe's slot changed) / queried again (fingerprints gone) /
-                    in progress and gone on / in progress and started over   (grp_debug_stream_stats)
+  per insert        tiles kept / queried again (a probe's slot changed) / queried again (fingerprints gone)   (grp_debug_stream_stats)
   steady state      reads/s, executed / useful probes
 and the DEVICE TIME an insert costs: (steady-state seconds of the form - seconds the same probes take at the rate of
 the launches without inserts) / inserts — what the stream loses per insert, not how long the host waits for one.
@@ -42,7 +41,7 @@ def run(keep, args):
         "executed_over_useful_probes": d["aux"]["kernel_stats"]["query"]["units"] / (d["aux"]["counters"]["hits"] + d["aux"]["counters"]["misses"]),
         "latency_us": ({"n": len(lat), "median": statistics.median(lat), "mean": statistics.fmean(lat), "p90": sorted(lat)[int(0.9 * (len(lat) - 1))], "min": min(lat)} if lat else None),
         "phases_us_workgroup0": ({k: statistics.fmean(p[i] for p in ph) for i, k in enumerate(("collect", "first_wait", "apply", "second_wait"))} if ph else None),
-        "per_insert": {k: sk[k] / n for k in ("tiles_kept", "tiles_redone_dirty", "tiles_redone_lost", "in_progress_went_on", "in_progress_restarted")},
+        "per_insert": {k: sk[k] / n for k in ("tiles_kept", "tiles_redone_dirty", "tiles_redone_lost")},
         "inserts_kept_nothing": sk["inserts_kept_nothing"], "inserts_kept": sk["inserts_kept"],
         "counters": d["aux"]["counters"], "query_Gprobes_per_s": d["aux"]["query_Gprobes_per_s"], "workload": d["config"]["workload"],
     }
