@@ -330,6 +330,8 @@ def main():
     ap.add_argument("--silver", type=int, default=-1, help="silver-path mode with this many paths (-M); default: the config's")
     ap.add_argument("--stream-batch", type=int, default=-1, help="reads per resident batch (0: all resident; default: 2 M when the packed reads exceed 100 GB)")
     ap.add_argument("--max-window", type=int, default=0)
+    ap.add_argument("--filter-scale", type=float, default=1.0, help="developer: the miBF's size x this (what -x / ntCard would have said for a larger genome): the same reads at another occupancy — "
+                    "not the BASELINE workload, the line says so")
     ap.add_argument("--repeat-frac", type=float, default=0.0, help="share of the genome made of repeat families (2-6 kb units at 1-5 %% divergence, ~30 / ~1 000 / ~10 000 copies; include/grpath_synth.h); "
                     "0 = the headline workload's uniform genome, where two reads share k-mers only where they overlap.  Not the headline: the line's config says so and aux.repeats sums up what the speculation did")
     ap.add_argument("--len-sigma", type=float, default=0.25, help="sigma of the log-normal read lengths (mean 25 kb, floor 20 kb); 0.25 = the headline workload (no read above ~64 kb), "
@@ -406,6 +408,8 @@ def main():
     hl = host.load()
     seeds = host.make_seed_pattern(PRESET, k, w, h)
     m = hl.gr_calc_optimal_size(hl.gr_hash_universe(w, G, h), 1, 0.1)
+    if a.filter_scale != 1.0:
+        m = int(m * a.filter_scale) // 64 * 64
 
     per_step = a.batch if a.batch else n_reads // a.steps
     if per_step < 1 or per_step * a.steps > n_reads:
@@ -722,6 +726,7 @@ def main():
                            "silver-path mode, %d paths (the run ends behind the last path: reads_timed = reads consumed)" % max_paths if silver else "golden-path mode"),
                        "reads": n_reads, "reads_timed": reads_done, "reads_per_step": per_step, "genome": G, "filter_bits": m, "pop": pop,
                        **({"repeat_frac": a.repeat_frac, "NOT_THE_HEADLINE_WORKLOAD": "repeat-rich genome (--repeat-frac)"} if a.repeat_frac > 0 else {}),
+                       **({"filter_scale": a.filter_scale, "occupancy": pop / m, "NOT_THE_BASELINE_FILTER_SIZE": "miBF of %g x the size -x gives (--filter-scale)" % a.filter_scale} if a.filter_scale != 1.0 else {"occupancy": pop / m}),
                        "read_lengths": {"sigma": a.len_sigma, "mean": float(rs.plan[1].mean()), "max": int(rs.plan[1].max()), "reads_over_64_tiles": int((rs.plan[1] >= 65 * tile).sum())},
                        "parallelism": ("one GPU: windows committed as batches where >= ~1 % of the reads insert, streaming windows elsewhere" if world == 1 else "replicated miBF on %d GPUs: batches on every rank where >= ~1 %% of the reads insert, streaming windows striped over the ranks elsewhere (32-B decisions all-gathered per stripe group)" % world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
