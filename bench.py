@@ -427,7 +427,8 @@ def main():
     eng = native.Engine(k, h, tile, m, seeds, device=local_rank)
     # the -o the filter size was computed for: the engine allocates the phase-2 tables beside the fill (grp_set_occupancy_hint;
     # a hint — grp_finalize measures the occupancy as ever), what the goldrush-path binary does with its own -o
-    eng.set_occupancy_hint(0.1)
+    if not a.share_gpu:  # (ranks sharing ONE device — the plumbing test of a one-GPU box — have no room for two sets of tables beside two bit vectors at C2's size)
+        eng.set_occupancy_hint(0.1)
     rs.eng = eng
     rs.get(0)
     t_synth = time.time() - t0
