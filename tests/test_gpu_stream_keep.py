@@ -56,3 +56,46 @@ def test_the_three_forms_of_keeping_decide_alike():
     assert got[0]["stats"]["tiles_kept"] == 0 and got[0]["stats"]["inserts_kept"] == 0 and got[0]["stats"]["inserts_kept_nothing"] == got[0]["inserts"]
     assert got[2]["stats"]["tiles_kept"] > 0 and got[1]["stats"]["tiles_kept"] > 0
     assert got[2]["stats"]["tiles_kept"] >= got[1]["stats"]["tiles_kept"]
+
+
+def test_a_device_shared_with_other_kernels_times_no_insert_out(oracle, native):
+    """The waits of an in-launch insert are for the workgroups that have BEGUN (stream_register), not for the grid: while
+    another stream keeps the CUs busy (large GEMMs through torch), the window's workgroups become resident a few at a time —
+    some of them in the middle of an insert.  Rounds 3 - 5 waited for the grid: such an insert timed out (2 s) and went back
+    to the host.  Here a timed-out wait ends the launch, and the scenario fails on the record that never comes."""
+    import threading
+
+    torch = pytest.importorskip("torch")
+    import stream_keep_scenario as sc
+    from oracle_engine import serial_reference
+
+    seeds = default_seeds(sc.H)
+    reads = sc.make_stream()
+    m = oracle.load().orc_calc_optimal_size(2_500_000, 1, 0.1)
+    exp, mf_ref = serial_reference(oracle, m, seeds, sc.TILE, sc.K, reads, block=sc.BLOCK)
+    stop = threading.Event()
+    launched = [0]
+
+    def hammer():
+        torch.cuda.set_device(0)
+        side = torch.cuda.Stream()
+        a = torch.randn(6144, 6144, device="cuda", dtype=torch.float16)
+        with torch.cuda.stream(side):
+            while not stop.is_set():
+                for _ in range(3):
+                    a @ a
+                    launched[0] += 1
+                side.synchronize()
+
+    t = threading.Thread(target=hammer, daemon=True)
+    t.start()
+    try:
+        r = sc.run(native, seeds, m, reads, limit=60.0)
+    finally:
+        stop.set()
+        t.join(timeout=120)
+    assert not t.is_alive()
+    assert launched[0] > 0
+    assert [q[:8] for q in r["records"]] == exp
+    assert np.array_equal(r["ids"], mf_ref.ids()) and np.array_equal(r["counts"], mf_ref.counts())
+    assert r["stats"]["inserts_kept"] + r["stats"]["inserts_kept_nothing"] == r["inserts"]
