@@ -643,15 +643,12 @@ launch_query(grp_ctx* c, const grp_reads* r, uint64_t n_launch, uint64_t t0, con
       return rc;
     }
     if (stream_ctl && stream_ctl->ctl) {
-      // A window that applies inserts itself: its workgroups wait for each other inside the launch, so ALL of them
-      // must be resident at once.  The grid is sized from the occupancy query below; a cooperative launch makes the
-      // runtime guarantee it (or refuse: another process on the device) instead of inferring it.
+      // A window that applies inserts itself: its workgroups wait for each other inside the launch.  The grid is sized
+      // from the occupancy query below and launched cooperatively — the runtime checks that it fits the device (or
+      // refuses: another process on it).  That is a check of sizes, not of residency: now and then a few
+      // workgroups begin only when others leave, so the waits count the workgroups that have begun (stream_register).
       // GRP_ERR_BUSY: refused — the caller begins the window in its classic form (it ends where it parks).
-      static const bool coop_off = [] { // developer switch
-        const char* e = getenv("GRP_STREAM_COOP");
-        return e && !strcmp(e, "off");
-      }();
-      if (!coop_off) {
+      {
         DevFilter a_f = c->f;
         DevReads a_rd = r->dev;
         const DevSeeds* a_sd = c->d_seeds;

@@ -6,7 +6,7 @@ sb=${2:-100000}
 run() { env "$@" python3 bench.py --config C4 --reads $reads --stream-batch $sb --steps 4 --no-cpu-baseline --no-pipeline-shaped 2>/dev/null | grep '^{' | tail -1; }
 run X=1 > /tmp/c1.json
 run X=2 > /tmp/c2.json
-run GRP_VERIFY_REDO=host > /tmp/c3.json
+run GRP_BATCH_OVERLAP=8 > /tmp/c3.json
 run GRP_BATCH_VERIFY=off > /tmp/c4.json
 run GRP_BATCH=off > /tmp/c5.json
 python3 - <<'PY'
