@@ -1445,8 +1445,21 @@ prealloc_start(grp_ctx* c)
   prealloc_sizes(c->f.m, c->pre.occupancy, nb, fc);
   const int device = c->device;
   grp_ctx::Prealloc* p = &c->pre;
-  c->pre.worker = std::thread([p, nb, fc, device] {
+  const uint64_t bv_bytes = c->f.m / 8;
+  c->pre.worker = std::thread([p, nb, fc, device, bv_bytes] {
     if (hipSetDevice(device) != hipSuccess) {
+      return;
+    }
+    // Only where the tables fit BESIDE what phase 1 may still need: two more bit vectors (the ranks' merge,
+    // grp_bv_merge_ranks) and 16 GB for the batches of reads that pass through — C2 has the room, C4's 246 GB of tables
+    // have not (grp_finalize then allocates when the fill is through, as it did until round 5).
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    const uint64_t need = nb * (uint64_t)GRP_UNIT_U4 * 16 + fc * sizeof(ulonglong2);
+    if ((uint64_t)free_b < need + 2 * bv_bytes + (16ull << 30)) {
       return;
     }
     uint4* u = nullptr;

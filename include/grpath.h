@@ -222,7 +222,9 @@ int grp_finalize(grp_ctx* ctx, uint64_t* pop);
  * grp_finalize used to spend with the device idle (the reference's own setup / allocation timers:
  * goldrush_path.cpp:1180-1208).  A hint only: grp_finalize measures the occupancy as before and
  * allocates again where the tables prepared for the hint are too small; the filter is the same
- * bit for bit either way.  0 < occupancy < 1.
+ * bit for bit either way.  Nothing is prepared where the tables do not fit beside two more bit
+ * vectors (a merge of several ranks' fills) and 16 GB of reads in flight (C4's 246 GB on a 288 GB
+ * device): grp_finalize allocates then.  0 < occupancy < 1.
  */
 int grp_set_occupancy_hint(grp_ctx* ctx, double occupancy);
 /* seconds grp_finalize spent by part (diagnostics of the line above): [0] popcount + wait for the fill, [1] waiting for /
