@@ -34,8 +34,14 @@ roofline: the query kernel.  `achieved` = ALGORITHMIC bytes (128 
           bytes that actually move (`moved_*`, from the committed rocprofv3 PMC pass:
           one 64-B bucket per probe) and the probe rate against the measured
           random-64-B-line ceiling of the memory system (profiles/*gather_ceiling.json).
+roofline_insert / roofline_fill: k_batch_collect + apply (2 x 128 B per record slot) and k_fill
+          (128 B per probe; `traffic` = its PMC read + write bytes).
 cpu_baseline: the CPU oracle (restatement of the reference) on bounded samples of the
           same workload, rank 0, N=1 only.
+aux     : end_to_end (fill + grp_finalize + the timed region: the whole goldrush-path run on resident
+          reads), probe_accounting (executed against useful probes, the excess attributed), stream_keep
+          (what the streaming windows kept across their in-launch inserts), phases.steady.fit (seconds
+          per read and per insert over the steady-state slices), pipeline_shaped, oracle_check.
 """
 from __future__ import annotations
 
